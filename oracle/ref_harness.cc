@@ -1,0 +1,429 @@
+// oracle/ref_harness.cc -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// A thin extern "C" driver around the *unmodified* reference sources of
+// wizardyesterday/HackRfDiags, compiled where they lie under /root/reference by
+// oracle/Makefile into oracle/_ref/libhrfd_ref.so (git-ignored; never committed;
+// no reference source is copied into this repository).  It exists so that
+//   * oracle/hrfd_oracle.c (our own CPU restatement) can be pinned against the
+//     real reference on arbitrary inputs (tests/test_oracle_vs_ref.py),
+//   * tests/golden/make_golden.py can generate golden vectors, and
+//   * bench.py can time the reference's own CPU chain as `cpu_baseline`
+//     (kind "reference").
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+// the resulting library.
+//
+// The reference classes driven here:
+//   IqDataProcessor::acceptIqData       radioDiags/src_diags/IqDataProcessor.cc:926
+//   {Am,Fm,WbFm,Ssb}Demodulator::acceptIqData  radioDiags/*Demodulator/*.cc
+//   SsbModulator::acceptData            radioDiags/SsbModulator/SsbModulator.cc:455
+//   Nco::run / Nco::runFast             radioDiags/Nco/Nco.cc:186,222
+//   Decimator_int16 / FirFilter_int16 / Interpolator_int16 / FirFilter / IirFilter
+//
+// The reference links against two symbols of its host application; we supply
+// them exactly as SURVEY.md section 8(c) describes.
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+
+// The harness (and only the harness) peeks at private members to dump
+// intermediate streams (decimatedData, demodulatedData).  The reference
+// translation units themselves are compiled untouched.
+#define private public
+#include "IqDataProcessor.h"
+#include "SsbModulator.h"
+#include "Nco.h"
+#include "Interpolator_int16.h"
+#include "FirFilter_int16.h"
+#include "FirFilter.h"
+#include "IirFilter.h"
+#include "DbfsCalculator.h"
+#undef private
+
+// Symbols the reference expects from radioDiags (Radio.cc:15, diagUi.cc:2881).
+uint32_t radio_adjustableReceiveGainInDb = 0;
+void nprintf(FILE *, const char *, ...) {}
+
+namespace {
+
+struct PcmSink
+{
+  std::vector<int16_t> pcm;
+  uint32_t callbacks;
+};
+
+// The reference's PCM callback carries no context pointer, so the harness
+// routes it through a "current sink" that is set around every call.
+thread_local PcmSink *g_sink = nullptr;
+
+void pcmCallback(int16_t *bufferPtr, uint32_t bufferLength)
+{
+  if (g_sink != nullptr)
+  {
+    g_sink->pcm.insert(g_sink->pcm.end(), bufferPtr, bufferPtr + bufferLength);
+    g_sink->callbacks++;
+  }
+}
+
+struct RefRx
+{
+  IqDataProcessor *proc;
+  AmDemodulator *am;
+  FmDemodulator *fm;
+  WbFmDemodulator *wbfm;
+  SsbDemodulator *ssb;
+  PcmSink sink;
+};
+
+struct RefDemod
+{
+  int mode;
+  AmDemodulator *am;
+  FmDemodulator *fm;
+  WbFmDemodulator *wbfm;
+  SsbDemodulator *ssb;
+  PcmSink sink;
+};
+
+uint32_t drain(PcmSink &sink, int16_t *pcmOut, uint32_t pcmCapacity)
+{
+  uint32_t n = (uint32_t)sink.pcm.size();
+  if (n > pcmCapacity)
+  {
+    n = pcmCapacity;
+  }
+  if (n > 0 && pcmOut != nullptr)
+  {
+    memcpy(pcmOut, sink.pcm.data(), n * sizeof(int16_t));
+  }
+  sink.pcm.clear();
+  return n;
+}
+
+} // namespace
+
+extern "C" {
+
+//---------------------------------------------------------------- rx, outer
+void *ref_rx_create(void)
+{
+  static char ip[] = "127.0.0.1";
+  RefRx *h = new RefRx;
+  h->sink.callbacks = 0;
+  h->proc = new IqDataProcessor(ip, 8001);
+  h->am = new AmDemodulator(pcmCallback);
+  h->fm = new FmDemodulator(pcmCallback);
+  h->wbfm = new WbFmDemodulator(pcmCallback);
+  h->ssb = new SsbDemodulator(pcmCallback);
+  // Same wiring as Radio.cc:179-203.
+  h->proc->setAmDemodulator(h->am);
+  h->proc->setFmDemodulator(h->fm);
+  h->proc->setWbFmDemodulator(h->wbfm);
+  h->proc->setSsbDemodulator(h->ssb);
+  h->proc->disableIqDump();
+  return h;
+}
+
+void ref_rx_destroy(void *hv)
+{
+  RefRx *h = (RefRx *)hv;
+  delete h->proc;
+  delete h->am;
+  delete h->fm;
+  delete h->wbfm;
+  delete h->ssb;
+  delete h;
+}
+
+// mode: IqDataProcessor::demodulatorType {None=0,Am=1,Fm=2,WbFm=3,Lsb=4,Usb=5}
+void ref_rx_set_mode(void *hv, int mode)
+{
+  RefRx *h = (RefRx *)hv;
+  h->proc->setDemodulatorMode((IqDataProcessor::demodulatorType)mode);
+}
+
+void ref_rx_set_gain(void *hv, int mode, float gain)
+{
+  RefRx *h = (RefRx *)hv;
+  switch (mode)
+  {
+    case 1: h->am->setDemodulatorGain(gain); break;
+    case 2: h->fm->setDemodulatorGain(gain); break;
+    case 3: h->wbfm->setDemodulatorGain(gain); break;
+    case 4:
+    case 5: h->ssb->setDemodulatorGain(gain); break;
+    default: break;
+  }
+}
+
+void ref_rx_set_threshold(void *hv, int32_t threshold)
+{
+  RefRx *h = (RefRx *)hv;
+  h->proc->setSignalDetectThreshold(threshold);
+}
+
+void ref_set_receive_gain_db(uint32_t gainInDb)
+{
+  radio_adjustableReceiveGainInDb = gainInDb;
+}
+
+// One IqDataProcessor::acceptIqData call.  Returns the number of PCM samples
+// the demodulator handed to the callback (0 when squelched or mode None).
+// iq256Out (optional, >= byteCount/8 bytes) receives decimatedData after the
+// Fs/4 mix; magnitudeOut (optional) the squelch's block-mean magnitude.
+uint32_t ref_rx_process(void *hv,
+                        const int8_t *bufferPtr,
+                        uint32_t byteCount,
+                        int16_t *pcmOut,
+                        uint32_t pcmCapacity,
+                        uint32_t *magnitudeOut,
+                        int8_t *iq256Out)
+{
+  RefRx *h = (RefRx *)hv;
+  std::vector<int8_t> scratch(bufferPtr, bufferPtr + byteCount);
+  g_sink = &h->sink;
+  h->proc->acceptIqData(0, scratch.data(), byteCount);
+  g_sink = nullptr;
+  if (magnitudeOut != nullptr)
+  {
+    *magnitudeOut = h->proc->squelchPtr->getSignalMagnitude();
+  }
+  if (iq256Out != nullptr)
+  {
+    memcpy(iq256Out, h->proc->decimatedData, byteCount / 8);
+  }
+  return drain(h->sink, pcmOut, pcmCapacity);
+}
+
+// WBFM only: copy the float stream produced by the last demodulateSignal call.
+void ref_rx_wbfm_float_stream(void *hv, float *out, uint32_t count)
+{
+  RefRx *h = (RefRx *)hv;
+  memcpy(out, h->wbfm->demodulatedData, count * sizeof(float));
+}
+
+//---------------------------------------------------------------- rx, inner
+void *ref_demod_create(int mode)
+{
+  RefDemod *h = new RefDemod;
+  h->mode = mode;
+  h->sink.callbacks = 0;
+  h->am = nullptr; h->fm = nullptr; h->wbfm = nullptr; h->ssb = nullptr;
+  switch (mode)
+  {
+    case 1: h->am = new AmDemodulator(pcmCallback); break;
+    case 2: h->fm = new FmDemodulator(pcmCallback); break;
+    case 3: h->wbfm = new WbFmDemodulator(pcmCallback); break;
+    case 4: h->ssb = new SsbDemodulator(pcmCallback);
+            h->ssb->setLsbDemodulationMode(); break;
+    case 5: h->ssb = new SsbDemodulator(pcmCallback);
+            h->ssb->setUsbDemodulationMode(); break;
+    default: break;
+  }
+  return h;
+}
+
+void ref_demod_destroy(void *hv)
+{
+  RefDemod *h = (RefDemod *)hv;
+  delete h->am; delete h->fm; delete h->wbfm; delete h->ssb;
+  delete h;
+}
+
+void ref_demod_set_gain(void *hv, float gain)
+{
+  RefDemod *h = (RefDemod *)hv;
+  if (h->am) h->am->setDemodulatorGain(gain);
+  if (h->fm) h->fm->setDemodulatorGain(gain);
+  if (h->wbfm) h->wbfm->setDemodulatorGain(gain);
+  if (h->ssb) h->ssb->setDemodulatorGain(gain);
+}
+
+void ref_demod_reset(void *hv)
+{
+  RefDemod *h = (RefDemod *)hv;
+  if (h->am) h->am->resetDemodulator();
+  if (h->fm) h->fm->resetDemodulator();
+  if (h->wbfm) h->wbfm->resetDemodulator();
+  if (h->ssb) h->ssb->resetDemodulator();
+}
+
+void ref_demod_set_sideband(void *hv, int lsb)
+{
+  RefDemod *h = (RefDemod *)hv;
+  if (h->ssb)
+  {
+    if (lsb) h->ssb->setLsbDemodulationMode();
+    else h->ssb->setUsbDemodulationMode();
+  }
+}
+
+// X::acceptIqData(int8_t*,uint32_t) on 256 kS/s, already mixed, IQ (<= 32768 B).
+uint32_t ref_demod_process(void *hv,
+                           const int8_t *bufferPtr,
+                           uint32_t byteCount,
+                           int16_t *pcmOut,
+                           uint32_t pcmCapacity)
+{
+  RefDemod *h = (RefDemod *)hv;
+  std::vector<int8_t> scratch(bufferPtr, bufferPtr + byteCount);
+  g_sink = &h->sink;
+  if (h->am) h->am->acceptIqData(scratch.data(), byteCount);
+  if (h->fm) h->fm->acceptIqData(scratch.data(), byteCount);
+  if (h->wbfm) h->wbfm->acceptIqData(scratch.data(), byteCount);
+  if (h->ssb) h->ssb->acceptIqData(scratch.data(), byteCount);
+  g_sink = nullptr;
+  return drain(h->sink, pcmOut, pcmCapacity);
+}
+
+//---------------------------------------------------------------- tx
+void *ref_ssbmod_create(int lsb)
+{
+  SsbModulator *m = new SsbModulator();
+  if (lsb) m->setLsbModulationMode();
+  else m->setUsbModulationMode();
+  return m;
+}
+
+void ref_ssbmod_destroy(void *hv)
+{
+  delete (SsbModulator *)hv;
+}
+
+void ref_ssbmod_set_sideband(void *hv, int lsb)
+{
+  SsbModulator *m = (SsbModulator *)hv;
+  if (lsb) m->setLsbModulationMode();
+  else m->setUsbModulationMode();
+}
+
+void ref_ssbmod_reset(void *hv)
+{
+  ((SsbModulator *)hv)->resetModulator();
+}
+
+// SsbModulator::acceptData; sampleCount <= 512 (fixed member arrays).
+uint32_t ref_ssbmod_process(void *hv,
+                            const int16_t *pcmPtr,
+                            uint32_t sampleCount,
+                            int8_t *iqOut)
+{
+  SsbModulator *m = (SsbModulator *)hv;
+  std::vector<int16_t> scratch(pcmPtr, pcmPtr + sampleCount);
+  uint32_t outBytes = 0;
+  m->acceptData(scratch.data(), sampleCount, iqOut, &outBytes);
+  return outBytes;
+}
+
+//---------------------------------------------------------------- Nco
+void *ref_nco_create(float sampleRate, float frequency)
+{
+  return new Nco(sampleRate, frequency);
+}
+
+void ref_nco_destroy(void *hv)
+{
+  delete (Nco *)hv;
+}
+
+void ref_nco_set_frequency(void *hv, float frequency)
+{
+  ((Nco *)hv)->setFrequency(frequency);
+}
+
+void ref_nco_reset(void *hv)
+{
+  ((Nco *)hv)->reset();
+}
+
+void ref_nco_run(void *hv, int fast, uint32_t count, float *iOut, float *qOut)
+{
+  Nco *n = (Nco *)hv;
+  for (uint32_t k = 0; k < count; k++)
+  {
+    if (fast) n->runFast(&iOut[k], &qOut[k]);
+    else n->run(&iOut[k], &qOut[k]);
+  }
+}
+
+void ref_nco_tables(void *hv, float *sinOut, float *cosOut)
+{
+  Nco *n = (Nco *)hv;
+  memcpy(sinOut, n->Sin, sizeof(n->Sin));
+  memcpy(cosOut, n->Cos, sizeof(n->Cos));
+}
+
+//---------------------------------------------------------------- primitives
+// Quantised coefficients exactly as the reference constructors produce them.
+void ref_quantise(const float *coefficientsPtr, int count, int16_t *out)
+{
+  std::vector<float> c(coefficientsPtr, coefficientsPtr + count);
+  FirFilter_int16 f(count, c.data());
+  memcpy(out, f.coefficientStoragePtr, count * sizeof(int16_t));
+}
+
+// Decimator_int16 over a buffer; returns number of outputs.
+uint32_t ref_decimate(const float *coefficientsPtr, int taps, int factor,
+                      const int16_t *in, uint32_t count, int16_t *out)
+{
+  std::vector<float> c(coefficientsPtr, coefficientsPtr + taps);
+  Decimator_int16 d(taps, c.data(), factor);
+  uint32_t n = 0;
+  for (uint32_t k = 0; k < count; k++)
+  {
+    int16_t y;
+    if (d.decimate(in[k], &y))
+    {
+      out[n++] = y;
+    }
+  }
+  return n;
+}
+
+// Interpolator_int16 over a buffer; out must hold count*factor samples.
+void ref_interpolate(const float *coefficientsPtr, int taps, int factor,
+                     const int16_t *in, uint32_t count, int16_t *out)
+{
+  std::vector<float> c(coefficientsPtr, coefficientsPtr + taps);
+  Interpolator_int16 p(taps, c.data(), factor);
+  for (uint32_t k = 0; k < count; k++)
+  {
+    p.interpolate(in[k], &out[k * factor]);
+  }
+}
+
+// IirFilter over a buffer (float Direct-Form-I, IirFilter.cc:161).
+void ref_iir(const float *b, int nb, const float *a, int na,
+             const float *in, uint32_t count, float *out)
+{
+  std::vector<float> bb(b, b + nb), aa(a, a + na);
+  IirFilter f(nb, bb.data(), na, aa.data());
+  for (uint32_t k = 0; k < count; k++)
+  {
+    out[k] = f.filterData(in[k]);
+  }
+}
+
+// DbfsCalculator's decibel table (DbfsCalculator.cc:58-65), word length 7.
+void ref_dbfs_table(int32_t *out)
+{
+  DbfsCalculator c(7);
+  memcpy(out, c.dbTable, sizeof(c.dbTable));
+}
+
+int32_t ref_magnitude_to_dbfs(uint32_t magnitude)
+{
+  DbfsCalculator c(7);
+  return c.convertMagnitudeToDbFs(magnitude);
+}
+
+// The UB-dependent float -> int16 narrowing, as the host compiler does it.
+int16_t ref_float_to_int16(float value)
+{
+  volatile float v = value;
+  return (int16_t)v;
+}
+
+} // extern "C"

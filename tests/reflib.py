@@ -1,0 +1,483 @@
+"""ctypes access to the two CHECKERS: oracle/libhrfd_oracle.so (our CPU
+restatement) and oracle/_ref/libhrfd_ref.so (the reference's own sources,
+compiled by oracle/Makefile).  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libhrfd_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libhrfd_ref.so")
+REF_INTERP = os.path.join(ORACLE_DIR, "_ref", "interpolateSignal")
+
+NONE, AM, FM, WBFM, LSB, USB = range(6)
+MODE_NAMES = {AM: "am", FM: "fm", WBFM: "wbfm", LSB: "lsb", USB: "usb"}
+
+_i8p = C.POINTER(C.c_int8)
+_i16p = C.POINTER(C.c_int16)
+_u32p = C.POINTER(C.c_uint32)
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def build_oracle():
+    if not os.path.exists(ORACLE_SO) or (
+            os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "hrfd_oracle.c"))):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_SO)
+
+
+class Oracle:
+    """Our CPU restatement."""
+    prefix = "orc"
+
+    def __init__(self):
+        build_oracle()
+        self.lib = L = C.CDLL(ORACLE_SO)
+        L.orc_rx_create.restype = C.c_void_p
+        L.orc_rx_destroy.argtypes = [C.c_void_p]
+        L.orc_rx_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_rx_set_gain.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.orc_rx_set_threshold.argtypes = [C.c_void_p, C.c_int32]
+        L.orc_rx_process.restype = C.c_uint32
+        L.orc_rx_process.argtypes = [C.c_void_p, _i8p, C.c_uint32, C.c_uint32, _i16p, C.c_uint32,
+                                     _u32p, C.POINTER(C.c_int), _i8p]
+        L.orc_rx_wbfm_float_stream.restype = C.c_uint32
+        L.orc_rx_wbfm_float_stream.argtypes = [C.c_void_p, _f32p, C.c_uint32]
+        L.orc_demod_create.restype = C.c_void_p
+        L.orc_demod_create.argtypes = [C.c_int]
+        L.orc_demod_destroy.argtypes = [C.c_void_p]
+        L.orc_demod_reset.argtypes = [C.c_void_p]
+        L.orc_demod_set_gain.argtypes = [C.c_void_p, C.c_float]
+        L.orc_demod_set_sideband.argtypes = [C.c_void_p, C.c_int]
+        L.orc_demod_process.restype = C.c_uint32
+        L.orc_demod_process.argtypes = [C.c_void_p, _i8p, C.c_uint32, _i16p, C.c_uint32]
+        L.orc_ssbmod_create.restype = C.c_void_p
+        L.orc_ssbmod_create.argtypes = [C.c_int]
+        L.orc_ssbmod_destroy.argtypes = [C.c_void_p]
+        L.orc_ssbmod_reset.argtypes = [C.c_void_p]
+        L.orc_ssbmod_set_sideband.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ssbmod_process.restype = C.c_uint32
+        L.orc_ssbmod_process.argtypes = [C.c_void_p, _i16p, C.c_uint32, _i8p]
+        L.orc_interp_create.restype = C.c_void_p
+        L.orc_interp_destroy.argtypes = [C.c_void_p]
+        L.orc_interp_process.restype = C.c_uint32
+        L.orc_interp_process.argtypes = [C.c_void_p, _i16p, C.c_uint32, _i8p]
+        L.orc_nco_create.restype = C.c_void_p
+        L.orc_nco_create.argtypes = [C.c_float, C.c_float]
+        L.orc_nco_destroy.argtypes = [C.c_void_p]
+        L.orc_nco_set_frequency.argtypes = [C.c_void_p, C.c_float]
+        L.orc_nco_reset.argtypes = [C.c_void_p]
+        L.orc_nco_run.argtypes = [C.c_void_p, C.c_int, C.c_uint32, _f32p, _f32p]
+        L.orc_nco_tables.argtypes = [C.c_void_p, _f32p, _f32p]
+        L.orc_quantise.argtypes = [_f32p, C.c_int, _i16p]
+        L.orc_decimate.restype = C.c_uint32
+        L.orc_decimate.argtypes = [_f32p, C.c_int, C.c_int, _i16p, C.c_uint32, _i16p]
+        L.orc_interpolate.argtypes = [_f32p, C.c_int, C.c_int, _i16p, C.c_uint32, _i16p]
+        L.orc_iir.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_uint32, _f32p]
+        L.orc_float_to_int16.restype = C.c_int16
+        L.orc_float_to_int16.argtypes = [C.c_float]
+        L.orc_atan2_lut.argtypes = [_f32p]
+        L.orc_dbfs_table.argtypes = [_i32p]
+        L.orc_table.restype = C.c_int
+        L.orc_table.argtypes = [C.c_char_p, _f32p, C.c_int]
+
+    # ---- tables / primitives
+    def table(self, name: str) -> np.ndarray:
+        buf = np.zeros(64, dtype=np.float32)
+        n = self.lib.orc_table(name.encode(), _p(buf, _f32p), 64)
+        assert n > 0, name
+        return buf[:n].copy()
+
+    def quantise(self, coeffs) -> np.ndarray:
+        c = np.ascontiguousarray(coeffs, dtype=np.float32)
+        out = np.zeros(len(c), dtype=np.int16)
+        self.lib.orc_quantise(_p(c, _f32p), len(c), _p(out, _i16p))
+        return out
+
+    def decimate(self, coeffs, factor, x) -> np.ndarray:
+        c = np.ascontiguousarray(coeffs, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        out = np.zeros(len(x) // factor + 2, dtype=np.int16)
+        n = self.lib.orc_decimate(_p(c, _f32p), len(c), factor, _p(x, _i16p), len(x), _p(out, _i16p))
+        return out[:n].copy()
+
+    def interpolate(self, coeffs, factor, x) -> np.ndarray:
+        c = np.ascontiguousarray(coeffs, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        out = np.zeros(len(x) * factor, dtype=np.int16)
+        self.lib.orc_interpolate(_p(c, _f32p), len(c), factor, _p(x, _i16p), len(x), _p(out, _i16p))
+        return out
+
+    def iir(self, b, a, x) -> np.ndarray:
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(len(x), dtype=np.float32)
+        self.lib.orc_iir(_p(b, _f32p), len(b), _p(a, _f32p), len(a), _p(x, _f32p), len(x), _p(out, _f32p))
+        return out
+
+    def float_to_int16(self, v: float) -> int:
+        return int(self.lib.orc_float_to_int16(C.c_float(v)))
+
+    def atan2_lut(self) -> np.ndarray:
+        out = np.zeros((256, 256), dtype=np.float32)
+        self.lib.orc_atan2_lut(_p(out, _f32p))
+        return out
+
+    def dbfs_table(self) -> np.ndarray:
+        out = np.zeros(257, dtype=np.int32)
+        self.lib.orc_dbfs_table(_p(out, _i32p))
+        return out
+
+    # ---- objects
+    def rx(self):
+        return _OrcRx(self.lib)
+
+    def demod(self, mode):
+        return _OrcDemod(self.lib, mode)
+
+    def ssbmod(self, lsb=True):
+        return _OrcSsbMod(self.lib, lsb)
+
+    def interp(self):
+        return _OrcInterp(self.lib)
+
+    def nco(self, fs, f):
+        return _Nco(self.lib, "orc", fs, f)
+
+
+class _OrcRx:
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = C.c_void_p(lib.orc_rx_create())
+        self.gain_db = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_rx_destroy(self.h)
+            self.h = None
+
+    def set_mode(self, mode):
+        self.lib.orc_rx_set_mode(self.h, mode)
+
+    def set_gain(self, mode, gain):
+        self.lib.orc_rx_set_gain(self.h, mode, C.c_float(gain))
+
+    def set_threshold(self, t):
+        self.lib.orc_rx_set_threshold(self.h, t)
+
+    def process(self, iq: np.ndarray):
+        """-> (pcm int16[n], magnitude, allowed, iq256 int8[bytes/8])"""
+        iq = np.ascontiguousarray(iq, dtype=np.int8)
+        pcm = np.zeros(len(iq) // 512 + 8, dtype=np.int16)
+        mag = C.c_uint32(0)
+        allowed = C.c_int(0)
+        iq256 = np.zeros(len(iq) // 8, dtype=np.int8)
+        n = self.lib.orc_rx_process(self.h, _p(iq, _i8p), len(iq), self.gain_db, _p(pcm, _i16p), len(pcm),
+                                    C.byref(mag), C.byref(allowed), _p(iq256, _i8p))
+        return pcm[:n].copy(), int(mag.value), bool(allowed.value), iq256
+
+    def wbfm_float_stream(self, count):
+        out = np.zeros(count, dtype=np.float32)
+        n = self.lib.orc_rx_wbfm_float_stream(self.h, _p(out, _f32p), count)
+        return out[:n]
+
+
+class _OrcDemod:
+    def __init__(self, lib, mode):
+        self.lib = lib
+        self.h = C.c_void_p(lib.orc_demod_create(mode))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_demod_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.lib.orc_demod_reset(self.h)
+
+    def set_gain(self, g):
+        self.lib.orc_demod_set_gain(self.h, C.c_float(g))
+
+    def set_sideband(self, lsb):
+        self.lib.orc_demod_set_sideband(self.h, int(bool(lsb)))
+
+    def process(self, iq256):
+        iq256 = np.ascontiguousarray(iq256, dtype=np.int8)
+        pcm = np.zeros(len(iq256) // 2 + 8, dtype=np.int16)
+        n = self.lib.orc_demod_process(self.h, _p(iq256, _i8p), len(iq256), _p(pcm, _i16p), len(pcm))
+        return pcm[:n].copy()
+
+
+class _OrcSsbMod:
+    def __init__(self, lib, lsb):
+        self.lib = lib
+        self.h = C.c_void_p(lib.orc_ssbmod_create(int(bool(lsb))))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_ssbmod_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.lib.orc_ssbmod_reset(self.h)
+
+    def set_sideband(self, lsb):
+        self.lib.orc_ssbmod_set_sideband(self.h, int(bool(lsb)))
+
+    def process(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        out = np.zeros(len(pcm) * 512, dtype=np.int8)
+        n = self.lib.orc_ssbmod_process(self.h, _p(pcm, _i16p), len(pcm), _p(out, _i8p))
+        return out[:n]
+
+
+class _OrcInterp:
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = C.c_void_p(lib.orc_interp_create())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_interp_destroy(self.h)
+            self.h = None
+
+    def process(self, iq16):
+        iq16 = np.ascontiguousarray(iq16, dtype=np.int16)
+        n_pairs = len(iq16) // 2
+        out = np.zeros(n_pairs * 512, dtype=np.int8)
+        self.lib.orc_interp_process(self.h, _p(iq16, _i16p), n_pairs, _p(out, _i8p))
+        return out
+
+
+class _Nco:
+    def __init__(self, lib, prefix, fs, f):
+        self.lib, self.px = lib, prefix
+        fn = getattr(lib, f"{prefix}_nco_create")
+        fn.restype = C.c_void_p
+        fn.argtypes = [C.c_float, C.c_float]
+        self.h = C.c_void_p(fn(C.c_float(fs), C.c_float(f)))
+        for nm, at in (("destroy", [C.c_void_p]), ("set_frequency", [C.c_void_p, C.c_float]),
+                       ("reset", [C.c_void_p]), ("run", [C.c_void_p, C.c_int, C.c_uint32, _f32p, _f32p]),
+                       ("tables", [C.c_void_p, _f32p, _f32p])):
+            getattr(lib, f"{prefix}_nco_{nm}").argtypes = at
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.lib, f"{self.px}_nco_destroy")(self.h)
+            self.h = None
+
+    def set_frequency(self, f):
+        getattr(self.lib, f"{self.px}_nco_set_frequency")(self.h, C.c_float(f))
+
+    def reset(self):
+        getattr(self.lib, f"{self.px}_nco_reset")(self.h)
+
+    def run(self, n, fast=False):
+        i = np.zeros(n, dtype=np.float32)
+        q = np.zeros(n, dtype=np.float32)
+        getattr(self.lib, f"{self.px}_nco_run")(self.h, int(fast), n, _p(i, _f32p), _p(q, _f32p))
+        return i, q
+
+    def tables(self):
+        s = np.zeros(16384, dtype=np.float32)
+        c = np.zeros(16384, dtype=np.float32)
+        getattr(self.lib, f"{self.px}_nco_tables")(self.h, _p(s, _f32p), _p(c, _f32p))
+        return s, c
+
+
+class Ref:
+    """The reference's own compiled sources (oracle/_ref)."""
+
+    def __init__(self):
+        if not have_ref():
+            raise FileNotFoundError(REF_SO)
+        self.lib = L = C.CDLL(REF_SO)
+        L.ref_rx_create.restype = C.c_void_p
+        L.ref_rx_destroy.argtypes = [C.c_void_p]
+        L.ref_rx_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.ref_rx_set_gain.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.ref_rx_set_threshold.argtypes = [C.c_void_p, C.c_int32]
+        L.ref_set_receive_gain_db.argtypes = [C.c_uint32]
+        L.ref_rx_process.restype = C.c_uint32
+        L.ref_rx_process.argtypes = [C.c_void_p, _i8p, C.c_uint32, _i16p, C.c_uint32, _u32p, _i8p]
+        L.ref_rx_wbfm_float_stream.argtypes = [C.c_void_p, _f32p, C.c_uint32]
+        L.ref_demod_create.restype = C.c_void_p
+        L.ref_demod_create.argtypes = [C.c_int]
+        L.ref_demod_destroy.argtypes = [C.c_void_p]
+        L.ref_demod_reset.argtypes = [C.c_void_p]
+        L.ref_demod_set_gain.argtypes = [C.c_void_p, C.c_float]
+        L.ref_demod_set_sideband.argtypes = [C.c_void_p, C.c_int]
+        L.ref_demod_process.restype = C.c_uint32
+        L.ref_demod_process.argtypes = [C.c_void_p, _i8p, C.c_uint32, _i16p, C.c_uint32]
+        L.ref_ssbmod_create.restype = C.c_void_p
+        L.ref_ssbmod_create.argtypes = [C.c_int]
+        L.ref_ssbmod_destroy.argtypes = [C.c_void_p]
+        L.ref_ssbmod_reset.argtypes = [C.c_void_p]
+        L.ref_ssbmod_set_sideband.argtypes = [C.c_void_p, C.c_int]
+        L.ref_ssbmod_process.restype = C.c_uint32
+        L.ref_ssbmod_process.argtypes = [C.c_void_p, _i16p, C.c_uint32, _i8p]
+        L.ref_quantise.argtypes = [_f32p, C.c_int, _i16p]
+        L.ref_decimate.restype = C.c_uint32
+        L.ref_decimate.argtypes = [_f32p, C.c_int, C.c_int, _i16p, C.c_uint32, _i16p]
+        L.ref_interpolate.argtypes = [_f32p, C.c_int, C.c_int, _i16p, C.c_uint32, _i16p]
+        L.ref_iir.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_uint32, _f32p]
+        L.ref_float_to_int16.restype = C.c_int16
+        L.ref_float_to_int16.argtypes = [C.c_float]
+        L.ref_dbfs_table.argtypes = [_i32p]
+        L.ref_magnitude_to_dbfs.restype = C.c_int32
+        L.ref_magnitude_to_dbfs.argtypes = [C.c_uint32]
+
+    def quantise(self, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.float32)
+        out = np.zeros(len(c), dtype=np.int16)
+        self.lib.ref_quantise(_p(c, _f32p), len(c), _p(out, _i16p))
+        return out
+
+    def decimate(self, coeffs, factor, x):
+        c = np.ascontiguousarray(coeffs, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        out = np.zeros(len(x) // factor + 2, dtype=np.int16)
+        n = self.lib.ref_decimate(_p(c, _f32p), len(c), factor, _p(x, _i16p), len(x), _p(out, _i16p))
+        return out[:n].copy()
+
+    def interpolate(self, coeffs, factor, x):
+        c = np.ascontiguousarray(coeffs, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        out = np.zeros(len(x) * factor, dtype=np.int16)
+        self.lib.ref_interpolate(_p(c, _f32p), len(c), factor, _p(x, _i16p), len(x), _p(out, _i16p))
+        return out
+
+    def iir(self, b, a, x):
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(len(x), dtype=np.float32)
+        self.lib.ref_iir(_p(b, _f32p), len(b), _p(a, _f32p), len(a), _p(x, _f32p), len(x), _p(out, _f32p))
+        return out
+
+    def float_to_int16(self, v):
+        return int(self.lib.ref_float_to_int16(C.c_float(v)))
+
+    def dbfs_table(self):
+        out = np.zeros(257, dtype=np.int32)
+        self.lib.ref_dbfs_table(_p(out, _i32p))
+        return out
+
+    def rx(self):
+        return _RefRx(self.lib)
+
+    def demod(self, mode):
+        return _RefDemod(self.lib, mode)
+
+    def ssbmod(self, lsb=True):
+        return _RefSsbMod(self.lib, lsb)
+
+    def nco(self, fs, f):
+        return _Nco(self.lib, "ref", fs, f)
+
+    @staticmethod
+    def interpolate_signal(iq16: np.ndarray) -> np.ndarray:
+        """Run the reference CLI tool signals/interpolateSignal (stdin -> stdout)."""
+        data = np.ascontiguousarray(iq16, dtype=np.int16).tobytes()
+        out = subprocess.run([REF_INTERP], input=data, stdout=subprocess.PIPE, check=True).stdout
+        return np.frombuffer(out, dtype=np.int8).copy()
+
+
+class _RefRx:
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = C.c_void_p(lib.ref_rx_create())
+        self.gain_db = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_rx_destroy(self.h)
+            self.h = None
+
+    def set_mode(self, mode):
+        self.lib.ref_rx_set_mode(self.h, mode)
+
+    def set_gain(self, mode, gain):
+        self.lib.ref_rx_set_gain(self.h, mode, C.c_float(gain))
+
+    def set_threshold(self, t):
+        self.lib.ref_rx_set_threshold(self.h, t)
+
+    def process(self, iq):
+        """-> (pcm, magnitude, allowed(None: not observable), iq256)"""
+        iq = np.ascontiguousarray(iq, dtype=np.int8)
+        pcm = np.zeros(len(iq) // 512 + 8, dtype=np.int16)
+        mag = C.c_uint32(0)
+        iq256 = np.zeros(len(iq) // 8, dtype=np.int8)
+        self.lib.ref_set_receive_gain_db(self.gain_db)
+        n = self.lib.ref_rx_process(self.h, _p(iq, _i8p), len(iq), _p(pcm, _i16p), len(pcm),
+                                    C.byref(mag), _p(iq256, _i8p))
+        return pcm[:n].copy(), int(mag.value), None, iq256
+
+    def wbfm_float_stream(self, count):
+        out = np.zeros(count, dtype=np.float32)
+        self.lib.ref_rx_wbfm_float_stream(self.h, _p(out, _f32p), count)
+        return out
+
+
+class _RefDemod(_OrcDemod):
+    def __init__(self, lib, mode):
+        self.lib = lib
+        self.h = C.c_void_p(lib.ref_demod_create(mode))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_demod_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.lib.ref_demod_reset(self.h)
+
+    def set_gain(self, g):
+        self.lib.ref_demod_set_gain(self.h, C.c_float(g))
+
+    def set_sideband(self, lsb):
+        self.lib.ref_demod_set_sideband(self.h, int(bool(lsb)))
+
+    def process(self, iq256):
+        iq256 = np.ascontiguousarray(iq256, dtype=np.int8)
+        pcm = np.zeros(len(iq256) // 2 + 8, dtype=np.int16)
+        n = self.lib.ref_demod_process(self.h, _p(iq256, _i8p), len(iq256), _p(pcm, _i16p), len(pcm))
+        return pcm[:n].copy()
+
+
+class _RefSsbMod:
+    def __init__(self, lib, lsb):
+        self.lib = lib
+        self.h = C.c_void_p(lib.ref_ssbmod_create(int(bool(lsb))))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_ssbmod_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        self.lib.ref_ssbmod_reset(self.h)
+
+    def set_sideband(self, lsb):
+        self.lib.ref_ssbmod_set_sideband(self.h, int(bool(lsb)))
+
+    def process(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        out = np.zeros(len(pcm) * 512, dtype=np.int8)
+        n = self.lib.ref_ssbmod_process(self.h, _p(pcm, _i16p), len(pcm), _p(out, _i8p))
+        return out[:n]

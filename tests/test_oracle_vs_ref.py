@@ -1,0 +1,203 @@
+"""Pin the CPU restatement (oracle/hrfd_oracle.c) against the reference's own
+compiled sources (oracle/_ref) -- bit-exact on every output, all modes."""
+import numpy as np
+import pytest
+
+from hackrfdiags_amd import synth
+from tests.reflib import AM, FM, WBFM, LSB, USB, NONE
+
+BLK = synth.BLOCK_BYTES
+MODES = [AM, FM, WBFM, LSB, USB]
+KINDS = ["lcg", "fmtone", "amtone", "dc_pos", "dc_neg", "impulse", "zeros"]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_quantised_tables(oracle, ref):
+    for name in ["HB1", "HB2", "HB3", "WBFM_D1", "POST_D12", "AUDIO_D40", "FM_TUNER_D32", "AM_D1",
+                 "AM_D2", "AM_D3", "SSB_DELAY", "SSB_HILBERT", "INTERP_HB8", "INTERP_HB3",
+                 "INTERP_HB2", "INTERP_HB1", "INTERPSIG_S1"]:
+        t = oracle.table(name)
+        assert (oracle.quantise(t) == ref.quantise(t)).all(), name
+    # SURVEY.md section 8a spot values
+    assert oracle.quantise(oracle.table("HB1")).tolist() == [8206, 16384, 8206]
+    assert oracle.quantise(oracle.table("SSB_DELAY"))[-1] == -32768   # negating delay quirk
+    assert (oracle.table("FM_DIFF") == np.array([0, 0, 1, 0, -1, 0, 0], dtype=np.float32)).all()
+
+
+def test_dbfs_table(oracle, ref):
+    assert (oracle.dbfs_table() == ref.dbfs_table()).all()
+    for m in [0, 1, 2, 50, 126, 127, 128, 192, 255, 256, 1000]:
+        assert ref.lib.ref_magnitude_to_dbfs(m) == oracle.dbfs_table()[min(m, 127)] - 42
+
+
+def test_float_to_int16_x86_semantics(oracle, ref):
+    for v in [0.0, 0.9, -0.9, 32767.0, 32768.0, 40000.0, -40000.5, 65536.0, 65537.7, 2147483520.0,
+              2147483648.0, -2147483648.0, -2147483904.0, 3e9, -3e9, 1e20, float("inf"),
+              float("-inf"), float("nan")]:
+        assert oracle.float_to_int16(v) == ref.float_to_int16(v), v
+    # documented values (hard parts)
+    assert oracle.float_to_int16(32768.0) == -32768
+    assert oracle.float_to_int16(40000.0) == -25536
+    assert oracle.float_to_int16(-40000.5) == 25536
+    assert oracle.float_to_int16(65536.0) == 0
+    assert oracle.float_to_int16(3e9) == 0
+
+
+@pytest.mark.parametrize("taps,factor", [(3, 2), (8, 4), (12, 4), (40, 2), (32, 4), (16, 2), (16, 1), (31, 1)])
+def test_q15_stage(oracle, ref, taps, factor):
+    rng = np.random.default_rng(taps * 10 + factor)
+    h = (rng.standard_normal(taps) * 0.3).astype(np.float32)
+    h[0] = 1.0     # 1.0 -> -32768 quirk
+    for n in [0, 1, factor, 7, 100, 4099]:
+        x = rng.integers(-32768, 32768, n).astype(np.int16)
+        assert (oracle.decimate(h, factor, x) == ref.decimate(h, factor, x)).all()
+
+
+@pytest.mark.parametrize("taps,factor", [(40, 2), (8, 2), (4, 2), (12, 4)])
+def test_q15_interpolator(oracle, ref, taps, factor):
+    rng = np.random.default_rng(taps + factor)
+    h = (rng.standard_normal(taps) * 0.4).astype(np.float32)
+    x = rng.integers(-32768, 32768, 777).astype(np.int16)
+    assert (oracle.interpolate(h, factor, x) == ref.interpolate(h, factor, x)).all()
+
+
+def test_iir_float(oracle, ref):
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(5000) * 1000).astype(np.float32)
+    for b, a in [([0.0253863, 0.0253863], [-0.9492274]), ([1, -1], [-0.95]), ([1, 2, 3], [0.5, -0.25])]:
+        assert (_bits(oracle.iir(b, a, x)) == _bits(ref.iir(b, a, x))).all()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("kind", KINDS)
+def test_rx_chain(oracle, ref, mode, kind):
+    nb = 3
+    x = synth.make_input(kind, 7, nb)
+    a, b = oracle.rx(), ref.rx()
+    a.set_mode(mode)
+    b.set_mode(mode)
+    for blk in range(nb):
+        xb = x[blk * BLK:(blk + 1) * BLK]
+        pa, ma, _, ia = a.process(xb)
+        pb, mb, _, ib = b.process(xb)
+        assert (ia == ib).all()
+        assert ma == mb
+        assert len(pa) == len(pb) == 512
+        assert (pa == pb).all()
+        if mode == WBFM:
+            assert (_bits(a.wbfm_float_stream(16384)) == _bits(b.wbfm_float_stream(16384))).all()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_rx_chunk_invariance_and_ragged(oracle, ref, mode):
+    """Any chunking in multiples of 64 bytes gives the same PCM;
+    ragged chunk sizes still match the reference call for call."""
+    x = synth.make_input("fmtone", 3, 2)
+    a = oracle.rx(); a.set_mode(mode)
+    whole = np.concatenate([a.process(x[k * BLK:(k + 1) * BLK])[0] for k in range(2)])
+    for chunk in (65536, 512, 64):
+        c = oracle.rx(); c.set_mode(mode)
+        parts = [c.process(x[o:o + chunk])[0] for o in range(0, len(x), chunk)]
+        assert (np.concatenate(parts) == whole).all(), chunk
+    # ragged: any multiple of 16 bytes (= one 256 kS/s IQ sample) is a legal call;
+    # fewer than 16 bytes would make the reference divide by zero in the squelch.
+    sizes = [16, 48, 1008, 4096, 262144, 80, 70000, 16 * 1234]
+    a = oracle.rx(); b = ref.rx(); a.set_mode(mode); b.set_mode(mode)
+    off = 0
+    for s in sizes:
+        pa, ma, _, ia = a.process(x[off:off + s]); pb, mb, _, ib = b.process(x[off:off + s])
+        assert (ia[:s // 8] == ib[:s // 8]).all() and ma == mb and len(pa) == len(pb) and (pa == pb).all(), s
+        off += s
+
+
+@pytest.mark.parametrize("mode", [AM, FM, WBFM, LSB])
+def test_rx_gain_setting_incl_overflow(oracle, ref, mode):
+    x = synth.make_input("lcg", 11, 2)
+    for gain in [1.0, 1234.5, 1e6, 1e12]:
+        a, b = oracle.rx(), ref.rx()
+        a.set_mode(mode); b.set_mode(mode)
+        a.set_gain(mode, gain); b.set_gain(mode, gain)
+        for blk in range(2):
+            pa = a.process(x[blk * BLK:(blk + 1) * BLK])[0]
+            pb = b.process(x[blk * BLK:(blk + 1) * BLK])[0]
+            assert (pa == pb).all(), (mode, gain)
+
+
+def test_rx_squelch_gate_and_tail(oracle, ref):
+    """threshold above the signal closes the gate: no PCM, demod state frozen;
+    one 'tail' block is still demodulated after the signal drops."""
+    loud = synth.make_input("fmtone", 1, 1)
+    quiet = synth.zeros_iq(synth.BLOCK_IQ)
+    seq = [loud, loud, quiet, quiet, loud, quiet, quiet, quiet, loud]
+    a, b = oracle.rx(), ref.rx()
+    for h in (a, b):
+        h.set_mode(WBFM)
+        h.set_threshold(-30)
+    lens = []
+    for xb in seq:
+        pa, ma, allowed, _ = a.process(xb)
+        pb, mb, _, _ = b.process(xb)
+        assert ma == mb and len(pa) == len(pb) and (pa == pb).all()
+        assert allowed == (len(pa) > 0)
+        lens.append(len(pa))
+    assert lens == [512, 512, 512, 0, 512, 512, 0, 0, 512]
+    # receive-gain subtraction moves the decision
+    a, b = oracle.rx(), ref.rx()
+    for h in (a, b):
+        h.set_mode(FM); h.set_threshold(-30); h.gain_db = 40
+    assert len(a.process(loud)[0]) == len(b.process(loud)[0]) == 0
+
+
+def test_rx_mode_switch_keeps_state(oracle, ref):
+    x = synth.make_input("lcg", 5, 6)
+    a, b = oracle.rx(), ref.rx()
+    for blk, mode in enumerate([WBFM, AM, LSB, USB, FM, WBFM]):
+        a.set_mode(mode); b.set_mode(mode)
+        pa = a.process(x[blk * BLK:(blk + 1) * BLK])[0]
+        pb = b.process(x[blk * BLK:(blk + 1) * BLK])[0]
+        assert (pa == pb).all(), (blk, mode)
+    a.set_mode(NONE); b.set_mode(NONE)
+    assert len(a.process(x[:BLK])[0]) == len(b.process(x[:BLK])[0]) == 0
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_inner_demod_api_and_reset(oracle, ref, mode):
+    x = synth.lcg_bytes(21, 3 * 32768)
+    a, b = oracle.demod(mode), ref.demod(mode)
+    for k in range(3):
+        if k == 2:
+            a.reset(); b.reset()       # WBFM reset leaves the de-emphasis IIR alone
+        pa = a.process(x[k * 32768:(k + 1) * 32768]); pb = b.process(x[k * 32768:(k + 1) * 32768])
+        assert len(pa) == 512 and (pa == pb).all()
+
+
+@pytest.mark.parametrize("lsb", [True, False])
+def test_ssb_modulator(oracle, ref, lsb):
+    pcm = synth.lcg_pcm(7, 4 * 512)
+    a, b = oracle.ssbmod(lsb), ref.ssbmod(lsb)
+    for k in range(4):
+        oa = a.process(pcm[k * 512:(k + 1) * 512]); ob = b.process(pcm[k * 512:(k + 1) * 512])
+        assert len(oa) == 262144 and (oa == ob).all()
+
+
+def test_interpolate_signal_tool(oracle, ref):
+    iq = synth.lcg_pcm(9, 2 * 700)
+    got = oracle.interp().process(iq)
+    want = ref.interpolate_signal(iq)
+    assert len(want) == 700 * 512 and (got == want).all()
+
+
+def test_nco(oracle, ref):
+    for fs, f in [(8000.0, 1000.0), (256000.0, 75000.0), (256000.0, -12345.6)]:
+        a, b = oracle.nco(fs, f), ref.nco(fs, f)
+        sa, ca = a.tables(); sb, cb = b.tables()
+        assert (_bits(sa) == _bits(sb)).all() and (_bits(ca) == _bits(cb)).all()
+        for fast in (False, True):
+            ia, qa = a.run(3000, fast); ib, qb = b.run(3000, fast)
+            assert (_bits(ia) == _bits(ib)).all() and (_bits(qa) == _bits(qb)).all()
+        a.set_frequency(f / 3); b.set_frequency(f / 3)
+        ia, qa = a.run(500, True); ib, qb = b.run(500, True)
+        assert (_bits(ia) == _bits(ib)).all() and (_bits(qa) == _bits(qb)).all()
