@@ -1,0 +1,96 @@
+"""Locate / load libhrfd.so (the C ABI of include/hrfd.h) with ctypes.
+
+There is deliberately no fallback: if the shared library is missing the import
+raises, and if there is no GPU every create call returns HRFD_ENODEV.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libhrfd.so")
+
+_i16p = C.POINTER(C.c_int16)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+_lib = None
+_runtime = None        # the HIP runtime CDLL the library was bound to
+
+
+def _load_hip_runtime():
+    """libhrfd.so carries no DT_NEEDED entry for the HIP runtime: a process must
+    hold exactly ONE HIP/HSA runtime.  When PyTorch is importable we bind to the
+    runtime it ships (so torch tensors, streams and RCCL share the device context
+    with our kernels); otherwise to the system ROCm runtime.  Set
+    HRFD_HIP_RUNTIME=/path/libamdhip64.so to force a choice."""
+    global _runtime
+    if _runtime is not None:
+        return _runtime
+    cands = []
+    forced = os.environ.get("HRFD_HIP_RUNTIME")
+    if forced:
+        cands.append(forced)
+    elif os.environ.get("HRFD_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401  (loads its bundled runtime)
+            tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+            if os.path.exists(tl):
+                cands.append(tl)
+        except Exception:
+            pass
+    cands += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so"]
+    last = None
+    for c in cands:
+        try:
+            _runtime = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return _runtime
+        except OSError as e:      # try the next candidate
+            last = e
+    raise HrfdError(f"no HIP runtime could be loaded ({last}); libhrfd.so needs libamdhip64")
+
+
+class HrfdError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HrfdError(f"{LIB_PATH} not found: build it with "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _load_hip_runtime()
+    L = C.CDLL(LIB_PATH)
+    L.hrfd_last_error.restype = C.c_char_p
+    L.hrfd_version.restype = C.c_int
+    L.hrfd_device_count.restype = C.c_int
+    L.hrfd_rx_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(_vp)]
+    L.hrfd_rx_destroy.argtypes = [_vp]
+    L.hrfd_rx_set_mode.argtypes = [_vp, C.c_uint32, C.c_int]
+    L.hrfd_rx_set_gain.argtypes = [_vp, C.c_uint32, C.c_int, C.c_float]
+    L.hrfd_rx_set_threshold.argtypes = [_vp, C.c_uint32, C.c_int32]
+    L.hrfd_rx_reset_demod.argtypes = [_vp, C.c_uint32, C.c_int]
+    L.hrfd_rx_process_block.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        _vp, _vp, _vp, _vp, _vp]
+    L.hrfd_rx_process_device.argtypes = [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         _vp, _vp, _vp, _vp, _vp, _vp]
+    L.hrfd_rx_sync.argtypes = [_vp, _u32p]
+    L.hrfd_rx_debug_set_warm.argtypes = [_vp, C.c_int]
+    L.hrfd_rx_debug_counters.argtypes = [_vp, _u32p]
+    L.hrfd_q15_table.argtypes = [C.c_char_p, _i16p, C.c_int]
+    L.hrfd_atan2_table.argtypes = [_f32p]
+    L.hrfd_dbfs_table.argtypes = [_i32p]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().hrfd_last_error().decode(errors="replace")
+        raise HrfdError(f"{what} failed ({rc}): {msg}")

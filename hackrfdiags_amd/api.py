@@ -1,0 +1,154 @@
+"""Python mirror of the C ABI (include/hrfd.h) -- thin ctypes plumbing used by
+the tests and bench.py.  Names follow the reference: an Rx is C channels of
+IqDataProcessor + demodulators; process_block == acceptIqData."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import HrfdError, check  # noqa: F401
+
+NONE, AM, FM, WBFM, LSB, USB = range(6)
+ALL = 0xFFFFFFFF
+BLOCK_BYTES = 262144
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(int(a))          # raw device pointer (e.g. torch tensor .data_ptr())
+
+
+class Rx:
+    """n_channels receive chains (hrfd_rx_*)."""
+
+    def __init__(self, n_channels: int, device: int = -1):
+        self.L = _lib.load()
+        self.n = int(n_channels)
+        h = C.c_void_p()
+        check(self.L.hrfd_rx_create(self.n, device, C.byref(h)), "hrfd_rx_create")
+        self.h = h
+        self.gain_db = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hrfd_rx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_mode(self, mode, channel=ALL):
+        check(self.L.hrfd_rx_set_mode(self.h, channel, mode), "hrfd_rx_set_mode")
+
+    def set_gain(self, mode, gain, channel=ALL):
+        check(self.L.hrfd_rx_set_gain(self.h, channel, mode, C.c_float(gain)), "hrfd_rx_set_gain")
+
+    def set_threshold(self, threshold, channel=ALL):
+        check(self.L.hrfd_rx_set_threshold(self.h, channel, threshold), "hrfd_rx_set_threshold")
+
+    def reset_demod(self, mode, channel=ALL):
+        check(self.L.hrfd_rx_reset_demod(self.h, channel, mode), "hrfd_rx_reset_demod")
+
+    def process_block(self, iq: np.ndarray, n_blocks: int = 1, want_iq256: bool = False):
+        """iq: int8 [C, n_blocks, block_bytes] (or flat).  Host buffers in, host arrays out:
+        (pcm [C,B,npcm], n_pcm [C,B], magnitude [C,B], allowed [C,B], iq256 [C,B,bb/8] | None)"""
+        iq = np.ascontiguousarray(iq, dtype=np.int8).reshape(self.n, n_blocks, -1)
+        bb = iq.shape[2]
+        npcm = bb // 512
+        pcm = np.zeros((self.n, n_blocks, npcm), dtype=np.int16)
+        n_pcm = np.zeros((self.n, n_blocks), dtype=np.uint32)
+        mag = np.zeros((self.n, n_blocks), dtype=np.uint32)
+        allowed = np.zeros((self.n, n_blocks), dtype=np.uint8)
+        iq256 = np.zeros((self.n, n_blocks, bb // 8), dtype=np.int8) if want_iq256 else None
+        check(self.L.hrfd_rx_process_block(self.h, _ptr(iq), bb, n_blocks, self.gain_db, _ptr(pcm),
+                                           _ptr(n_pcm), _ptr(mag), _ptr(allowed), _ptr(iq256)),
+              "hrfd_rx_process_block")
+        return pcm, n_pcm, mag, allowed, iq256
+
+    def process_device(self, d_iq, channel_stride, block_bytes, n_blocks, d_pcm, d_n_pcm=None,
+                       d_magnitude=None, d_allowed=None, d_iq256=None, stream=None):
+        """All pointers are device addresses (ints); asynchronous."""
+        check(self.L.hrfd_rx_process_device(self.h, _ptr(d_iq), channel_stride, block_bytes, n_blocks,
+                                            self.gain_db, _ptr(d_pcm), _ptr(d_n_pcm), _ptr(d_magnitude),
+                                            _ptr(d_allowed), _ptr(d_iq256), _ptr(stream)),
+              "hrfd_rx_process_device")
+
+    def sync(self) -> int:
+        v = C.c_uint32(0)
+        check(self.L.hrfd_rx_sync(self.h, C.byref(v)), "hrfd_rx_sync")
+        return int(v.value)
+
+    # test hooks
+    def debug_set_warm(self, warm: int):
+        check(self.L.hrfd_rx_debug_set_warm(self.h, warm), "hrfd_rx_debug_set_warm")
+
+    def debug_counters(self):
+        out = (C.c_uint32 * 8)()
+        check(self.L.hrfd_rx_debug_counters(self.h, out), "hrfd_rx_debug_counters")
+        return list(out)
+
+
+class SingleChannelRx:
+    """One channel with the call shape the golden checks use (mirrors one
+    IqDataProcessor::acceptIqData call per process())."""
+
+    def __init__(self, device: int = -1):
+        self.rx = Rx(1, device)
+
+    @property
+    def gain_db(self):
+        return self.rx.gain_db
+
+    @gain_db.setter
+    def gain_db(self, v):
+        self.rx.gain_db = int(v)
+
+    def set_mode(self, mode):
+        self.rx.set_mode(mode)
+
+    def set_gain(self, mode, gain):
+        self.rx.set_gain(mode, gain)
+
+    def set_threshold(self, t):
+        self.rx.set_threshold(t)
+
+    def process(self, iq):
+        pcm, n_pcm, mag, allowed, iq256 = self.rx.process_block(iq, 1, want_iq256=True)
+        n = int(n_pcm[0, 0])
+        return pcm[0, 0, :n].copy(), int(mag[0, 0]), bool(allowed[0, 0]), iq256[0, 0]
+
+
+class Engine:
+    """Factory with the interface tests/goldencheck.py expects."""
+
+    def rx(self):
+        return SingleChannelRx()
+
+
+def q15_table(name: str) -> np.ndarray:
+    L = _lib.load()
+    buf = np.zeros(64, dtype=np.int16)
+    n = L.hrfd_q15_table(name.encode(), buf.ctypes.data_as(C.POINTER(C.c_int16)), 64)
+    return buf[:n].copy()
+
+
+def atan2_table() -> np.ndarray:
+    L = _lib.load()
+    out = np.zeros((256, 256), dtype=np.float32)
+    check(L.hrfd_atan2_table(out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def dbfs_table() -> np.ndarray:
+    L = _lib.load()
+    out = np.zeros(257, dtype=np.int32)
+    check(L.hrfd_dbfs_table(out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out
+
+
+def device_count() -> int:
+    return int(_lib.load().hrfd_device_count())

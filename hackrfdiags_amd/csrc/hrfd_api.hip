@@ -1,0 +1,734 @@
+// hackrfdiags_amd/csrc/hrfd_api.hip -- host side of the C ABI declared in
+// include/hrfd.h.  Owns device memory, per-channel state, streams and launches;
+// contains no signal processing of its own and NO CPU fallback: without a HIP
+// device every create call fails with HRFD_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "../../include/hrfd.h"
+#include "hrfd_device.h"
+#include "hrfd_tables.h"
+
+namespace hrfd {
+template <int MODE> __global__ void k_rx_wbfm(const RxParams);
+__global__ void k_rx_epilogue(const EpilogueParams);
+__global__ void k_rx_commit(const EpilogueParams);
+} // namespace hrfd
+
+using namespace hrfd;
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+  do                                                                                     \
+  {                                                                                      \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+    {                                                                                    \
+      return fail(HRFD_ENODEV, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                  __FILE__, __LINE__);                                                   \
+    }                                                                                    \
+  } while (0)
+
+extern "C" const char *hrfd_last_error(void) { return g_err; }
+extern "C" int hrfd_version(void) { return HRFD_VERSION; }
+
+extern "C" int hrfd_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------ host-built tables
+// Built with the host libm exactly as the reference constructors do, never with
+// device intrinsics:
+//   atan2 table  WbFmDemodulator.cc:137-148 / FmDemodulator.cc:159-170
+//   dBFS table   DbfsCalculator.cc:58-65 (20*log10f(i), truncated)
+static void build_atan2(float *out)
+{
+  for (int x = 0; x < 256; x++)
+  {
+    for (int y = 0; y < 256; y++)
+    {
+      const double xa = (double)x - 128;
+      const double ya = (double)y - 128;
+      out[y * 256 + x] = (float)atan2(ya, xa);
+    }
+  }
+}
+
+static void build_dbfs(int32_t *out)
+{
+  for (int i = 1; i <= 256; i++)
+  {
+    const float db = 20 * log10f((float)i);
+    out[i] = (int32_t)db;
+  }
+  out[0] = out[1];
+}
+
+extern "C" int hrfd_atan2_table(float *out)
+{
+  if (out == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_atan2_table: NULL");
+  }
+  build_atan2(out);
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_dbfs_table(int32_t *out)
+{
+  if (out == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_dbfs_table: NULL");
+  }
+  build_dbfs(out);
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_q15_table(const char *name, int16_t *out, int cap)
+{
+  if (name == nullptr)
+  {
+    return 0;
+  }
+  for (const NamedTable &t : kNamedTables)
+  {
+    if (strcmp(t.name, name) == 0)
+    {
+      if (out != nullptr)
+      {
+        memcpy(out, t.taps, sizeof(int16_t) * (size_t)std::min(cap, t.n));
+      }
+      return t.n;
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ rx handle
+struct hrfd_rx
+{
+  int device = 0;
+  uint32_t n_channels = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t last_stream = nullptr;
+
+  std::mutex mu;                       // guards h_cfg / dirty (setters may come from another thread)
+  std::vector<ChanCfg> h_cfg;
+  bool cfg_dirty = true;
+  std::vector<std::pair<uint32_t, int>> pending_resets;   // (channel, mode)
+
+  ChanCfg *d_cfg = nullptr;
+  ChanState *d_state = nullptr;
+  ChanState *d_state_out = nullptr;
+  float *d_lut = nullptr;
+  int32_t *d_dbfs = nullptr;
+  uint32_t *d_counters = nullptr;
+  uint32_t *d_lists = nullptr;         // [6][n_channels] channel ids grouped by mode
+  uint32_t list_count[6] = {0, 0, 0, 0, 0, 0};
+
+  // per-call scratch, grown on demand (units = channels * blocks)
+  size_t cap_units = 0;
+  uint8_t *d_present = nullptr;
+  uint32_t *d_magnitude = nullptr;
+  float *d_chk_pub = nullptr;
+  float *d_chk_spec = nullptr;
+
+  // staging for the host-buffer entry
+  size_t cap_iq = 0, cap_pcm = 0, cap_iq256 = 0;
+  int8_t *d_iq = nullptr;
+  int16_t *d_pcm = nullptr;
+  int8_t *d_iq256 = nullptr;
+  size_t cap_npcm = 0, cap_allowed = 0, cap_mag_out = 0;
+  uint32_t *d_npcm = nullptr;
+  uint8_t *d_allowed = nullptr;
+  uint32_t *d_mag_out = nullptr;
+  uint32_t replays = 0;                // launches redone on the exact path (diagnostic)
+  uint32_t total_repairs = 0;          // de-emphasis tiles repaired in place since creation
+
+  // test hooks
+  int warm = kWarm;
+  uint32_t last_counters[kNumCounters] = {0};
+};
+
+static int rx_free(hrfd_rx *h)
+{
+  if (h == nullptr)
+  {
+    return HRFD_OK;
+  }
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_dbfs, h->d_counters,
+                  h->d_lists, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
+                  h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out};
+  for (void *p : ptrs)
+  {
+    if (p) (void)hipFree(p);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return HRFD_OK;
+}
+
+static ChanCfg default_cfg()
+{
+  ChanCfg c;
+  memset(&c, 0, sizeof(c));
+  c.mode = HRFD_MODE_NONE;                               // IqDataProcessor.cc:63
+  c.threshold = -200;                                    // IqDataProcessor.cc:121
+  c.gain_am = 300;                                       // AmDemodulator.cc:102
+  c.gain_fm = (float)(64000 / (2 * M_PI));               // FmDemodulator.cc:173
+  c.gain_wbfm = (float)(256000 / (2 * M_PI));            // WbFmDemodulator.cc:151
+  c.gain_ssb = 300;                                      // SsbDemodulator.cc ctor
+  c.lsb = 1;                                             // SsbDemodulator.cc ctor
+  return c;
+}
+
+extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
+{
+  if (out == nullptr || n_channels == 0)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_create: need n_channels > 0 and a result pointer");
+  }
+  *out = nullptr;
+  if (hrfd_device_count() <= 0)
+  {
+    return fail(HRFD_ENODEV, "hrfd_rx_create: no HIP device visible (this library has no CPU path)");
+  }
+  if (device < 0)
+  {
+    HIP_TRY(hipGetDevice(&device));
+  }
+  HIP_TRY(hipSetDevice(device));
+  hrfd_rx *h = new hrfd_rx;
+  h->device = device;
+  h->n_channels = n_channels;
+  h->h_cfg.assign(n_channels, default_cfg());
+  int rc = HRFD_OK;
+  auto alloc = [&](void **p, size_t bytes) -> bool {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess)
+    {
+      rc = fail(HRFD_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      return false;
+    }
+    return true;
+  };
+  bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && alloc((void **)&h->d_cfg, sizeof(ChanCfg) * n_channels);
+  ok = ok && alloc((void **)&h->d_state, sizeof(ChanState) * n_channels);
+  ok = ok && alloc((void **)&h->d_state_out, sizeof(ChanState) * n_channels);
+  ok = ok && alloc((void **)&h->d_lut, sizeof(float) * 65536);
+  ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
+  ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * kNumCounters);
+  ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 6 * n_channels);
+  if (!ok)
+  {
+    if (rc == HRFD_OK) rc = fail(HRFD_ENODEV, "hrfd_rx_create: stream creation failed");
+    rx_free(h);
+    return rc;
+  }
+  // Zero state == the reference's freshly constructed objects: zero filter
+  // pipelines, previousTheta = 0, tracker in NoSignal.  A zero raw/iq256
+  // history is exactly equivalent to zero filter state.
+  // (offset-binary tails hold 0x80 = value 0.)
+  std::vector<ChanState> init(n_channels);
+  memset(init.data(), 0, sizeof(ChanState) * n_channels);
+  for (auto &s : init)
+  {
+    memset(s.fm_tail, 0x80, sizeof(s.fm_tail));
+    memset(s.am_tail, 0x80, sizeof(s.am_tail));
+    memset(s.ssb_tail, 0x80, sizeof(s.ssb_tail));
+  }
+  std::vector<float> lut(65536);
+  int32_t dbfs[257];
+  build_atan2(lut.data());
+  build_dbfs(dbfs);
+  hipError_t e = hipMemcpy(h->d_state, init.data(), sizeof(ChanState) * n_channels, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_state_out, init.data(), sizeof(ChanState) * n_channels, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_lut, lut.data(), sizeof(float) * 65536, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_dbfs, dbfs, sizeof(dbfs), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(h->d_counters, 0, sizeof(uint32_t) * kNumCounters);
+  if (e != hipSuccess)
+  {
+    rc = fail(HRFD_ENODEV, "hrfd_rx_create: initial upload failed: %s", hipGetErrorString(e));
+    rx_free(h);
+    return rc;
+  }
+  *out = h;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_rx_destroy(hrfd_rx *h) { return rx_free(h); }
+
+template <typename F>
+static int for_channels(hrfd_rx *h, uint32_t channel, F f)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL handle");
+  }
+  if (channel != HRFD_ALL_CHANNELS && channel >= h->n_channels)
+  {
+    return fail(HRFD_EINVAL, "channel %u out of range (%u channels)", channel, h->n_channels);
+  }
+  std::lock_guard<std::mutex> g(h->mu);
+  const uint32_t lo = (channel == HRFD_ALL_CHANNELS) ? 0 : channel;
+  const uint32_t hi = (channel == HRFD_ALL_CHANNELS) ? h->n_channels : channel + 1;
+  for (uint32_t c = lo; c < hi; c++)
+  {
+    f(c);
+  }
+  h->cfg_dirty = true;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_rx_set_mode(hrfd_rx *h, uint32_t channel, int mode)
+{
+  if (mode < HRFD_MODE_NONE || mode > HRFD_MODE_USB)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_set_mode: bad mode %d", mode);
+  }
+  return for_channels(h, channel, [&](uint32_t c) {
+    h->h_cfg[c].mode = mode;
+    // IqDataProcessor::setDemodulatorMode also selects the SSB sideband (:357-372)
+    if (mode == HRFD_MODE_LSB) h->h_cfg[c].lsb = 1;
+    if (mode == HRFD_MODE_USB) h->h_cfg[c].lsb = 0;
+  });
+}
+
+extern "C" int hrfd_rx_set_gain(hrfd_rx *h, uint32_t channel, int mode, float gain)
+{
+  if (mode < HRFD_MODE_AM || mode > HRFD_MODE_USB)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_set_gain: bad mode %d", mode);
+  }
+  return for_channels(h, channel, [&](uint32_t c) {
+    switch (mode)
+    {
+      case HRFD_MODE_AM: h->h_cfg[c].gain_am = gain; break;
+      case HRFD_MODE_FM: h->h_cfg[c].gain_fm = gain; break;
+      case HRFD_MODE_WBFM: h->h_cfg[c].gain_wbfm = gain; break;
+      default: h->h_cfg[c].gain_ssb = gain; break;
+    }
+  });
+}
+
+extern "C" int hrfd_rx_set_threshold(hrfd_rx *h, uint32_t channel, int32_t threshold)
+{
+  return for_channels(h, channel, [&](uint32_t c) { h->h_cfg[c].threshold = threshold; });
+}
+
+extern "C" int hrfd_rx_reset_demod(hrfd_rx *h, uint32_t channel, int mode)
+{
+  if (mode < HRFD_MODE_AM || mode > HRFD_MODE_USB)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_reset_demod: bad mode %d", mode);
+  }
+  return for_channels(h, channel, [&](uint32_t c) { h->pending_resets.push_back({c, mode}); });
+}
+
+// test hook (not in the public header): shrink the de-emphasis warm-up so that
+// the speculation-failure / replay path can be exercised.
+extern "C" int hrfd_rx_debug_set_warm(hrfd_rx *h, int warm)
+{
+  if (h == nullptr || warm < 0 || warm > kWarm)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_set_warm: 0..%d", kWarm);
+  }
+  h->warm = warm;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_rx_debug_counters(hrfd_rx *h, uint32_t *out8)
+{
+  if (h == nullptr || out8 == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL");
+  }
+  memcpy(out8, h->last_counters, sizeof(h->last_counters));
+  out8[kNumCounters - 1] = h->replays;
+  out8[kNumCounters - 2] = h->total_repairs;
+  return HRFD_OK;
+}
+
+static int grow(void **p, size_t *cap, size_t need)
+{
+  if (need <= *cap && *p != nullptr)
+  {
+    return HRFD_OK;
+  }
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  hipError_t e = hipMalloc(p, need);
+  if (e != hipSuccess)
+  {
+    *cap = 0;
+    return fail(HRFD_ENOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+  }
+  *cap = need;
+  return HRFD_OK;
+}
+
+// apply queued X::resetDemodulator calls to the device state
+static int apply_resets(hrfd_rx *h, hipStream_t s, std::vector<std::pair<uint32_t, int>> &resets)
+{
+  for (auto &r : resets)
+  {
+    ChanState *d = h->d_state + r.first;
+    switch (r.second)
+    {
+      case HRFD_MODE_WBFM:
+        // WbFmDemodulator.cc:265-278: the three decimators and previousTheta;
+        // the de-emphasis filter (wb_p, wb_y) is left alone.
+        HIP_TRY(hipMemsetAsync(&d->wb_theta, 0, sizeof(float), s));
+        HIP_TRY(hipMemsetAsync(d->wb_s, 0, sizeof(d->wb_s) + sizeof(d->wb_u) + sizeof(d->wb_v), s));
+        break;
+      case HRFD_MODE_FM:
+        HIP_TRY(hipMemsetAsync(d->fm_tail, 0x80, sizeof(d->fm_tail), s));
+        break;
+      case HRFD_MODE_AM:
+        HIP_TRY(hipMemsetAsync(d->am_tail, 0x80, sizeof(d->am_tail), s));
+        HIP_TRY(hipMemsetAsync(&d->am_x1, 0, 2 * sizeof(float), s));
+        break;
+      default:
+        HIP_TRY(hipMemsetAsync(d->ssb_tail, 0x80, sizeof(d->ssb_tail), s));
+        HIP_TRY(hipMemsetAsync(&d->ssb_x1, 0, 2 * sizeof(float) + sizeof(d->ssb_i) + sizeof(d->ssb_q), s));
+        break;
+    }
+  }
+  resets.clear();
+  return HRFD_OK;
+}
+
+struct LaunchOpts
+{
+  uint32_t out_blocks;     // layout [C][out_blocks] of the caller's output buffers
+  uint32_t out_b0;         // first block of that layout this launch fills
+  int serial;              // exact one-lane de-emphasis (replay path)
+};
+
+static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, uint32_t block_bytes,
+                     uint32_t n_blocks, uint32_t gain_db, int16_t *d_pcm, uint32_t *d_n_pcm,
+                     uint32_t *d_magnitude, uint8_t *d_allowed, int8_t *d_iq256, hipStream_t s,
+                     const LaunchOpts &opt)
+{
+  if (h == nullptr || d_iq == nullptr || d_pcm == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_process: NULL handle or buffer");
+  }
+  if (block_bytes == 0 || (block_bytes % 1024u) != 0 || block_bytes > HRFD_BLOCK_BYTES)
+  {
+    return fail(HRFD_EINVAL, "block_bytes must be a multiple of 1024 and <= %u (got %u)",
+                HRFD_BLOCK_BYTES, block_bytes);
+  }
+  if (n_blocks == 0 || opt.out_b0 + n_blocks > opt.out_blocks)
+  {
+    return fail(HRFD_EINVAL, "bad block count");
+  }
+  if (channel_stride < (uint64_t)block_bytes * n_blocks)
+  {
+    return fail(HRFD_EINVAL, "channel_stride smaller than n_blocks*block_bytes");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+
+  const uint32_t n256 = block_bytes / 16;
+  // 64 de-emphasis tiles end at n256; tile 0 is sacrificial, tile 1 must start at
+  // or before the first history sample the integer stages read (-kNeedHist).
+  int tile = (int)((n256 + kNeedHist + 62) / 63);
+  if ((tile & 1) == 0)
+  {
+    tile++;                                              // odd lane stride: no LDS bank conflicts
+  }
+  const int origin = (int)n256 - 64 * tile;
+  const int hal = ((h->warm - origin) + 63) / 64 * 64;
+  if (hal > kMaxHal)
+  {
+    return fail(HRFD_EINVAL, "internal: history %d exceeds %d", hal, kMaxHal);
+  }
+  if (n_blocks > 1 && (uint32_t)(hal + 64) * 16u > block_bytes)
+  {
+    return fail(HRFD_EINVAL, "blocks of %u bytes are too short for a multi-block call "
+                "(need >= %u); submit them one per call", block_bytes, (uint32_t)(hal + 64) * 16u);
+  }
+  if (opt.serial && n_blocks != 1)
+  {
+    return fail(HRFD_ESTATE, "internal: serial replay needs n_blocks == 1");
+  }
+
+  // configuration snapshot
+  std::vector<std::pair<uint32_t, int>> resets;
+  {
+    std::lock_guard<std::mutex> g(h->mu);
+    resets.swap(h->pending_resets);
+    if (h->cfg_dirty)
+    {
+      std::vector<uint32_t> lists((size_t)6 * h->n_channels);
+      uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
+      for (uint32_t c = 0; c < h->n_channels; c++)
+      {
+        const int m = h->h_cfg[c].mode;
+        lists[(size_t)m * h->n_channels + cnt[m]++] = c;
+      }
+      memcpy(h->list_count, cnt, sizeof(cnt));
+      // synchronous uploads: the host vectors are only valid under the lock
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipMemcpy(h->d_cfg, h->h_cfg.data(), sizeof(ChanCfg) * h->n_channels, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(h->d_lists, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice));
+      h->cfg_dirty = false;
+    }
+  }
+  int rc = apply_resets(h, s, resets);
+  if (rc != HRFD_OK)
+  {
+    return rc;
+  }
+  for (int m : {HRFD_MODE_AM, HRFD_MODE_FM, HRFD_MODE_LSB, HRFD_MODE_USB})
+  {
+    if (h->list_count[m] != 0)
+    {
+      return fail(HRFD_ESTATE, "demodulator mode %d is not built into this library yet", m);
+    }
+  }
+
+  // launch-local scratch (present flags, cross-block check values) and the
+  // magnitude buffer used when the caller does not want one
+  const size_t units = (size_t)h->n_channels * n_blocks;
+  const size_t ounits = (size_t)h->n_channels * opt.out_blocks;
+  if (std::max(units, ounits) > h->cap_units)
+  {
+    HIP_TRY(hipStreamSynchronize(s));
+    const size_t need = std::max(units, ounits);
+    size_t c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    h->cap_units = 0;
+    if ((rc = grow((void **)&h->d_present, &c1, need)) != HRFD_OK) return rc;
+    if ((rc = grow((void **)&h->d_magnitude, &c2, need * 4)) != HRFD_OK) return rc;
+    if ((rc = grow((void **)&h->d_chk_pub, &c3, need * 4)) != HRFD_OK) return rc;
+    if ((rc = grow((void **)&h->d_chk_spec, &c4, need * 4)) != HRFD_OK) return rc;
+    h->cap_units = need;
+  }
+
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint32_t) * kNumCounters, s));
+
+  RxParams P;
+  memset(&P, 0, sizeof(P));
+  P.iq = d_iq;
+  P.ch_stride = channel_stride;
+  P.block_bytes = block_bytes;
+  P.n_blocks = n_blocks;
+  P.n256 = n256;
+  P.tile = tile;
+  P.origin = origin;
+  P.hal = hal;
+  P.warm = h->warm;
+  P.serial = opt.serial;
+  P.out_blocks = opt.out_blocks;
+  P.out_b0 = opt.out_b0;
+  P.gain_db = gain_db;
+  P.state = h->d_state;
+  P.state_out = h->d_state_out;
+  P.cfg = h->d_cfg;
+  P.pcm = d_pcm;
+  P.magnitude = (d_magnitude != nullptr) ? d_magnitude : h->d_magnitude;
+  P.present = h->d_present;
+  P.iq256 = d_iq256;
+  P.atan2_lut = h->d_lut;
+  P.dbfs = h->d_dbfs;
+  P.chk_pub = h->d_chk_pub;
+  P.chk_spec = h->d_chk_spec;
+  P.counters = h->d_counters;
+
+  for (int m : {HRFD_MODE_NONE, HRFD_MODE_WBFM})
+  {
+    const uint32_t n = h->list_count[m];
+    if (n == 0)
+    {
+      continue;
+    }
+    P.chan_list = h->d_lists + (size_t)m * h->n_channels;
+    P.n_list = n;
+    const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+    if (m == HRFD_MODE_NONE)
+    {
+      hipLaunchKernelGGL(k_rx_wbfm<0>, dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_rx_wbfm<3>, dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+
+  EpilogueParams E;
+  memset(&E, 0, sizeof(E));
+  E.n_channels = h->n_channels;
+  E.n_blocks = n_blocks;
+  E.n_pcm_per_block = n256 / 32;
+  E.out_blocks = opt.out_blocks;
+  E.out_b0 = opt.out_b0;
+  E.cfg = h->d_cfg;
+  E.state = h->d_state;
+  E.state_out = h->d_state_out;
+  E.present = h->d_present;
+  E.allowed = d_allowed;
+  E.n_pcm = d_n_pcm;
+  E.chk_pub = h->d_chk_pub;
+  E.chk_spec = h->d_chk_spec;
+  E.counters = h->d_counters;
+  const uint32_t eg = (h->n_channels + 255u) / 256u;
+  hipLaunchKernelGGL(k_rx_epilogue, dim3(eg), dim3(256), 0, s, E);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_rx_commit, dim3(eg), dim3(256), 0, s, E);
+  HIP_TRY(hipGetLastError());
+  h->last_stream = s;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_rx_process_device(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride,
+                                      uint32_t block_bytes, uint32_t n_blocks, uint32_t gain_db,
+                                      int16_t *d_pcm, uint32_t *d_n_pcm, uint32_t *d_magnitude,
+                                      uint8_t *d_signal_allowed, int8_t *d_iq256k_opt, void *stream)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL handle");
+  }
+  hipStream_t s = (stream != nullptr) ? (hipStream_t)stream : h->stream;
+  const LaunchOpts opt = {n_blocks, 0, 0};
+  return rx_launch(h, d_iq, channel_stride, block_bytes, n_blocks, gain_db, d_pcm, d_n_pcm,
+                   d_magnitude, d_signal_allowed, d_iq256k_opt, s, opt);
+}
+
+extern "C" int hrfd_rx_sync(hrfd_rx *h, uint32_t *n_violations)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL handle");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->last_stream ? h->last_stream : h->stream;
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMemcpy(h->last_counters, h->d_counters, sizeof(h->last_counters), hipMemcpyDeviceToHost));
+  if (n_violations != nullptr)
+  {
+    *n_violations = h->last_counters[kCntGate] + h->last_counters[kCntSpec];
+    h->total_repairs += h->last_counters[kCntRepair];
+  }
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t block_bytes,
+                                     uint32_t n_blocks, uint32_t gain_db, int16_t *pcm,
+                                     uint32_t *n_pcm, uint32_t *magnitude, uint8_t *signal_allowed,
+                                     int8_t *iq256k_opt)
+{
+  if (h == nullptr || iq == nullptr || pcm == nullptr || n_pcm == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_process_block: NULL argument");
+  }
+  if (block_bytes == 0 || (block_bytes % 1024u) != 0 || block_bytes > HRFD_BLOCK_BYTES || n_blocks == 0)
+  {
+    return fail(HRFD_EINVAL, "block_bytes must be a multiple of 1024 and <= %u, n_blocks > 0", HRFD_BLOCK_BYTES);
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const uint32_t C = h->n_channels;
+  const size_t units = (size_t)C * n_blocks;
+  const uint32_t npcm = block_bytes / 512;
+  const size_t iq_bytes = units * block_bytes;
+  const size_t pcm_bytes = units * npcm * sizeof(int16_t);
+  const size_t iq256_bytes = units * (block_bytes / 8);
+  hipStream_t s = h->stream;
+  int rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  if ((rc = grow((void **)&h->d_iq, &h->cap_iq, iq_bytes)) != HRFD_OK) return rc;
+  if ((rc = grow((void **)&h->d_pcm, &h->cap_pcm, pcm_bytes)) != HRFD_OK) return rc;
+  if (iq256k_opt != nullptr)
+  {
+    if ((rc = grow((void **)&h->d_iq256, &h->cap_iq256, iq256_bytes)) != HRFD_OK) return rc;
+  }
+  if ((rc = grow((void **)&h->d_npcm, &h->cap_npcm, units * 4)) != HRFD_OK) return rc;
+  if ((rc = grow((void **)&h->d_allowed, &h->cap_allowed, units)) != HRFD_OK) return rc;
+  if ((rc = grow((void **)&h->d_mag_out, &h->cap_mag_out, units * 4)) != HRFD_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_iq, iq, iq_bytes, hipMemcpyHostToDevice, s));
+  // mode NONE / squelched units produce no PCM: hand back zeros rather than stale bytes
+  HIP_TRY(hipMemsetAsync(h->d_pcm, 0, pcm_bytes, s));
+
+  const uint64_t stride = (uint64_t)block_bytes * n_blocks;
+  int8_t *d_iq256 = iq256k_opt ? h->d_iq256 : nullptr;
+  uint32_t viol = 0;
+  bool done = false;
+  if (n_blocks > 1 && (uint32_t)(kMaxHal + 64) * 16u <= block_bytes)
+  {
+    // whole batch in one launch, blocks of a channel in parallel (speculative)
+    const LaunchOpts opt = {n_blocks, 0, 0};
+    rc = rx_launch(h, h->d_iq, stride, block_bytes, n_blocks, gain_db, h->d_pcm, h->d_npcm,
+                   h->d_mag_out, h->d_allowed, d_iq256, s, opt);
+    if (rc != HRFD_OK) return rc;
+    if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
+    done = (viol == 0);
+  }
+  if (!done)
+  {
+    // exact path: one block per launch (state advances in order); a launch whose
+    // de-emphasis tiles did not re-synchronise is redone on the one-lane path.
+    for (uint32_t b = 0; b < n_blocks; b++)
+    {
+      for (int attempt = 0; attempt < 2; attempt++)
+      {
+        const LaunchOpts opt = {n_blocks, b, attempt};
+        rc = rx_launch(h, h->d_iq + (size_t)b * block_bytes, stride, block_bytes, 1, gain_db,
+                       h->d_pcm, h->d_npcm, h->d_mag_out, h->d_allowed, d_iq256, s, opt);
+        if (rc != HRFD_OK) return rc;
+        if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
+        if (viol == 0) break;
+        h->replays++;
+      }
+      if (viol != 0)
+      {
+        return fail(HRFD_ESTATE, "internal: exact replay still reports %u violations", viol);
+      }
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(pcm, h->d_pcm, pcm_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(n_pcm, h->d_npcm, units * 4, hipMemcpyDeviceToHost, s));
+  if (signal_allowed != nullptr)
+  {
+    HIP_TRY(hipMemcpyAsync(signal_allowed, h->d_allowed, units, hipMemcpyDeviceToHost, s));
+  }
+  if (magnitude != nullptr)
+  {
+    HIP_TRY(hipMemcpyAsync(magnitude, h->d_mag_out, units * 4, hipMemcpyDeviceToHost, s));
+  }
+  if (iq256k_opt != nullptr)
+  {
+    HIP_TRY(hipMemcpyAsync(iq256k_opt, h->d_iq256, iq256_bytes, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  return HRFD_OK;
+}

@@ -1,0 +1,128 @@
+// hackrfdiags_amd/csrc/hrfd_device.h -- structures shared by the host side of the
+// C ABI (hrfd_api.hip) and the gfx950 kernels (hrfd_rx_kernels.hip, ...).
+#ifndef HRFD_DEVICE_H
+#define HRFD_DEVICE_H
+
+#include <stdint.h>
+
+namespace hrfd {
+
+// ---- geometry of one launch unit ("channel-block") --------------------------
+// One workgroup demodulates one block of one channel: n256 = block_bytes/16
+// samples of the 256 kS/s stream.  For blocks after the first of a call the
+// workgroup also re-derives `hal` samples of history from the tail of the
+// previous block's raw input (time-parallelism along one channel).
+constexpr int kThreads = 512;                 // 8 wave64 per workgroup
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxN256 = 16384;               // 262144-byte block
+constexpr int kWarm = 512;                    // de-emphasis warm-up (P(miss) ~1e-5 per tile)
+constexpr int kHist = 704;                    // exact history kept in front of a block (>= 644)
+constexpr int kMaxHal = 1600;                 // >= kWarm - origin for every block size, multiple of 64
+constexpr int kNeedHist = 644;                // first history sample the integer stages read
+constexpr int kMaxNV = kMaxN256 + kMaxHal;    // floats of the v/y stream in LDS
+
+// carried history sizes of the integer stages ("carried state")
+constexpr int kWbS = 4, kWbU = 8, kWbV = 38;  // WBFM: last N-M inputs of D(8,4), D(12,4), D(40,2)
+constexpr int kFmTail = 704;                  // FM:  iq256 samples (>= 684)
+constexpr int kAmTail = 320;                  // AM/SSB: iq256 samples (>= 260)
+constexpr int kSsbHist = 32;                  // 8 kS/s I/Q history (>= 30)
+
+// ---- per-channel persistent state (device memory, one per channel) ----------
+struct alignas(16) ChanState
+{
+  // front end: the last 16 raw input bytes (7-sample halo per rail, A2)
+  int8_t fe_tail[16];
+  // squelch: SignalTracker state (A5) -- 1 = Tracking
+  uint32_t tracking;
+  uint32_t pad0[3];
+
+  // WBFM (W2/W3): theta of the last sample, b1*x[n-1], y[n-1], stage histories
+  float wb_theta;
+  float wb_p;
+  float wb_y;
+  float pad1;
+  int16_t wb_s[kWbS];
+  int16_t wb_u[kWbU];
+  int16_t wb_v[kWbV + 2];
+
+  // FM (F1-F4): last kFmTail samples of the 256 kS/s stream it consumed
+  // (stored as offset-binary index bytes i,q), everything else is derived.
+  uint8_t fm_tail[2 * kFmTail];
+
+  // AM (M1/M2) and SSB (S1/S2): iq256 tails + 8 kS/s recurrences
+  uint8_t am_tail[2 * kAmTail];
+  float am_x1, am_y1;                          // dc-removal x[n-1], y[n-1]
+  uint8_t ssb_tail[2 * kAmTail];
+  float ssb_x1, ssb_y1;
+  int16_t ssb_i[kSsbHist];                     // last 8 kS/s I samples (delay line)
+  int16_t ssb_q[kSsbHist];                     // last 8 kS/s Q samples (Hilbert)
+};
+
+// ---- per-channel configuration (host mirror uploaded when dirty) ------------
+struct alignas(16) ChanCfg
+{
+  int32_t mode;                                // HRFD_MODE_*
+  int32_t threshold;                           // dBFS
+  float gain_am, gain_fm, gain_wbfm, gain_ssb;
+  int32_t lsb;                                 // SSB sideband
+  int32_t pad;
+};
+
+// ---- launch parameters -------------------------------------------------------
+struct RxParams
+{
+  const int8_t *iq;            // [C][n_blocks][block_bytes]
+  uint64_t ch_stride;          // bytes between channels
+  uint32_t block_bytes;
+  uint32_t n_blocks;
+  uint32_t n256;               // block_bytes / 16
+  int32_t tile;                // de-emphasis tile length T (odd)
+  int32_t origin;              // tile 0 (sacrificial) starts here; tile 1 starts <= -kNeedHist; tiles end at n256
+  int32_t hal;                 // history samples re-derived for blocks b > 0
+  int32_t warm;                // de-emphasis warm-up length (kWarm; tests shrink it)
+  int32_t serial;              // 1: exact one-lane recurrence (replay path, n_blocks == 1)
+  uint32_t out_blocks;         // outputs are laid out [C][out_blocks][...]; this launch fills
+  uint32_t out_b0;             //   blocks out_b0 .. out_b0 + n_blocks - 1 of that layout
+  const uint32_t *chan_list;   // channels of this launch (all in the same mode)
+  uint32_t n_list;
+  uint32_t gain_db;
+  ChanState *state;            // read at b == 0
+  ChanState *state_out;        // written by the last block (== state when n_blocks == 1)
+  const ChanCfg *cfg;
+  int16_t *pcm;                // [C][n_blocks][n256/32]
+  uint32_t *magnitude;         // [C][n_blocks] block-mean magnitude
+  uint8_t *present;            // [C][n_blocks] detector result (before the tracker)
+  int8_t *iq256;               // optional [C][n_blocks][2*n256]
+  const float *atan2_lut;      // [256][256]
+  const int32_t *dbfs;         // [257]
+  float *chk_pub;              // [C][n_blocks] y at (n256 - kHist + 59) of this block
+  float *chk_spec;             // [C][n_blocks] y at (-kHist + 59) as speculated by this block
+  uint32_t *counters;          // kCnt*
+};
+
+struct EpilogueParams
+{
+  uint32_t n_channels;
+  uint32_t n_blocks;
+  uint32_t n_pcm_per_block;
+  uint32_t out_blocks, out_b0; // layout of allowed / n_pcm (see RxParams)
+  const ChanCfg *cfg;
+  ChanState *state;
+  const ChanState *state_out;
+  const uint8_t *present;
+  uint8_t *allowed;            // optional out
+  uint32_t *n_pcm;             // optional out
+  const float *chk_pub;
+  const float *chk_spec;
+  uint32_t *counters;          // kCnt*
+};
+
+constexpr int kCntRepair = 0;  // de-emphasis tiles re-run in place because their warm-up had not re-synchronised
+constexpr int kCntGate = 1;    // blocks b > 0 whose squelch gate turned out closed
+constexpr int kCntSpec = 2;    // blocks b > 0 whose first tile disagrees with the predecessor
+constexpr int kCntCommit = 3;  // 1 when the epilogue committed the pending state
+constexpr int kNumCounters = 8;
+
+} // namespace hrfd
+
+#endif // HRFD_DEVICE_H

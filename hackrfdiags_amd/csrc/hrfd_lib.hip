@@ -1,0 +1,5 @@
+// hackrfdiags_amd/csrc/hrfd_lib.hip -- unity translation unit of libhrfd.so.
+// Kernels and their launchers live in one TU so that no relocatable device code
+// / device link step is needed (plain `hipcc -c` + host link).
+#include "hrfd_rx_kernels.hip"
+#include "hrfd_api.hip"

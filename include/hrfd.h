@@ -1,0 +1,194 @@
+/* include/hrfd.h -- C ABI of libhrfd.so, the MI355X (gfx950) implementation of the
+ * HackRfDiags demodulation / modulation hot path.
+ *
+ * Plain C: opaque handles, raw pointers, sizes, int return codes.  No C++ or
+ * torch types cross this boundary.  Every entry point names the reference
+ * interface it stands in for (file:line under /root/reference/radioDiags).
+ * The reference-named C++ classes in hackrfdiags_amd/csrc/shim/ are thin
+ * wrappers over these calls (INTEGRATION.md shows how they are linked in).
+ *
+ * Conventions
+ *   - return 0 on success, a negative HRFD_E* code on failure
+ *     (hrfd_last_error() returns a human-readable message for the calling thread)
+ *   - "channel" = one independent IQ stream = one IqDataProcessor + its four
+ *     demodulators in the reference (Radio.cc:164-203)
+ *   - one "block" = 262144 bytes of interleaved int8 IQ at 2.048 MS/s = 64 ms
+ *     (hackRf/hackrf.c:101, DataConsumer.h:15) -> 512 int16 PCM samples at 8 kS/s
+ *   - handles are single-caller for process calls; setters may be called from
+ *     another thread and take effect at the next process call (the reference
+ *     has the same unsynchronised CLI-thread setters)
+ */
+#ifndef HRFD_H
+#define HRFD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HRFD_VERSION 1
+
+/* error codes */
+#define HRFD_OK            0
+#define HRFD_EINVAL       -1   /* bad argument (size not a multiple of 512 bytes, NULL, ...) */
+#define HRFD_ENODEV       -2   /* no HIP device / HIP runtime failure */
+#define HRFD_ENOMEM       -3
+#define HRFD_ESTATE       -4   /* handle misuse */
+
+/* demodulator modes == IqDataProcessor::demodulatorType (hdr_diags/IqDataProcessor.h:21) */
+#define HRFD_MODE_NONE 0
+#define HRFD_MODE_AM   1
+#define HRFD_MODE_FM   2
+#define HRFD_MODE_WBFM 3
+#define HRFD_MODE_LSB  4
+#define HRFD_MODE_USB  5
+
+#define HRFD_ALL_CHANNELS 0xffffffffu
+
+#define HRFD_BLOCK_BYTES   262144u   /* DATA_CONSUMER_BUFFER_SIZE, hdr_diags/DataConsumer.h:15 */
+#define HRFD_PCM_PER_BLOCK 512u      /* PCM_BLOCK_SIZE, hdr_diags/BasebandDataProcessor.h:16 */
+
+typedef struct hrfd_rx hrfd_rx;       /* C channels of IqDataProcessor + demodulators */
+typedef struct hrfd_demod hrfd_demod; /* C channels of one {Am,Fm,WbFm,Ssb}Demodulator */
+typedef struct hrfd_mod hrfd_mod;     /* C channels of SsbModulator / interpolateSignal */
+
+const char *hrfd_last_error(void);
+int hrfd_version(void);
+/* number of visible HIP devices (0 when there is no GPU; never fails) */
+int hrfd_device_count(void);
+
+/* ------------------------------------------------------------------------------
+ * Receive, outer boundary.
+ * Replaces: IqDataProcessor::IqDataProcessor / ~IqDataProcessor
+ *           (src_diags/IqDataProcessor.cc:56-160) for n_channels streams at once,
+ *           together with the four demodulator objects Radio.cc:179-197 creates.
+ * device < 0 selects the current HIP device.
+ */
+int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out);
+int hrfd_rx_destroy(hrfd_rx *h);
+
+/* IqDataProcessor::setDemodulatorMode (IqDataProcessor.cc:346-375); LSB/USB also
+ * select the SSB demodulator's sideband, as the reference does. */
+int hrfd_rx_set_mode(hrfd_rx *h, uint32_t channel, int mode);
+/* {Am,Fm,WbFm,Ssb}Demodulator::setDemodulatorGain (e.g. WbFmDemodulator.cc:299) */
+int hrfd_rx_set_gain(hrfd_rx *h, uint32_t channel, int mode, float gain);
+/* IqDataProcessor::setSignalDetectThreshold (IqDataProcessor.cc:392-405), dBFS */
+int hrfd_rx_set_threshold(hrfd_rx *h, uint32_t channel, int32_t threshold);
+/* X::resetDemodulator (e.g. WbFmDemodulator.cc:265-278; NB: the WBFM de-emphasis
+ * filter is not reset there, and is not reset here) */
+int hrfd_rx_reset_demod(hrfd_rx *h, uint32_t channel, int mode);
+
+/* IqDataProcessor::acceptIqData (IqDataProcessor.cc:926-1038) for every channel,
+ * n_blocks consecutive blocks per channel in one call.  Host buffers:
+ *   iq            [n_channels][n_blocks][block_bytes] int8, interleaved I,Q, 2.048 MS/s
+ *   block_bytes   multiple of 1024, <= 262144 (the reference's caller always
+ *                 passes 262144, DataConsumer.cc:341)
+ *   gain_db       radio_adjustableReceiveGainInDb (Radio.cc:15) at call time
+ *   pcm           [n_channels][n_blocks][block_bytes/512] int16   (out)
+ *   n_pcm         [n_channels][n_blocks] samples actually produced: block_bytes/512,
+ *                 or 0 when squelched / mode NONE (the reference then makes no
+ *                 PCM callback)                                     (out)
+ *   magnitude     [n_channels][n_blocks] Squelch::getSignalMagnitude() (out, may be NULL)
+ *   signal_allowed[n_channels][n_blocks] Squelch::run() result       (out, may be NULL)
+ *   iq256k_opt    [n_channels][n_blocks][block_bytes/8] decimatedData after the
+ *                 Fs/4 mix -- what `enable iqdump` sends by UDP      (out, may be NULL)
+ * Blocking: returns when the outputs are in the host buffers.
+ */
+int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t block_bytes,
+                          uint32_t n_blocks, uint32_t gain_db, int16_t *pcm,
+                          uint32_t *n_pcm, uint32_t *magnitude,
+                          uint8_t *signal_allowed, int8_t *iq256k_opt);
+
+/* Same work with every buffer already resident in device memory (HBM); this is
+ * the entry the batched benchmark drives.  d_iq is [n_channels][n_blocks]
+ * [block_bytes] with channel_stride bytes between channels.  Asynchronous on
+ * `stream` (a hipStream_t, NULL = the handle's own stream).  Optional outputs
+ * may be NULL.  When n_blocks > 1 the blocks of one channel are demodulated
+ * concurrently: the call speculates that every squelch gate in the batch is
+ * open and that the WBFM de-emphasis tiles re-synchronise; both
+ * assumptions are verified on the device and hrfd_rx_sync() reports them.
+ */
+int hrfd_rx_process_device(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride,
+                           uint32_t block_bytes, uint32_t n_blocks, uint32_t gain_db,
+                           int16_t *d_pcm, uint32_t *d_n_pcm, uint32_t *d_magnitude,
+                           uint8_t *d_signal_allowed, int8_t *d_iq256k_opt,
+                           void *stream);
+/* Waits for the last hrfd_rx_process_device call.  *n_violations (may be NULL)
+ * receives the number of (channel, block) units whose speculation failed in
+ * that call (0 = every output is exact); when it is non-zero the per-channel
+ * state has NOT been advanced and the caller should resubmit the batch one block
+ * per call (n_blocks == 1 is always exact).  hrfd_rx_process_block does this
+ * by itself. */
+int hrfd_rx_sync(hrfd_rx *h, uint32_t *n_violations);
+
+/* ------------------------------------------------------------------------------
+ * Receive, inner boundary: one demodulator class, n_channels instances.
+ * Replaces: X::X(pcmCallbackPtr), X::acceptIqData(int8_t*,uint32_t),
+ *           X::setDemodulatorGain, X::resetDemodulator,
+ *           SsbDemodulator::set{Lsb,Usb}DemodulationMode
+ *           (WbFmDemodulator.h:23-31, FmDemodulator.h:23-31, AmDemodulator.h:23-31,
+ *            SsbDemodulator.h:24-34).
+ * Input is 256 kS/s int8 IQ, already mixed; bytes_per_channel a multiple of 64,
+ * <= 32768 (the reference's fixed member arrays).  The PCM callback of the
+ * reference becomes the pcm/n_pcm output pair; the C++ shim invokes the callback.
+ */
+int hrfd_demod_create(int mode, uint32_t n_channels, int device, hrfd_demod **out);
+int hrfd_demod_destroy(hrfd_demod *h);
+int hrfd_demod_reset(hrfd_demod *h, uint32_t channel);
+int hrfd_demod_set_gain(hrfd_demod *h, uint32_t channel, float gain);
+int hrfd_demod_set_sideband(hrfd_demod *h, uint32_t channel, int lsb);
+int hrfd_demod_process(hrfd_demod *h, const int8_t *iq256k, uint32_t bytes_per_channel,
+                       int16_t *pcm, uint32_t *n_pcm);
+
+/* ------------------------------------------------------------------------------
+ * Transmit: PCM -> int8 IQ through the 8-stage x256 half-band interpolator.
+ * kind HRFD_MOD_SSB replaces SsbModulator::acceptData (SsbModulator.cc:455-470)
+ * incl. set{Lsb,Usb}ModulationMode / resetModulator (SsbModulator.h:23-35);
+ * kind HRFD_MOD_INTERP replaces the signals/interpolateSignal tool
+ * (signals/interpolateSignal.cc:250-374: int16 IQ pairs in, its own stage-1 table).
+ */
+#define HRFD_MOD_SSB    1
+#define HRFD_MOD_INTERP 2
+int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out);
+int hrfd_mod_destroy(hrfd_mod *h);
+int hrfd_mod_reset(hrfd_mod *h, uint32_t channel);
+int hrfd_mod_set_sideband(hrfd_mod *h, uint32_t channel, int lsb);
+/* pcm [n_channels][n_per_channel] int16 (SSB) or [n_channels][2*n_per_channel]
+ * int16 IQ pairs (INTERP); iq_out [n_channels][512*n_per_channel] int8;
+ * *out_bytes = 512*n_per_channel (bytes per channel, as the reference returns). */
+int hrfd_mod_process(hrfd_mod *h, const int16_t *pcm, uint32_t n_per_channel,
+                     int8_t *iq_out, uint32_t *out_bytes);
+int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32_t n_per_channel,
+                            int8_t *d_iq_out, void *stream);
+int hrfd_mod_sync(hrfd_mod *h);
+
+/* ------------------------------------------------------------------------------
+ * Nco (Nco/Nco.cc:186-257, Nco/PhaseAccumulator.cc:157-181): n_channels
+ * oscillators advanced `count` samples each; fast != 0 selects runFast's table.
+ * i_out/q_out are [n_channels][count] float host buffers.
+ */
+typedef struct hrfd_nco hrfd_nco;
+int hrfd_nco_create(uint32_t n_channels, float sample_rate, float frequency, int device,
+                    hrfd_nco **out);
+int hrfd_nco_destroy(hrfd_nco *h);
+int hrfd_nco_set_frequency(hrfd_nco *h, uint32_t channel, float frequency);
+int hrfd_nco_reset(hrfd_nco *h, uint32_t channel);
+int hrfd_nco_run(hrfd_nco *h, int fast, uint32_t count, float *i_out, float *q_out);
+
+/* ------------------------------------------------------------------------------
+ * Introspection used by the tests: copy out the constant tables the kernels use.
+ * name: "HB1","HB2","HB3","WBFM_D1","POST_D12","AUDIO_D40","FM_TUNER_D32","AM_D1",
+ * "AM_D2","AM_D3","SSB_DELAY","SSB_HILBERT","INTERP_HB8","INTERP_HB3","INTERP_HB2",
+ * "INTERP_HB1","INTERPSIG_S1" (Q15 taps).  Returns the tap count, 0 if unknown. */
+int hrfd_q15_table(const char *name, int16_t *out, int cap);
+/* host-built atan2 table [256][256] (float bits) and dBFS table [257] */
+int hrfd_atan2_table(float *out);
+int hrfd_dbfs_table(int32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HRFD_H */
