@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline measurement (BASELINE.json).
+
+A "step" is one pass of the fused demodulator over one batch of synthetic input
+that is already resident in HBM: `channels` independent WBFM channels x `blocks`
+consecutive 262144-byte blocks of int8 IQ (2.048 MS/s) -> 8 kS/s int16 PCM.
+Streams continue from step to step (per-channel state is carried on the device).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: channels are independent, so every rank owns its own `channels`
+channels on its own GPU (weak scaling); there is no data-path collective.  The
+ranks only meet for the barrier around the timed region and a MAX over elapsed
+times.  Rank 0 prints ONE JSON line.
+
+Extra objects in the JSON line:
+  roofline      algorithmic HBM bytes per launch / mean duration of the dominant
+                kernel, measured with HIP events on the launch stream during the
+                timed region, against the 8 TB/s HBM3E peak
+  cpu_baseline  the reference's own CPU chain (oracle/_ref, compiled from the
+                reference sources) timed on this box's host cores on a bounded
+                sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BLOCK = 262144
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_fm_batch(channels, blocks, device, first_channel=0):
+    """FM test signal of SURVEY.md 8(d), generated on the GPU: carrier at -64 kHz,
+    +-30 kHz deviation by a (300 + 100*(c mod 32)) Hz tone, amplitude 100, uniform
+    noise in [-3,4].  (Same signal family as hackrfdiags_amd/synth.py; the noise
+    comes from torch's generator here, so the bytes differ from the test vectors.)"""
+    n = blocks * (BLOCK // 2)
+    out = torch.empty((channels, blocks, BLOCK), dtype=torch.int8, device=device)
+    k = torch.arange(n, dtype=torch.float64, device=device)
+    gen = torch.Generator(device=device)
+    for c in range(channels):
+        ch = first_channel + c
+        f_c = 300.0 + 100.0 * (ch % 32)
+        beta = 30000.0 / f_c
+        phi = (2.0 * np.pi * (-64000.0) / 2048000.0) * k - beta * (torch.cos((2.0 * np.pi * f_c / 2048000.0) * k) - 1.0)
+        gen.manual_seed(12345 + ch)
+        noise = torch.randint(-3, 5, (2, n), device=device, generator=gen, dtype=torch.int32)
+        i = torch.round(100.0 * torch.cos(phi)).to(torch.int32) + noise[0]
+        q = torch.round(100.0 * torch.sin(phi)).to(torch.int32) + noise[1]
+        iq = torch.stack([i, q], dim=1).to(torch.int8)          # [n, 2] interleaved
+        out[c] = iq.reshape(blocks, BLOCK)
+    return out
+
+
+def make_random_batch(channels, blocks, device, first_channel=0):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1 + first_channel)
+    return torch.randint(-128, 128, (channels, blocks, BLOCK), dtype=torch.int8, device=device, generator=gen)
+
+
+def cpu_baseline(seconds, threads):
+    """Reference CPU chain (IqDataProcessor::acceptIqData in WBFM mode), one
+    channel per thread, each looping over the same 8-block FM test signal."""
+    from hackrfdiags_amd import synth
+    from tests import reflib
+    kind = "reference"
+    try:
+        eng = reflib.Ref()
+    except (FileNotFoundError, OSError):
+        eng = reflib.Oracle()          # our restatement, if the prebuilt reference did not travel
+        kind = "port"
+    nb = 8
+    x = synth.make_input("fmtone", 0, nb).reshape(nb, BLOCK)
+    handles = []
+    for _ in range(threads):
+        h = eng.rx()
+        h.set_mode(reflib.WBFM)
+        handles.append(h)
+    counts = [0] * threads
+    stop = time.perf_counter() + seconds
+
+    def work(i):
+        h = handles[i]
+        n = 0
+        while time.perf_counter() < stop:
+            for b in range(nb):
+                h.process(x[b])
+            n += nb
+        counts[i] = n
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    blocks = sum(counts)
+    return {
+        "value": round(blocks * (BLOCK // 2) / dt / 1e6, 2),
+        "unit": "MSamples/s",
+        "cores": threads,
+        "kind": kind,
+        "sample": f"{blocks} blocks of 262144 B (FM test signal, WBFM mode) over {dt:.1f} s, "
+                  f"{threads} thread(s), one channel per thread",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=256, help="channels per GPU (BASELINE config 2)")
+    ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
+    ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libhrfd has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
+
+    from hackrfdiags_amd import api
+
+    C, B = args.channels, args.blocks
+    gen = make_fm_batch if args.signal == "fmtone" else make_random_batch
+    iq = gen(C, B, device, first_channel=rank * C)
+    pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=device)
+    n_pcm = torch.zeros((C, B), dtype=torch.int32, device=device)
+    rx = api.Rx(C, device=local_rank)
+    rx.set_mode(api.WBFM)
+    stream = torch.cuda.Stream(device=device)
+    rx.debug_enable_timing(max(args.steps, 1))
+
+    def step():
+        rx.process_device(iq.data_ptr(), B * BLOCK, BLOCK, B, pcm.data_ptr(), d_n_pcm=n_pcm.data_ptr(),
+                          stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    rx.sync()
+    rx.debug_enable_timing(max(args.steps, 1))          # restart the slot counter
+
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    stream.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    rx.sync()
+    counters = rx.debug_counters()
+    kernel_ms = [rx.debug_kernel_ms(i) for i in range(args.steps)]
+    produced = int(n_pcm.sum().item())
+    assert produced == C * B * 512, f"PCM samples produced {produced} != {C * B * 512}"
+
+    samples_per_step = C * B * (BLOCK // 2)
+    value = world * samples_per_step * args.steps / elapsed / 1e6            # MSamples/s, whole job
+    algo_bytes = C * B * (BLOCK + 1024 + 4)                                   # 2.0078 B / IQ sample
+    mean_ms = float(np.mean(kernel_ms))
+    achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        line = {
+            "metric": "IQ MSamples/s demodulated (2.048 MS/s->8 kS/s WBFM) per GPU; % HBM roofline",
+            "value": round(value, 1),
+            "unit": "MSamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int8 IQ -> Q15 int16/int32 + f32 recurrence -> int16 PCM",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{C} concurrent WBFM channels per GPU at 2.048 MS/s (BASELINE config 2), "
+                            f"{B} blocks of 262144 B per channel per step, input resident in HBM",
+                "channels_per_gpu": C, "blocks_per_step": B, "signal": args.signal,
+                "parallelism": f"channels sharded, {world} rank(s), no data-path collective",
+            },
+            "per_gpu_value": round(value / world, 1),
+            "realtime_channels_per_gpu": int(value / world / 2.048),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "hrfd::k_rx_wbfm<3>",
+                "kernel_ms_mean": round(mean_ms, 4),
+                "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+            "verification": {"uncommitted_launches": counters[5], "tiles_repaired_in_place": counters[4],
+                             "launches": counters[6]},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, os.cpu_count() or 1)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,10 @@ def load() -> C.CDLL:
     L.hrfd_rx_sync.argtypes = [_vp, _u32p]
     L.hrfd_rx_debug_set_warm.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_counters.argtypes = [_vp, _u32p]
+    L.hrfd_rx_debug_set_stagger.argtypes = [_vp, C.c_int]
+    L.hrfd_rx_debug_stamps.argtypes = [_vp, C.c_uint32, _vp]
+    L.hrfd_rx_debug_enable_timing.argtypes = [_vp, C.c_int]
+    L.hrfd_rx_debug_kernel_ms.argtypes = [_vp, C.c_int, _f32p]
     L.hrfd_q15_table.argtypes = [C.c_char_p, _i16p, C.c_int]
     L.hrfd_atan2_table.argtypes = [_f32p]
     L.hrfd_dbfs_table.argtypes = [_i32p]

@@ -86,7 +86,30 @@ class Rx:
     def debug_set_warm(self, warm: int):
         check(self.L.hrfd_rx_debug_set_warm(self.h, warm), "hrfd_rx_debug_set_warm")
 
+    def debug_enable_timing(self, slots=1):
+        """HIP events around the demodulator kernels of every launch (slot = launch % slots)."""
+        check(self.L.hrfd_rx_debug_enable_timing(self.h, int(slots)), "hrfd_rx_debug_enable_timing")
+
+    def debug_kernel_ms(self, slot=0) -> float:
+        ms = C.c_float(0)
+        check(self.L.hrfd_rx_debug_kernel_ms(self.h, int(slot), C.byref(ms)), "hrfd_rx_debug_kernel_ms")
+        return float(ms.value)
+
+    def debug_stamps(self, groups: int, read: bool = False):
+        """groups > 0, read=False: allocate stamp storage; read=True: fetch [groups, 8] uint64."""
+        if not read:
+            check(self.L.hrfd_rx_debug_stamps(self.h, groups, None), "hrfd_rx_debug_stamps")
+            return None
+        out = np.zeros((groups, 8), dtype=np.uint64)
+        check(self.L.hrfd_rx_debug_stamps(self.h, groups, _ptr(out)), "hrfd_rx_debug_stamps")
+        return out
+
+    def debug_set_stagger(self, units: int):
+        check(self.L.hrfd_rx_debug_set_stagger(self.h, units), "hrfd_rx_debug_set_stagger")
+
     def debug_counters(self):
+        """[repairs, gate_viol, spec_viol, committed, total_repairs, total_uncommitted_launches,
+        total_launches, host_replays] -- the first four describe the last launch."""
         out = (C.c_uint32 * 8)()
         check(self.L.hrfd_rx_debug_counters(self.h, out), "hrfd_rx_debug_counters")
         return list(out)

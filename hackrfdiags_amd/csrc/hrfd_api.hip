@@ -171,8 +171,15 @@ struct hrfd_rx
   uint32_t replays = 0;                // launches redone on the exact path (diagnostic)
   uint32_t total_repairs = 0;          // de-emphasis tiles repaired in place since creation
 
+  // measurement hook: HIP events around the demodulator kernels of a launch
+  std::vector<hipEvent_t> ev;           // 2 events per slot; slot = launch index % slots
+  uint32_t ev_launches = 0;
+
   // test hooks
+  unsigned long long *d_dbg = nullptr;  // optional phase stamps (hrfd_rx_debug_stamps)
+  size_t dbg_cap = 0;
   int warm = kWarm;
+  int stagger = 4;
   uint32_t last_counters[kNumCounters] = {0};
 };
 
@@ -190,6 +197,10 @@ static int rx_free(hrfd_rx *h)
   for (void *p : ptrs)
   {
     if (p) (void)hipFree(p);
+  }
+  for (hipEvent_t e : h->ev)
+  {
+    (void)hipEventDestroy(e);
   }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -366,6 +377,81 @@ extern "C" int hrfd_rx_debug_set_warm(hrfd_rx *h, int warm)
   return HRFD_OK;
 }
 
+// measurement hook (not in the public header): bracket the demodulator kernels
+// of every launch with HIP events recorded on the launch stream.  `slots` event
+// pairs are used round-robin (launch i -> slot i % slots); after a sync,
+// hrfd_rx_debug_kernel_ms(h, slot, &ms) returns the elapsed time of that launch.
+extern "C" int hrfd_rx_debug_enable_timing(hrfd_rx *h, int slots)
+{
+  if (h == nullptr || slots < 0 || slots > 4096)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_enable_timing: 0..4096 slots");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  for (hipEvent_t e : h->ev)
+  {
+    (void)hipEventDestroy(e);
+  }
+  h->ev.clear();
+  h->ev_launches = 0;
+  for (int i = 0; i < 2 * slots; i++)
+  {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    h->ev.push_back(e);
+  }
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_rx_debug_kernel_ms(hrfd_rx *h, int slot, float *ms)
+{
+  if (h == nullptr || ms == nullptr || slot < 0 || (size_t)(2 * slot + 1) >= h->ev.size())
+  {
+    return fail(HRFD_EINVAL, "timing slot out of range");
+  }
+  HIP_TRY(hipEventElapsedTime(ms, h->ev[2 * slot], h->ev[2 * slot + 1]));
+  return HRFD_OK;
+}
+
+// diagnostic hook: per-workgroup cycle stamps at the phase boundaries of k_rx_wbfm<3>
+// (slots 0..5; see HRFD_STAMP in hrfd_rx_kernels.hip).  cap_groups = 0 turns it off.
+extern "C" int hrfd_rx_debug_stamps(hrfd_rx *h, uint32_t cap_groups, unsigned long long *host_out)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  if (host_out != nullptr && h->d_dbg != nullptr)
+  {
+    HIP_TRY(hipMemcpy(host_out, h->d_dbg, h->dbg_cap * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return HRFD_OK;
+  }
+  if (h->d_dbg)
+  {
+    (void)hipFree(h->d_dbg);
+    h->d_dbg = nullptr;
+    h->dbg_cap = 0;
+  }
+  if (cap_groups > 0)
+  {
+    HIP_TRY(hipMalloc((void **)&h->d_dbg, (size_t)cap_groups * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_dbg, 0, (size_t)cap_groups * 8 * sizeof(unsigned long long)));
+    h->dbg_cap = (size_t)cap_groups * 8;
+  }
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_rx_debug_set_stagger(hrfd_rx *h, int units)
+{
+  if (h == nullptr || units < 0)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_set_stagger: 0..64");
+  }
+  h->stagger = units;
+  return HRFD_OK;
+}
+
 extern "C" int hrfd_rx_debug_counters(hrfd_rx *h, uint32_t *out8)
 {
   if (h == nullptr || out8 == nullptr)
@@ -374,7 +460,6 @@ extern "C" int hrfd_rx_debug_counters(hrfd_rx *h, uint32_t *out8)
   }
   memcpy(out8, h->last_counters, sizeof(h->last_counters));
   out8[kNumCounters - 1] = h->replays;
-  out8[kNumCounters - 2] = h->total_repairs;
   return HRFD_OK;
 }
 
@@ -534,7 +619,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     h->cap_units = need;
   }
 
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint32_t) * kNumCounters, s));
+  HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint32_t) * kCntSticky, s));   // the sticky totals survive
 
   RxParams P;
   memset(&P, 0, sizeof(P));
@@ -548,6 +633,8 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.hal = hal;
   P.warm = h->warm;
   P.serial = opt.serial;
+  P.stagger = h->stagger & 63;
+  P.dbg_flags = h->stagger >> 8;
   P.out_blocks = opt.out_blocks;
   P.out_b0 = opt.out_b0;
   P.gain_db = gain_db;
@@ -563,7 +650,14 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.chk_pub = h->d_chk_pub;
   P.chk_spec = h->d_chk_spec;
   P.counters = h->d_counters;
+  P.dbg = nullptr;
 
+  const size_t ev_slots = h->ev.size() / 2;
+  const size_t ev_slot = ev_slots ? (h->ev_launches % ev_slots) : 0;
+  if (ev_slots)
+  {
+    HIP_TRY(hipEventRecord(h->ev[2 * ev_slot], s));
+  }
   for (int m : {HRFD_MODE_NONE, HRFD_MODE_WBFM})
   {
     const uint32_t n = h->list_count[m];
@@ -574,6 +668,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     P.chan_list = h->d_lists + (size_t)m * h->n_channels;
     P.n_list = n;
     const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+    P.dbg = (h->d_dbg != nullptr && (size_t)grid * 8 <= h->dbg_cap && m == HRFD_MODE_WBFM) ? h->d_dbg : nullptr;
     if (m == HRFD_MODE_NONE)
     {
       hipLaunchKernelGGL(k_rx_wbfm<0>, dim3(grid), dim3(kThreads), 0, s, P);
@@ -583,6 +678,12 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       hipLaunchKernelGGL(k_rx_wbfm<3>, dim3(grid), dim3(kThreads), 0, s, P);
     }
     HIP_TRY(hipGetLastError());
+  }
+
+  if (ev_slots)
+  {
+    HIP_TRY(hipEventRecord(h->ev[2 * ev_slot + 1], s));
+    h->ev_launches++;
   }
 
   EpilogueParams E;
@@ -635,10 +736,10 @@ extern "C" int hrfd_rx_sync(hrfd_rx *h, uint32_t *n_violations)
   hipStream_t s = h->last_stream ? h->last_stream : h->stream;
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipMemcpy(h->last_counters, h->d_counters, sizeof(h->last_counters), hipMemcpyDeviceToHost));
+  h->total_repairs = h->last_counters[kCntTotRepair];
   if (n_violations != nullptr)
   {
     *n_violations = h->last_counters[kCntGate] + h->last_counters[kCntSpec];
-    h->total_repairs += h->last_counters[kCntRepair];
   }
   return HRFD_OK;
 }
@@ -732,3 +833,26 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
   HIP_TRY(hipStreamSynchronize(s));
   return HRFD_OK;
 }
+
+// ------------------------------------------------------------------ not yet built
+// Entry points of include/hrfd.h whose kernels are still being written.  They
+// fail loudly (HRFD_ESTATE) -- there is no CPU stand-in behind them.
+#define HRFD_TODO(name) return fail(HRFD_ESTATE, name ": this entry point is not built into libhrfd.so yet")
+extern "C" int hrfd_demod_create(int, uint32_t, int, hrfd_demod **) { HRFD_TODO("hrfd_demod_create"); }
+extern "C" int hrfd_demod_destroy(hrfd_demod *) { HRFD_TODO("hrfd_demod_destroy"); }
+extern "C" int hrfd_demod_reset(hrfd_demod *, uint32_t) { HRFD_TODO("hrfd_demod_reset"); }
+extern "C" int hrfd_demod_set_gain(hrfd_demod *, uint32_t, float) { HRFD_TODO("hrfd_demod_set_gain"); }
+extern "C" int hrfd_demod_set_sideband(hrfd_demod *, uint32_t, int) { HRFD_TODO("hrfd_demod_set_sideband"); }
+extern "C" int hrfd_demod_process(hrfd_demod *, const int8_t *, uint32_t, int16_t *, uint32_t *) { HRFD_TODO("hrfd_demod_process"); }
+extern "C" int hrfd_mod_create(int, uint32_t, int, hrfd_mod **) { HRFD_TODO("hrfd_mod_create"); }
+extern "C" int hrfd_mod_destroy(hrfd_mod *) { HRFD_TODO("hrfd_mod_destroy"); }
+extern "C" int hrfd_mod_reset(hrfd_mod *, uint32_t) { HRFD_TODO("hrfd_mod_reset"); }
+extern "C" int hrfd_mod_set_sideband(hrfd_mod *, uint32_t, int) { HRFD_TODO("hrfd_mod_set_sideband"); }
+extern "C" int hrfd_mod_process(hrfd_mod *, const int16_t *, uint32_t, int8_t *, uint32_t *) { HRFD_TODO("hrfd_mod_process"); }
+extern "C" int hrfd_mod_process_device(hrfd_mod *, const int16_t *, uint32_t, int8_t *, void *) { HRFD_TODO("hrfd_mod_process_device"); }
+extern "C" int hrfd_mod_sync(hrfd_mod *) { HRFD_TODO("hrfd_mod_sync"); }
+extern "C" int hrfd_nco_create(uint32_t, float, float, int, hrfd_nco **) { HRFD_TODO("hrfd_nco_create"); }
+extern "C" int hrfd_nco_destroy(hrfd_nco *) { HRFD_TODO("hrfd_nco_destroy"); }
+extern "C" int hrfd_nco_set_frequency(hrfd_nco *, uint32_t, float) { HRFD_TODO("hrfd_nco_set_frequency"); }
+extern "C" int hrfd_nco_reset(hrfd_nco *, uint32_t) { HRFD_TODO("hrfd_nco_reset"); }
+extern "C" int hrfd_nco_run(hrfd_nco *, int, uint32_t, float *, float *) { HRFD_TODO("hrfd_nco_run"); }

@@ -12,7 +12,7 @@ namespace hrfd {
 // samples of the 256 kS/s stream.  For blocks after the first of a call the
 // workgroup also re-derives `hal` samples of history from the tail of the
 // previous block's raw input (time-parallelism along one channel).
-constexpr int kThreads = 512;                 // 8 wave64 per workgroup
+constexpr int kThreads = 1024;                // 16 wave64 per workgroup (2 workgroups = 32 waves per CU)
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxN256 = 16384;               // 262144-byte block
 constexpr int kWarm = 512;                    // de-emphasis warm-up (P(miss) ~1e-5 per tile)
@@ -81,6 +81,8 @@ struct RxParams
   int32_t hal;                 // history samples re-derived for blocks b > 0
   int32_t warm;                // de-emphasis warm-up length (kWarm; tests shrink it)
   int32_t serial;              // 1: exact one-lane recurrence (replay path, n_blocks == 1)
+  int32_t dbg_flags;           // timing experiments only (results are wrong when non-zero)
+  int32_t stagger;             // start-up delay of odd dispatch layers, in units of s_sleep(127) (~8k cycles)
   uint32_t out_blocks;         // outputs are laid out [C][out_blocks][...]; this launch fills
   uint32_t out_b0;             //   blocks out_b0 .. out_b0 + n_blocks - 1 of that layout
   const uint32_t *chan_list;   // channels of this launch (all in the same mode)
@@ -98,6 +100,7 @@ struct RxParams
   float *chk_pub;              // [C][n_blocks] y at (n256 - kHist + 59) of this block
   float *chk_spec;             // [C][n_blocks] y at (-kHist + 59) as speculated by this block
   uint32_t *counters;          // kCnt*
+  unsigned long long *dbg;     // optional [grid][8] s_memtime stamps at phase boundaries (diagnostic builds of bench only)
 };
 
 struct EpilogueParams
@@ -121,6 +124,10 @@ constexpr int kCntRepair = 0;  // de-emphasis tiles re-run in place because thei
 constexpr int kCntGate = 1;    // blocks b > 0 whose squelch gate turned out closed
 constexpr int kCntSpec = 2;    // blocks b > 0 whose first tile disagrees with the predecessor
 constexpr int kCntCommit = 3;  // 1 when the epilogue committed the pending state
+constexpr int kCntSticky = 4;  // counters from here on are never reset (totals since creation):
+constexpr int kCntTotRepair = 4;
+constexpr int kCntTotViol = 5; // launches whose state was NOT committed
+constexpr int kCntTotLaunch = 6;
 constexpr int kNumCounters = 8;
 
 } // namespace hrfd

@@ -1,0 +1,217 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the committed
+golden vectors and against the CPU oracle on seeded inputs.  Run on the GPU box
+with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from hackrfdiags_amd import api, synth
+from tests import goldencheck as G
+from tests.reflib import WBFM, NONE
+
+pytestmark = pytest.mark.gpu
+BLK = synth.BLOCK_BYTES
+ARR, MAN = G.load()
+
+
+@pytest.fixture(scope="module")
+def engine():
+    if api.device_count() < 1:
+        pytest.fail("no GPU visible: the HIP path cannot run (and there is no CPU fallback)")
+    return api.Engine()
+
+
+# ---------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("case", [c for c in MAN["rx"] if c["mode"] == WBFM], ids=lambda c: c["key"])
+def test_golden_rx_wbfm(engine, case):
+    G.check_rx_case(engine, ARR, case)          # bit-exact, the float recurrence included
+
+
+@pytest.mark.parametrize("case", MAN["frontend"], ids=lambda c: c["key"])
+def test_golden_frontend(engine, case):
+    G.check_frontend_case(engine, ARR, case)
+
+
+@pytest.mark.parametrize("case", [c for c in MAN["rx_long"] if c["mode"] == WBFM], ids=lambda c: "long_wbfm")
+def test_golden_rx_long(engine, case):
+    G.check_long_case(engine, case)
+
+
+def test_golden_squelch(engine):
+    G.check_squelch(engine, ARR, MAN["squelch"][0])
+
+
+# ---------------------------------------------------------------- oracle parity, batched
+def _oracle_stream(oracle, mode, x, nb, gain=None, threshold=None):
+    o = oracle.rx()
+    o.set_mode(mode)
+    if gain is not None:
+        o.set_gain(mode, gain)
+    if threshold is not None:
+        o.set_threshold(threshold)
+    return [o.process(x[b]) for b in range(nb)]
+
+
+@pytest.mark.parametrize("kind", ["lcg", "fmtone", "dc_pos", "dc_neg", "impulse", "zeros"])
+def test_batched_blocks_match_oracle(oracle, kind):
+    """blocks of one channel demodulated concurrently (time-parallel) must equal
+    the strictly sequential reference, and the state must carry into the next call."""
+    C, B = 5, 4
+    xs = np.stack([synth.make_input(kind, 20 + c, 2 * B) for c in range(C)]).reshape(C, 2 * B, BLK)
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    r1 = rx.process_block(xs[:, :B], B, want_iq256=True)
+    r2 = rx.process_block(xs[:, B:], B, want_iq256=True)
+    pcm = np.concatenate([r1[0], r2[0]], axis=1)
+    mag = np.concatenate([r1[2], r2[2]], axis=1)
+    iq256 = np.concatenate([r1[4], r2[4]], axis=1)
+    assert (r1[1] == 512).all() and (r2[1] == 512).all()
+    for c in range(C):
+        want = _oracle_stream(oracle, WBFM, xs[c], 2 * B)
+        for b in range(2 * B):
+            assert (pcm[c, b] == want[b][0]).all(), (c, b)
+            assert mag[c, b] == want[b][1]
+            assert (iq256[c, b] == want[b][3]).all()
+    cnt = rx.debug_counters()
+    assert cnt[5] == 0 and cnt[7] == 0          # nothing uncommitted, nothing replayed
+
+
+def test_mode_none_produces_magnitude_only(oracle):
+    x = synth.make_input("fmtone", 9, 2).reshape(1, 2, BLK)
+    rx = api.Rx(1)
+    pcm, n_pcm, mag, allowed, iq256 = rx.process_block(x, 2, want_iq256=True)
+    want = _oracle_stream(oracle, NONE, x[0], 2)
+    assert (n_pcm == 0).all() and (allowed == 1).all()
+    for b in range(2):
+        assert mag[0, b] == want[b][1] and (iq256[0, b] == want[b][3]).all()
+
+
+def test_mixed_none_and_wbfm_channels(oracle):
+    C, B = 6, 2
+    xs = np.stack([synth.make_input("lcg", 50 + c, B) for c in range(C)]).reshape(C, B, BLK)
+    rx = api.Rx(C)
+    for c in range(C):
+        rx.set_mode(api.WBFM if c % 2 else api.NONE, channel=c)
+    pcm, n_pcm, mag, _, _ = rx.process_block(xs, B)
+    for c in range(C):
+        want = _oracle_stream(oracle, WBFM if c % 2 else NONE, xs[c], B)
+        for b in range(B):
+            assert n_pcm[c, b] == len(want[b][0]) and mag[c, b] == want[b][1]
+            assert (pcm[c, b, :n_pcm[c, b]] == want[b][0]).all()
+
+
+@pytest.mark.parametrize("gain", [1.0, 1234.5, 1e6, 1e12])
+def test_gain_incl_float_to_int16_wrap(oracle, gain):
+    x = synth.make_input("lcg", 11, 2).reshape(1, 2, BLK)
+    rx = api.Rx(1)
+    rx.set_mode(api.WBFM)
+    rx.set_gain(api.WBFM, gain)
+    pcm = rx.process_block(x, 2)[0]
+    want = _oracle_stream(oracle, WBFM, x[0], 2, gain=gain)
+    for b in range(2):
+        assert (pcm[0, b] == want[b][0]).all()
+
+
+@pytest.mark.parametrize("bb", [1024, 4096, 32768, 65536, 262144])
+def test_block_sizes(oracle, bb):
+    nb = 6
+    x = synth.make_input("fmtone", 4, 6)[: nb * bb].reshape(1, nb, bb)
+    rx = api.Rx(1)
+    rx.set_mode(api.WBFM)
+    a = rx.process_block(x[:, :3], 3)[0]
+    b = rx.process_block(x[:, 3:], 3)[0]
+    got = np.concatenate([a, b], axis=1).reshape(-1)
+    o = oracle.rx(); o.set_mode(WBFM)
+    want = np.concatenate([o.process(x[0, k])[0] for k in range(nb)])
+    assert (got == want).all()
+
+
+def test_invalid_sizes_are_rejected():
+    rx = api.Rx(1)
+    with pytest.raises(api.HrfdError):
+        rx.process_block(np.zeros((1, 1, 1000), dtype=np.int8), 1)     # not a multiple of 1024
+    with pytest.raises(api.HrfdError):
+        rx.process_block(np.zeros((1, 1, 2 * 262144), dtype=np.int8), 1)  # larger than a block
+
+
+def test_squelch_in_a_batch_falls_back_to_exact_path(oracle):
+    """a closed gate inside a multi-block call breaks the 'all gates open'
+    speculation: the call must notice, not commit, and replay block by block."""
+    loud = synth.make_input("fmtone", 1, 1)
+    quiet = synth.zeros_iq(synth.BLOCK_IQ)
+    pattern = [1, 1, 0, 0, 1, 0, 0, 0, 1]
+    x = np.stack([loud if p else quiet for p in pattern]).reshape(1, len(pattern), BLK)
+    rx = api.Rx(1)
+    rx.set_mode(api.WBFM)
+    rx.set_threshold(-30)
+    pcm, n_pcm, mag, allowed, _ = rx.process_block(x, len(pattern))
+    want = _oracle_stream(oracle, WBFM, x[0], len(pattern), threshold=-30)
+    for b in range(len(pattern)):
+        assert n_pcm[0, b] == len(want[b][0]) and bool(allowed[0, b]) == want[b][2]
+        assert (pcm[0, b, :n_pcm[0, b]] == want[b][0]).all()
+    assert rx.debug_counters()[7] == 0          # replays only count de-emphasis redo, none needed
+
+
+@pytest.mark.parametrize("warm", [64, 256, 384])
+def test_short_warmup_is_repaired_exactly(oracle, warm):
+    """Shrinking the de-emphasis warm-up makes tiles fail to re-synchronise; the
+    verify-and-repair step must still deliver the sequential result bit for bit."""
+    C, B = 3, 3
+    xs = np.stack([synth.make_input("fmtone" if c else "lcg", 70 + c, B) for c in range(C)]).reshape(C, B, BLK)
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    rx.debug_set_warm(warm)
+    pcm = rx.process_block(xs, B)[0]
+    for c in range(C):
+        want = _oracle_stream(oracle, WBFM, xs[c], B)
+        for b in range(B):
+            assert (pcm[c, b] == want[b][0]).all(), (warm, c, b)
+    assert rx.debug_counters()[4] > 0           # the repair path really ran
+
+
+def test_reset_demod_wbfm(oracle):
+    x = synth.lcg_bytes(21, 3 * BLK).reshape(1, 3, BLK)
+    rx = api.Rx(1)
+    rx.set_mode(api.WBFM)
+    o = oracle.rx(); o.set_mode(WBFM)
+    for k in range(3):
+        if k == 2:
+            rx.reset_demod(api.WBFM)
+            o.lib.orc_demod_reset  # (the outer oracle object has no reset; emulate via inner API below)
+        got = rx.process_block(x[:, k:k + 1], 1)[0][0, 0]
+        if k < 2:
+            assert (got == o.process(x[0, k])[0]).all()
+    # after a reset the decimator pipelines and previousTheta are zero but the
+    # de-emphasis filter keeps its state (WbFmDemodulator.cc:265-278): compare with
+    # the inner-API oracle driven by the same 256 kS/s stream.
+    d = oracle.demod(WBFM)
+    f = oracle.rx()
+    iq256 = [f.process(x[0, k])[3] for k in range(3)]
+    want = []
+    for k in range(3):
+        if k == 2:
+            d.reset()
+        want.append(d.process(iq256[k]))
+    assert (got == want[2]).all()
+
+
+def test_device_entry_and_sync(oracle):
+    import torch
+    C, B = 4, 3
+    xs = np.stack([synth.make_input("lcg", 90 + c, B) for c in range(C)]).reshape(C, B, BLK)
+    dev = torch.device("cuda:0")
+    d_iq = torch.from_numpy(xs).to(dev)
+    d_pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+    d_np = torch.zeros((C, B), dtype=torch.int32, device=dev)
+    d_mag = torch.zeros((C, B), dtype=torch.int32, device=dev)
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    s = torch.cuda.Stream()
+    rx.process_device(d_iq.data_ptr(), B * BLK, BLK, B, d_pcm.data_ptr(), d_n_pcm=d_np.data_ptr(),
+                      d_magnitude=d_mag.data_ptr(), stream=s.cuda_stream)
+    assert rx.sync() == 0
+    pcm = d_pcm.cpu().numpy()
+    for c in range(C):
+        want = _oracle_stream(oracle, WBFM, xs[c], B)
+        for b in range(B):
+            assert (pcm[c, b] == want[b][0]).all() and int(d_mag[c, b]) == want[b][1]
+    assert (d_np.cpu().numpy() == 512).all()

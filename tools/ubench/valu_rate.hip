@@ -1,0 +1,70 @@
+// Microbenchmark: issue cost of VALU instruction kinds on gfx950 (cycles per
+// wave64 instruction, one wave per SIMD and 8 waves per SIMD).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define REP16(x) x x x x x x x x x x x x x x x x
+
+#define KERNEL(name, body)                                                        \
+  __global__ void name(unsigned long long *out, int iters)                        \
+  {                                                                               \
+    unsigned a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3; \
+    unsigned b0 = 0x00010002, b1 = 0x00030004;                                    \
+    unsigned long long t0 = __builtin_readcyclecounter();                         \
+    for (int i = 0; i < iters; i++)                                               \
+    {                                                                             \
+      REP16(body)                                                                 \
+    }                                                                             \
+    unsigned long long t1 = __builtin_readcyclecounter();                         \
+    if ((threadIdx.x & 63) == 0)                                                  \
+      out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;           \
+    if (a0 + a1 + a2 + a3 == 0x12345678) out[0] = b0 + b1;                        \
+  }
+
+// 4 independent chains per body -> 64 instructions per loop iteration
+KERNEL(k_add_u32, asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+KERNEL(k_pk_add_u16, asm volatile("v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %1, %1, %4\n v_pk_add_u16 %2, %2, %4\n v_pk_add_u16 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+KERNEL(k_pk_mad_u16, asm volatile("v_pk_mad_u16 %0, %0, %4, %5\n v_pk_mad_u16 %1, %1, %4, %5\n v_pk_mad_u16 %2, %2, %4, %5\n v_pk_mad_u16 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_pk_ashr, asm volatile("v_pk_ashrrev_i16 %0, 1, %0\n v_pk_ashrrev_i16 %1, 1, %1\n v_pk_ashrrev_i16 %2, 1, %2\n v_pk_ashrrev_i16 %3, 1, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+KERNEL(k_perm, asm volatile("v_perm_b32 %0, %0, %4, %5\n v_perm_b32 %1, %1, %4, %5\n v_perm_b32 %2, %2, %4, %5\n v_perm_b32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_dpp_shr, asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+KERNEL(k_dpp_row, asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+KERNEL(k_mad_u24, asm volatile("v_mad_u32_u24 %0, %0, %4, %5\n v_mad_u32_u24 %1, %1, %4, %5\n v_mad_u32_u24 %2, %2, %4, %5\n v_mad_u32_u24 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_dot2, asm volatile("v_dot2_i32_i16 %0, %4, %5, %0\n v_dot2_i32_i16 %1, %4, %5, %1\n v_dot2_i32_i16 %2, %4, %5, %2\n v_dot2_i32_i16 %3, %4, %5, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_mul_f32, asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+KERNEL(k_lshl_add, asm volatile("v_lshl_add_u32 %0, %0, 1, %4\n v_lshl_add_u32 %1, %1, 1, %4\n v_lshl_add_u32 %2, %2, 1, %4\n v_lshl_add_u32 %3, %3, 1, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+KERNEL(k_add3, asm volatile("v_add3_u32 %0, %0, %4, %5\n v_add3_u32 %1, %1, %4, %5\n v_add3_u32 %2, %2, %4, %5\n v_add3_u32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_sad_u8, asm volatile("v_sad_u8 %0, %0, %4, %5\n v_sad_u8 %1, %1, %4, %5\n v_sad_u8 %2, %2, %4, %5\n v_sad_u8 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_add_sdwa, asm volatile("v_add_u32_sdwa %0, %0, %4 dst_sel:DWORD src0_sel:BYTE_0 src1_sel:BYTE_2\n v_add_u32_sdwa %1, %1, %4 dst_sel:DWORD src0_sel:BYTE_0 src1_sel:BYTE_2\n v_add_u32_sdwa %2, %2, %4 dst_sel:DWORD src0_sel:BYTE_0 src1_sel:BYTE_2\n v_add_u32_sdwa %3, %3, %4 dst_sel:DWORD src0_sel:BYTE_0 src1_sel:BYTE_2" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+// dependent chain of v_add_u32 (latency)
+KERNEL(k_dep_add, asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %0, %0, %4\n v_add_u32 %0, %0, %4\n v_add_u32 %0, %0, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+KERNEL(k_dep_mulf, asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %0, %0, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+KERNEL(k_dep_pk, asm volatile("v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %0, %0, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+
+typedef void (*kern_t)(unsigned long long *, int);
+static void run(const char *name, kern_t k, int threads)
+{
+  unsigned long long *d, h[4096];
+  hipMalloc(&d, sizeof(h));
+  const int iters = 2000;
+  hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, d, iters);
+  hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, d, iters);
+  hipDeviceSynchronize();
+  hipMemcpy(h, d, sizeof(unsigned long long) * 256 * (threads / 64), hipMemcpyDeviceToHost);
+  double sum = 0; int n = 256 * (threads / 64);
+  for (int i = 0; i < n; i++) sum += (double)h[i];
+  const double per_wave = sum / n / (iters * 64.0);          // ticks per instruction as seen by one wave
+  const int waves_per_simd = threads / 256;
+  printf("%-14s %4d thr/WG: %6.2f ticks/instr/wave -> %5.2f ticks/instr/SIMD\n", name, threads, per_wave,
+         per_wave / (waves_per_simd ? waves_per_simd : 1));
+  hipFree(d);
+}
+#define RUN(k) run(#k, k, 256); run(#k, k, 1024);
+int main()
+{
+  RUN(k_add_u32) RUN(k_pk_add_u16) RUN(k_pk_mad_u16) RUN(k_pk_ashr) RUN(k_perm) RUN(k_dpp_shr) RUN(k_dpp_row)
+  RUN(k_mad_u24) RUN(k_dot2) RUN(k_mul_f32) RUN(k_lshl_add) RUN(k_add3) RUN(k_sad_u8) RUN(k_add_sdwa)
+  RUN(k_dep_add) RUN(k_dep_mulf) RUN(k_dep_pk)
+  return 0;
+}
