@@ -19,6 +19,8 @@
 
 namespace hrfd {
 template <int MODE> __global__ void k_rx_wbfm(const RxParams);
+template <int MODE> __global__ void k_rx_fir(const RxParams);
+template <int MODE> __global__ void k_rx_post(const RxParams);
 __global__ void k_rx_epilogue(const EpilogueParams);
 __global__ void k_rx_commit(const EpilogueParams);
 } // namespace hrfd
@@ -158,6 +160,8 @@ struct hrfd_rx
   uint32_t *d_magnitude = nullptr;
   float *d_chk_pub = nullptr;
   float *d_chk_spec = nullptr;
+  int16_t *d_ssb_iq = nullptr;         // 8 kS/s I/Q of the SSB channels, [units][2][npcm]
+  size_t cap_ssb = 0;
 
   // staging for the host-buffer entry
   size_t cap_iq = 0, cap_pcm = 0, cap_iq256 = 0;
@@ -193,7 +197,7 @@ static int rx_free(hrfd_rx *h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_dbfs, h->d_counters,
                   h->d_lists, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
-                  h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out};
+                  h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq};
   for (void *p : ptrs)
   {
     if (p) (void)hipFree(p);
@@ -594,13 +598,6 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   {
     return rc;
   }
-  for (int m : {HRFD_MODE_AM, HRFD_MODE_FM, HRFD_MODE_LSB, HRFD_MODE_USB})
-  {
-    if (h->list_count[m] != 0)
-    {
-      return fail(HRFD_ESTATE, "demodulator mode %d is not built into this library yet", m);
-    }
-  }
 
   // launch-local scratch (present flags, cross-block check values) and the
   // magnitude buffer used when the caller does not want one
@@ -619,6 +616,15 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     h->cap_units = need;
   }
 
+  if (h->list_count[HRFD_MODE_LSB] + h->list_count[HRFD_MODE_USB] != 0)
+  {
+    const size_t need = units * (size_t)(n256 / 32) * 2 * sizeof(int16_t);
+    if (need > h->cap_ssb)
+    {
+      HIP_TRY(hipStreamSynchronize(s));
+      if ((rc = grow((void **)&h->d_ssb_iq, &h->cap_ssb, need)) != HRFD_OK) return rc;
+    }
+  }
   HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint32_t) * kCntSticky, s));   // the sticky totals survive
 
   RxParams P;
@@ -645,6 +651,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.magnitude = (d_magnitude != nullptr) ? d_magnitude : h->d_magnitude;
   P.present = h->d_present;
   P.iq256 = d_iq256;
+  P.ssb_iq = h->d_ssb_iq;
   P.atan2_lut = h->d_lut;
   P.dbfs = h->d_dbfs;
   P.chk_pub = h->d_chk_pub;
@@ -676,6 +683,35 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     else
     {
       hipLaunchKernelGGL(k_rx_wbfm<3>, dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  // per-mode dispatch of the other demodulators (BASELINE config 3); the 8 kS/s
+  // recurrences of AM and SSB follow in their own one-workgroup-per-channel kernel
+  P.dbg = nullptr;
+  for (int m : {HRFD_MODE_FM, HRFD_MODE_AM, HRFD_MODE_LSB, HRFD_MODE_USB})
+  {
+    const uint32_t n = h->list_count[m];
+    if (n == 0)
+    {
+      continue;
+    }
+    P.chan_list = h->d_lists + (size_t)m * h->n_channels;
+    P.n_list = n;
+    const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+    if (m == HRFD_MODE_FM)
+    {
+      hipLaunchKernelGGL(k_rx_fir<2>, dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    else if (m == HRFD_MODE_AM)
+    {
+      hipLaunchKernelGGL(k_rx_fir<1>, dim3(grid), dim3(kThreads), 0, s, P);
+      hipLaunchKernelGGL(k_rx_post<1>, dim3(n), dim3(256), 0, s, P);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_rx_fir<4>, dim3(grid), dim3(kThreads), 0, s, P);
+      hipLaunchKernelGGL(k_rx_post<4>, dim3(n), dim3(256), 0, s, P);
     }
     HIP_TRY(hipGetLastError());
   }

@@ -24,7 +24,7 @@ constexpr int kMaxNV = kMaxN256 + kMaxHal;    // floats of the v/y stream in LDS
 // carried history sizes of the integer stages ("carried state")
 constexpr int kWbS = 4, kWbU = 8, kWbV = 38;  // WBFM: last N-M inputs of D(8,4), D(12,4), D(40,2)
 constexpr int kFmTail = 704;                  // FM:  iq256 samples (>= 684)
-constexpr int kAmTail = 320;                  // AM/SSB: iq256 samples (>= 260)
+constexpr int kAmTail = 384;                  // AM/SSB: iq256 samples (>= 324, multiple of 64)
 constexpr int kSsbHist = 32;                  // 8 kS/s I/Q history (>= 30)
 
 // ---- per-channel persistent state (device memory, one per channel) ----------
@@ -95,6 +95,7 @@ struct RxParams
   uint32_t *magnitude;         // [C][n_blocks] block-mean magnitude
   uint8_t *present;            // [C][n_blocks] detector result (before the tracker)
   int8_t *iq256;               // optional [C][n_blocks][2*n256]
+  int16_t *ssb_iq;             // SSB scratch [C][n_blocks][2][n256/32]: 8 kS/s I and Q rails
   const float *atan2_lut;      // [256][256]
   const int32_t *dbfs;         // [257]
   float *chk_pub;              // [C][n_blocks] y at (n256 - kHist + 59) of this block

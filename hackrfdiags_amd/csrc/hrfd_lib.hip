@@ -2,4 +2,5 @@
 // Kernels and their launchers live in one TU so that no relocatable device code
 // / device link step is needed (plain `hipcc -c` + host link).
 #include "hrfd_rx_kernels.hip"
+#include "hrfd_rx_fir_kernels.hip"
 #include "hrfd_api.hip"

@@ -286,13 +286,70 @@ __device__ __forceinline__ bool map_unit(uint32_t w, uint32_t n_list, uint32_t n
 //               U  int16         kUOff*2 + (m + 160)          m   in [-160, n256/4)
 //               V  int16         kVOff*2 + (k + 38)           k   in [-38, n256/16)
 constexpr int kSDwords = (kMaxN256 + kHist) / 2;             // 8544
-constexpr int kUOff = 8576;                                   // dword offset of U (>= kSDwords, 16-B aligned)
+constexpr int kPairsPerThread = ((kMaxN256 + kHist) / 2 + kThreads - 1) / kThreads;
+
+// ---- the two audio-rate integer stages shared by WBFM and FM ------------------
+// U (64 kS/s, int16) lives at dword kUOff with kUHist samples of history in
+// front, V (16 kS/s) at kVOff with kVHist; both tables are the reference's
+// postDemodDecimator2 / audioDecimator (WbFmDemodulator.cc:28-86 ==
+// FmDemodulator.cc:53-111).
+constexpr int kUOff = 8576;                                   // dword offset of U (16-B aligned)
 constexpr int kUHist = 160;
 constexpr int kVOff = kUOff + (kMaxN256 / 4 + kUHist) / 2;    // 10704
 constexpr int kVHist = 38;
-constexpr int kPairsPerThread = ((kMaxN256 + kHist) / 2 + kThreads - 1) / kThreads;
 static_assert(kVOff + (kMaxN256 / 16 + kVHist) / 2 + 1 <= kMaxNV, "LDS map");
 static_assert(kSDwords <= kUOff && (kUOff % 4) == 0, "LDS map");
+
+// V[k] = D(12,4)(U) for k in [kmin, n16); kmin even; two outputs per thread
+__device__ __forceinline__ void stage_d12(uint32_t *lds, const int kmin, const int n16, const int tid)
+{
+  const int nV = n16 - kmin;
+  for (int q = tid; q < (nV >> 1); q += kThreads)
+  {
+    const int k = kmin + 2 * q;
+    // U[4k-8 .. 4k+7] -> 8 dwords from (4k - 8 + kUHist)/2
+    const uint32_t *up = lds + kUOff + ((4 * k - 8 + kUHist) >> 1);
+    uint32_t u[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      const uint2 t = *reinterpret_cast<const uint2 *>(up + 2 * j);
+      u[2 * j] = t.x;
+      u[2 * j + 1] = t.y;
+    }
+    int acc0 = 1 << 14, acc1 = 1 << 14;
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+    {
+      acc0 = dot2(u[j], kRevD12.p[j], acc0);
+      acc1 = dot2(u[j + 2], kRevD12.p[j], acc1);
+    }
+    const uint32_t w = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+    lds[kVOff + ((k + kVHist) >> 1)] = w;
+  }
+}
+
+// PCM[p] = D(40,2)(V) for p in [0, nP); two outputs per thread, one packed store
+__device__ __forceinline__ void stage_d40(const uint32_t *lds, const int nP, uint32_t *pcm32, const int tid)
+{
+  for (int q = tid; q < (nP >> 1); q += kThreads)
+  {
+    const int p = 2 * q;
+    // V[2p-38 .. 2p+3] -> 21 dwords from (2p - 38 + kVHist)/2 = p
+    const uint32_t *vq = lds + kVOff + p;
+    int acc0 = 1 << 14, acc1 = 1 << 14;
+    uint32_t prev = vq[0];
+#pragma unroll
+    for (int j = 0; j < 20; j++)
+    {
+      const uint32_t next = vq[j + 1];
+      acc0 = dot2(prev, kRevD40.p[j], acc0);
+      acc1 = dot2(next, kRevD40.p[j], acc1);
+      prev = next;
+    }
+    pcm32[q] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+  }
+}
 
 // One lane's run of y[n] = v[n] - a1*y[n-1] over `count` consecutive samples at
 // `in` (IirFilter.cc:161-176: r = a1*y; y = v - r -- two rounded operations).
@@ -391,6 +448,7 @@ struct StreamCtx
   float kgain;
   int hal, vstart, n256;
   int lane;
+  int qoff;                      // FIR modes: int16 index of the Q rail inside lds (I rail at 0)
   bool first;
 };
 
@@ -484,6 +542,14 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
         const uint32_t iq = mixed ^ 0x00800080u;
         dump[X.vstart + 64 * ch + lane] = (uint16_t)((iq & 0xffu) | ((iq >> 8) & 0xff00u));
       }
+    }
+    if (MODE == 1 || MODE == 2 || MODE == 4)
+    {
+      // AM / FM / SSB: the mixed 256 kS/s sample as two int16 rails in LDS
+      int16_t *rails = reinterpret_cast<int16_t *>(X.lds);
+      const int at = X.vstart + 64 * ch + lane + X.hal;
+      rails[at] = (int16_t)((int)(mixed & 0xffu) - 128);
+      rails[X.qoff + at] = (int16_t)((int)(mixed >> 16) - 128);
     }
     if (MODE != 3)
     {
@@ -948,58 +1014,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   }
   __syncthreads();
 
-  // C3: V[k] = D(12,4)(U); two outputs per thread
-  {
-    const int kmin = first ? 0 : -kVHist;
-    const int nV = (n256 >> 4) - kmin;
-    for (int q = tid; q < (nV >> 1); q += kThreads)
-    {
-      const int k = kmin + 2 * q;
-      // U[4k-8 .. 4k+7] -> 8 dwords from (4k - 8 + kUHist)/2
-      const uint32_t *up = lds + kUOff + ((4 * k - 8 + kUHist) >> 1);
-      uint32_t u[8];
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-      {
-        const uint2 t = *reinterpret_cast<const uint2 *>(up + 2 * j);
-        u[2 * j] = t.x;
-        u[2 * j + 1] = t.y;
-      }
-      int acc0 = 1 << 14, acc1 = 1 << 14;
-#pragma unroll
-      for (int j = 0; j < 6; j++)
-      {
-        acc0 = dot2(u[j], kRevD12.p[j], acc0);
-        acc1 = dot2(u[j + 2], kRevD12.p[j], acc1);
-      }
-      const uint32_t w = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
-      lds[kVOff + ((k + kVHist) >> 1)] = w;
-    }
-  }
+  // C3: V[k] = D(12,4)(U);  C4: PCM[p] = D(40,2)(V)
+  stage_d12(lds, first ? 0 : -kVHist, n256 >> 4, tid);
   __syncthreads();
-
-  // C4: PCM[p] = D(40,2)(V); two outputs per thread, one packed store
-  {
-    const int nP = n256 >> 5;
-    uint32_t *pcm32 = reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)nP);
-    for (int q = tid; q < (nP >> 1); q += kThreads)
-    {
-      const int p = 2 * q;
-      // V[2p-38 .. 2p+3] -> 21 dwords from (2p - 38 + kVHist)/2 = p
-      const uint32_t *vq = lds + kVOff + p;
-      int acc0 = 1 << 14, acc1 = 1 << 14;
-      uint32_t prev = vq[0];
-#pragma unroll
-      for (int j = 0; j < 20; j++)
-      {
-        const uint32_t next = vq[j + 1];
-        acc0 = dot2(prev, kRevD40.p[j], acc0);
-        acc1 = dot2(next, kRevD40.p[j], acc1);
-        prev = next;
-      }
-      pcm32[q] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
-    }
-  }
+  stage_d40(lds, n256 >> 5, reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)(n256 >> 5)), tid);
 
   HRFD_STAMP(5)
   // carried histories for the next call
@@ -1117,6 +1135,27 @@ __global__ void k_rx_commit(const EpilogueParams E)
     for (int i = 0; i < kWbS; i++) dst->wb_s[i] = src->wb_s[i];
     for (int i = 0; i < kWbU; i++) dst->wb_u[i] = src->wb_u[i];
     for (int i = 0; i < kWbV; i++) dst->wb_v[i] = src->wb_v[i];
+  }
+  else if (mode == 2)
+  {
+    for (int i = 0; i < 2 * kFmTail; i++) dst->fm_tail[i] = src->fm_tail[i];
+  }
+  else if (mode == 1)
+  {
+    for (int i = 0; i < 2 * kAmTail; i++) dst->am_tail[i] = src->am_tail[i];
+    dst->am_x1 = src->am_x1;
+    dst->am_y1 = src->am_y1;
+  }
+  else if (mode == 4 || mode == 5)
+  {
+    for (int i = 0; i < 2 * kAmTail; i++) dst->ssb_tail[i] = src->ssb_tail[i];
+    dst->ssb_x1 = src->ssb_x1;
+    dst->ssb_y1 = src->ssb_y1;
+    for (int i = 0; i < kSsbHist; i++)
+    {
+      dst->ssb_i[i] = src->ssb_i[i];
+      dst->ssb_q[i] = src->ssb_q[i];
+    }
   }
 }
 

@@ -6,7 +6,7 @@ import pytest
 
 from hackrfdiags_amd import api, synth
 from tests import goldencheck as G
-from tests.reflib import WBFM, NONE
+from tests.reflib import AM, FM, WBFM, LSB, USB, NONE
 
 pytestmark = pytest.mark.gpu
 BLK = synth.BLOCK_BYTES
@@ -21,9 +21,11 @@ def engine():
 
 
 # ---------------------------------------------------------------- golden vectors
-@pytest.mark.parametrize("case", [c for c in MAN["rx"] if c["mode"] == WBFM], ids=lambda c: c["key"])
-def test_golden_rx_wbfm(engine, case):
-    G.check_rx_case(engine, ARR, case)          # bit-exact, the float recurrence included
+@pytest.mark.parametrize("case", MAN["rx"], ids=lambda c: c["key"])
+def test_golden_rx(engine, case):
+    # bit-exact in every mode, the float recurrences (WBFM de-emphasis, AM/SSB dc
+    # removal) included: tolerance 0 LSB where BASELINE.json would allow +-1
+    G.check_rx_case(engine, ARR, case)
 
 
 @pytest.mark.parametrize("case", MAN["frontend"], ids=lambda c: c["key"])
@@ -31,13 +33,24 @@ def test_golden_frontend(engine, case):
     G.check_frontend_case(engine, ARR, case)
 
 
-@pytest.mark.parametrize("case", [c for c in MAN["rx_long"] if c["mode"] == WBFM], ids=lambda c: "long_wbfm")
+@pytest.mark.parametrize("case", MAN["rx_long"], ids=lambda c: f"long_mode{c['mode']}")
 def test_golden_rx_long(engine, case):
     G.check_long_case(engine, case)
 
 
 def test_golden_squelch(engine):
     G.check_squelch(engine, ARR, MAN["squelch"][0])
+
+
+@pytest.mark.parametrize("case", MAN["chunked"], ids=lambda c: c["key"])
+def test_golden_chunked_1024(engine, oracle, case):
+    """the reference is chunk-invariant for multiples of 64 bytes; the HIP path takes
+    multiples of 1024: 256 calls of 1024 bytes must equal the 64-byte-chunk golden."""
+    x = synth.make_input(case["kind"], case["seed"], 1)
+    h = engine.rx()
+    h.set_mode(case["mode"])
+    got = np.concatenate([h.process(x[o:o + 1024])[0] for o in range(0, len(x), 1024)])
+    assert (got == ARR[case["key"]]).all()
 
 
 # ---------------------------------------------------------------- oracle parity, batched
@@ -49,6 +62,57 @@ def _oracle_stream(oracle, mode, x, nb, gain=None, threshold=None):
     if threshold is not None:
         o.set_threshold(threshold)
     return [o.process(x[b]) for b in range(nb)]
+
+
+@pytest.mark.parametrize("mode", [AM, FM, LSB, USB])
+@pytest.mark.parametrize("kind", ["lcg", "amtone", "dc_neg", "impulse"])
+def test_batched_blocks_match_oracle_other_modes(oracle, mode, kind):
+    C, B = 3, 4
+    xs = np.stack([synth.make_input(kind, 30 + c, 2 * B) for c in range(C)]).reshape(C, 2 * B, BLK)
+    rx = api.Rx(C)
+    rx.set_mode(mode)
+    r1 = rx.process_block(xs[:, :B], B)
+    r2 = rx.process_block(xs[:, B:], B)
+    pcm = np.concatenate([r1[0], r2[0]], axis=1)
+    mag = np.concatenate([r1[2], r2[2]], axis=1)
+    for c in range(C):
+        want = _oracle_stream(oracle, mode, xs[c], 2 * B)
+        for b in range(2 * B):
+            assert (pcm[c, b] == want[b][0]).all(), (mode, kind, c, b)
+            assert mag[c, b] == want[b][1]
+    assert rx.debug_counters()[5] == 0
+
+
+def test_mixed_mode_bank(oracle):
+    """BASELINE config 3 in miniature: AM + FM + WBFM + LSB + USB + NONE channels in
+    one handle, per-mode kernel dispatch, two calls."""
+    modes = [AM, FM, WBFM, LSB, USB, NONE, WBFM, AM, FM, USB]
+    C, B = len(modes), 3
+    xs = np.stack([synth.make_input("lcg" if c % 2 else "amtone", 60 + c, 2 * B) for c in range(C)])
+    xs = xs.reshape(C, 2 * B, BLK)
+    rx = api.Rx(C)
+    for c, m in enumerate(modes):
+        rx.set_mode(m, channel=c)
+    r1 = rx.process_block(xs[:, :B], B)
+    r2 = rx.process_block(xs[:, B:], B)
+    pcm = np.concatenate([r1[0], r2[0]], axis=1)
+    npcm = np.concatenate([r1[1], r2[1]], axis=1)
+    for c, m in enumerate(modes):
+        want = _oracle_stream(oracle, m, xs[c], 2 * B)
+        for b in range(2 * B):
+            assert npcm[c, b] == len(want[b][0])
+            assert (pcm[c, b, :npcm[c, b]] == want[b][0]).all(), (c, m, b)
+
+
+def test_mode_switch_keeps_each_demodulators_state(oracle):
+    x = synth.make_input("lcg", 5, 6).reshape(1, 6, BLK)
+    rx = api.Rx(1)
+    o = oracle.rx()
+    for blk, mode in enumerate([WBFM, AM, LSB, USB, FM, WBFM]):
+        rx.set_mode(mode)
+        o.set_mode(mode)
+        got = rx.process_block(x[:, blk:blk + 1], 1)[0][0, 0]
+        assert (got == o.process(x[0, blk])[0]).all(), (blk, mode)
 
 
 @pytest.mark.parametrize("kind", ["lcg", "fmtone", "dc_pos", "dc_neg", "impulse", "zeros"])
@@ -99,28 +163,30 @@ def test_mixed_none_and_wbfm_channels(oracle):
             assert (pcm[c, b, :n_pcm[c, b]] == want[b][0]).all()
 
 
+@pytest.mark.parametrize("mode", [AM, FM, WBFM, LSB])
 @pytest.mark.parametrize("gain", [1.0, 1234.5, 1e6, 1e12])
-def test_gain_incl_float_to_int16_wrap(oracle, gain):
+def test_gain_incl_float_to_int16_wrap(oracle, mode, gain):
     x = synth.make_input("lcg", 11, 2).reshape(1, 2, BLK)
     rx = api.Rx(1)
-    rx.set_mode(api.WBFM)
-    rx.set_gain(api.WBFM, gain)
+    rx.set_mode(mode)
+    rx.set_gain(mode, gain)
     pcm = rx.process_block(x, 2)[0]
-    want = _oracle_stream(oracle, WBFM, x[0], 2, gain=gain)
+    want = _oracle_stream(oracle, mode, x[0], 2, gain=gain)
     for b in range(2):
         assert (pcm[0, b] == want[b][0]).all()
 
 
+@pytest.mark.parametrize("mode", [AM, FM, WBFM, USB])
 @pytest.mark.parametrize("bb", [1024, 4096, 32768, 65536, 262144])
-def test_block_sizes(oracle, bb):
+def test_block_sizes(oracle, mode, bb):
     nb = 6
     x = synth.make_input("fmtone", 4, 6)[: nb * bb].reshape(1, nb, bb)
     rx = api.Rx(1)
-    rx.set_mode(api.WBFM)
+    rx.set_mode(mode)
     a = rx.process_block(x[:, :3], 3)[0]
     b = rx.process_block(x[:, 3:], 3)[0]
     got = np.concatenate([a, b], axis=1).reshape(-1)
-    o = oracle.rx(); o.set_mode(WBFM)
+    o = oracle.rx(); o.set_mode(mode)
     want = np.concatenate([o.process(x[0, k])[0] for k in range(nb)])
     assert (got == want).all()
 
