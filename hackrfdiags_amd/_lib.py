@@ -87,6 +87,12 @@ def load() -> C.CDLL:
     L.hrfd_rx_debug_stamps.argtypes = [_vp, C.c_uint32, _vp]
     L.hrfd_rx_debug_enable_timing.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_kernel_ms.argtypes = [_vp, C.c_int, _f32p]
+    L.hrfd_demod_create.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(_vp)]
+    L.hrfd_demod_destroy.argtypes = [_vp]
+    L.hrfd_demod_reset.argtypes = [_vp, C.c_uint32]
+    L.hrfd_demod_set_gain.argtypes = [_vp, C.c_uint32, C.c_float]
+    L.hrfd_demod_set_sideband.argtypes = [_vp, C.c_uint32, C.c_int]
+    L.hrfd_demod_process.argtypes = [_vp, _vp, C.c_uint32, _vp, _vp]
     L.hrfd_q15_table.argtypes = [C.c_char_p, _i16p, C.c_int]
     L.hrfd_atan2_table.argtypes = [_f32p]
     L.hrfd_dbfs_table.argtypes = [_i32p]

@@ -145,11 +145,52 @@ class SingleChannelRx:
         return pcm[0, 0, :n].copy(), int(mag[0, 0]), bool(allowed[0, 0]), iq256[0, 0]
 
 
+class Demod:
+    """n_channels instances of one demodulator class on 256 kS/s mixed IQ
+    (hrfd_demod_*; mirrors X::acceptIqData / setDemodulatorGain / resetDemodulator)."""
+
+    def __init__(self, mode: int, n_channels: int = 1, device: int = -1):
+        self.L = _lib.load()
+        self.n = int(n_channels)
+        h = C.c_void_p()
+        check(self.L.hrfd_demod_create(mode, self.n, device, C.byref(h)), "hrfd_demod_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hrfd_demod_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self, channel=ALL):
+        check(self.L.hrfd_demod_reset(self.h, channel), "hrfd_demod_reset")
+
+    def set_gain(self, gain, channel=ALL):
+        check(self.L.hrfd_demod_set_gain(self.h, channel, C.c_float(gain)), "hrfd_demod_set_gain")
+
+    def set_sideband(self, lsb, channel=ALL):
+        check(self.L.hrfd_demod_set_sideband(self.h, channel, int(bool(lsb))), "hrfd_demod_set_sideband")
+
+    def process(self, iq256):
+        """iq256: int8 [C, bytes] (or flat for C == 1) -> pcm int16 [C, bytes/64]"""
+        iq256 = np.ascontiguousarray(iq256, dtype=np.int8).reshape(self.n, -1)
+        nb = iq256.shape[1]
+        pcm = np.zeros((self.n, nb // 64), dtype=np.int16)
+        n_pcm = np.zeros(self.n, dtype=np.uint32)
+        check(self.L.hrfd_demod_process(self.h, _ptr(iq256), nb, _ptr(pcm), _ptr(n_pcm)), "hrfd_demod_process")
+        assert (n_pcm == nb // 64).all()
+        return pcm if self.n > 1 else pcm[0]
+
+
 class Engine:
     """Factory with the interface tests/goldencheck.py expects."""
 
     def rx(self):
         return SingleChannelRx()
+
+    def demod(self, mode):
+        return Demod(mode, 1)
 
 
 def q15_table(name: str) -> np.ndarray:

@@ -501,6 +501,7 @@ static int apply_resets(hrfd_rx *h, hipStream_t s, std::vector<std::pair<uint32_
         break;
       case HRFD_MODE_FM:
         HIP_TRY(hipMemsetAsync(d->fm_tail, 0x80, sizeof(d->fm_tail), s));
+        HIP_TRY(hipMemsetAsync(d->fm_u, 0, sizeof(d->fm_u) + sizeof(d->fm_v), s));
         break;
       case HRFD_MODE_AM:
         HIP_TRY(hipMemsetAsync(d->am_tail, 0x80, sizeof(d->am_tail), s));
@@ -521,6 +522,7 @@ struct LaunchOpts
   uint32_t out_blocks;     // layout [C][out_blocks] of the caller's output buffers
   uint32_t out_b0;         // first block of that layout this launch fills
   int serial;              // exact one-lane de-emphasis (replay path)
+  int src256;              // input is the 256 kS/s mixed stream (hrfd_demod_*)
 };
 
 static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, uint32_t block_bytes,
@@ -532,7 +534,14 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   {
     return fail(HRFD_EINVAL, "hrfd_rx_process: NULL handle or buffer");
   }
-  if (block_bytes == 0 || (block_bytes % 1024u) != 0 || block_bytes > HRFD_BLOCK_BYTES)
+  if (opt.src256)
+  {
+    if (block_bytes == 0 || (block_bytes % 128u) != 0 || block_bytes > 32768u)
+    {
+      return fail(HRFD_EINVAL, "256 kS/s input must be a multiple of 128 bytes and <= 32768 (got %u)", block_bytes);
+    }
+  }
+  else if (block_bytes == 0 || (block_bytes % 1024u) != 0 || block_bytes > HRFD_BLOCK_BYTES)
   {
     return fail(HRFD_EINVAL, "block_bytes must be a multiple of 1024 and <= %u (got %u)",
                 HRFD_BLOCK_BYTES, block_bytes);
@@ -547,7 +556,8 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   }
   HIP_TRY(hipSetDevice(h->device));
 
-  const uint32_t n256 = block_bytes / 16;
+  const uint32_t n256 = opt.src256 ? block_bytes / 2 : block_bytes / 16;
+  const uint32_t halo_unit = opt.src256 ? 2u : 16u;   // input bytes per 256 kS/s sample
   // 64 de-emphasis tiles end at n256; tile 0 is sacrificial, tile 1 must start at
   // or before the first history sample the integer stages read (-kNeedHist).
   int tile = (int)((n256 + kNeedHist + 62) / 63);
@@ -561,10 +571,10 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   {
     return fail(HRFD_EINVAL, "internal: history %d exceeds %d", hal, kMaxHal);
   }
-  if (n_blocks > 1 && (uint32_t)(hal + 64) * 16u > block_bytes)
+  if (n_blocks > 1 && (uint32_t)(hal + 64) * halo_unit > block_bytes)
   {
     return fail(HRFD_EINVAL, "blocks of %u bytes are too short for a multi-block call "
-                "(need >= %u); submit them one per call", block_bytes, (uint32_t)(hal + 64) * 16u);
+                "(need >= %u); submit them one per call", block_bytes, (uint32_t)(hal + 64) * halo_unit);
   }
   if (opt.serial && n_blocks != 1)
   {
@@ -639,6 +649,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.hal = hal;
   P.warm = h->warm;
   P.serial = opt.serial;
+  P.src256 = opt.src256;
   P.stagger = h->stagger & 63;
   P.dbg_flags = h->stagger >> 8;
   P.out_blocks = opt.out_blocks;
@@ -757,7 +768,7 @@ extern "C" int hrfd_rx_process_device(hrfd_rx *h, const int8_t *d_iq, uint64_t c
     return fail(HRFD_EINVAL, "NULL handle");
   }
   hipStream_t s = (stream != nullptr) ? (hipStream_t)stream : h->stream;
-  const LaunchOpts opt = {n_blocks, 0, 0};
+  const LaunchOpts opt = {n_blocks, 0, 0, 0};
   return rx_launch(h, d_iq, channel_stride, block_bytes, n_blocks, gain_db, d_pcm, d_n_pcm,
                    d_magnitude, d_signal_allowed, d_iq256k_opt, s, opt);
 }
@@ -823,7 +834,7 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
   if (n_blocks > 1 && (uint32_t)(kMaxHal + 64) * 16u <= block_bytes)
   {
     // whole batch in one launch, blocks of a channel in parallel (speculative)
-    const LaunchOpts opt = {n_blocks, 0, 0};
+    const LaunchOpts opt = {n_blocks, 0, 0, 0};
     rc = rx_launch(h, h->d_iq, stride, block_bytes, n_blocks, gain_db, h->d_pcm, h->d_npcm,
                    h->d_mag_out, h->d_allowed, d_iq256, s, opt);
     if (rc != HRFD_OK) return rc;
@@ -838,7 +849,7 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
     {
       for (int attempt = 0; attempt < 2; attempt++)
       {
-        const LaunchOpts opt = {n_blocks, b, attempt};
+        const LaunchOpts opt = {n_blocks, b, attempt, 0};
         rc = rx_launch(h, h->d_iq + (size_t)b * block_bytes, stride, block_bytes, 1, gain_db,
                        h->d_pcm, h->d_npcm, h->d_mag_out, h->d_allowed, d_iq256, s, opt);
         if (rc != HRFD_OK) return rc;
@@ -870,16 +881,131 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
   return HRFD_OK;
 }
 
+// ------------------------------------------------------------------ inner boundary
+// hrfd_demod: n_channels instances of ONE demodulator class, fed with the
+// 256 kS/s, already mixed, int8 IQ stream -- X::acceptIqData(int8_t*,uint32_t).
+// Same kernels as the outer boundary, entered behind the front end (src256).
+struct hrfd_demod
+{
+  hrfd_rx *rx = nullptr;
+  int mode = 0;
+};
+
+extern "C" int hrfd_demod_create(int mode, uint32_t n_channels, int device, hrfd_demod **out)
+{
+  if (out == nullptr || mode < HRFD_MODE_AM || mode > HRFD_MODE_USB)
+  {
+    return fail(HRFD_EINVAL, "hrfd_demod_create: mode must be AM, FM, WBFM, LSB or USB");
+  }
+  *out = nullptr;
+  hrfd_rx *rx = nullptr;
+  int rc = hrfd_rx_create(n_channels, device, &rx);
+  if (rc != HRFD_OK)
+  {
+    return rc;
+  }
+  rc = hrfd_rx_set_mode(rx, HRFD_ALL_CHANNELS, mode);
+  if (rc != HRFD_OK)
+  {
+    rx_free(rx);
+    return rc;
+  }
+  hrfd_demod *h = new hrfd_demod;
+  h->rx = rx;
+  h->mode = mode;
+  *out = h;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_demod_destroy(hrfd_demod *h)
+{
+  if (h != nullptr)
+  {
+    rx_free(h->rx);
+    delete h;
+  }
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_demod_reset(hrfd_demod *h, uint32_t channel)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL handle");
+  }
+  return hrfd_rx_reset_demod(h->rx, channel, h->mode);
+}
+
+extern "C" int hrfd_demod_set_gain(hrfd_demod *h, uint32_t channel, float gain)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL handle");
+  }
+  return hrfd_rx_set_gain(h->rx, channel, h->mode, gain);
+}
+
+extern "C" int hrfd_demod_set_sideband(hrfd_demod *h, uint32_t channel, int lsb)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL handle");
+  }
+  if (h->mode != HRFD_MODE_LSB && h->mode != HRFD_MODE_USB)
+  {
+    return fail(HRFD_ESTATE, "hrfd_demod_set_sideband: not an SSB demodulator");
+  }
+  // SsbDemodulator::set{Lsb,Usb}DemodulationMode (SsbDemodulator.cc): a flag, no state change
+  return hrfd_rx_set_mode(h->rx, channel, lsb ? HRFD_MODE_LSB : HRFD_MODE_USB);
+}
+
+extern "C" int hrfd_demod_process(hrfd_demod *dh, const int8_t *iq256k, uint32_t bytes_per_channel,
+                                  int16_t *pcm, uint32_t *n_pcm)
+{
+  if (dh == nullptr || iq256k == nullptr || pcm == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_demod_process: NULL argument");
+  }
+  hrfd_rx *h = dh->rx;
+  if (bytes_per_channel == 0 || (bytes_per_channel % 128u) != 0 || bytes_per_channel > 32768u)
+  {
+    return fail(HRFD_EINVAL, "hrfd_demod_process: bytes_per_channel must be a multiple of 128 and <= 32768");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const uint32_t C = h->n_channels;
+  const uint32_t npcm = bytes_per_channel / 64;
+  const size_t iq_bytes = (size_t)C * bytes_per_channel;
+  const size_t pcm_bytes = (size_t)C * npcm * sizeof(int16_t);
+  hipStream_t s = h->stream;
+  int rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  if ((rc = grow((void **)&h->d_iq, &h->cap_iq, iq_bytes)) != HRFD_OK) return rc;
+  if ((rc = grow((void **)&h->d_pcm, &h->cap_pcm, pcm_bytes)) != HRFD_OK) return rc;
+  if ((rc = grow((void **)&h->d_npcm, &h->cap_npcm, (size_t)C * 4)) != HRFD_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_iq, iq256k, iq_bytes, hipMemcpyHostToDevice, s));
+  const LaunchOpts opt = {1, 0, 0, 1};
+  rc = rx_launch(h, h->d_iq, bytes_per_channel, bytes_per_channel, 1, 0, h->d_pcm, h->d_npcm, nullptr,
+                 nullptr, nullptr, s, opt);
+  if (rc != HRFD_OK) return rc;
+  uint32_t viol = 0;
+  if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
+  if (viol != 0)
+  {
+    return fail(HRFD_ESTATE, "internal: single-block launch reported %u violations", viol);
+  }
+  HIP_TRY(hipMemcpyAsync(pcm, h->d_pcm, pcm_bytes, hipMemcpyDeviceToHost, s));
+  if (n_pcm != nullptr)
+  {
+    HIP_TRY(hipMemcpyAsync(n_pcm, h->d_npcm, (size_t)C * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  return HRFD_OK;
+}
+
 // ------------------------------------------------------------------ not yet built
 // Entry points of include/hrfd.h whose kernels are still being written.  They
 // fail loudly (HRFD_ESTATE) -- there is no CPU stand-in behind them.
 #define HRFD_TODO(name) return fail(HRFD_ESTATE, name ": this entry point is not built into libhrfd.so yet")
-extern "C" int hrfd_demod_create(int, uint32_t, int, hrfd_demod **) { HRFD_TODO("hrfd_demod_create"); }
-extern "C" int hrfd_demod_destroy(hrfd_demod *) { HRFD_TODO("hrfd_demod_destroy"); }
-extern "C" int hrfd_demod_reset(hrfd_demod *, uint32_t) { HRFD_TODO("hrfd_demod_reset"); }
-extern "C" int hrfd_demod_set_gain(hrfd_demod *, uint32_t, float) { HRFD_TODO("hrfd_demod_set_gain"); }
-extern "C" int hrfd_demod_set_sideband(hrfd_demod *, uint32_t, int) { HRFD_TODO("hrfd_demod_set_sideband"); }
-extern "C" int hrfd_demod_process(hrfd_demod *, const int8_t *, uint32_t, int16_t *, uint32_t *) { HRFD_TODO("hrfd_demod_process"); }
 extern "C" int hrfd_mod_create(int, uint32_t, int, hrfd_mod **) { HRFD_TODO("hrfd_mod_create"); }
 extern "C" int hrfd_mod_destroy(hrfd_mod *) { HRFD_TODO("hrfd_mod_destroy"); }
 extern "C" int hrfd_mod_reset(hrfd_mod *, uint32_t) { HRFD_TODO("hrfd_mod_reset"); }

@@ -48,6 +48,10 @@ struct alignas(16) ChanState
   // FM (F1-F4): last kFmTail samples of the 256 kS/s stream it consumed
   // (stored as offset-binary index bytes i,q), everything else is derived.
   uint8_t fm_tail[2 * kFmTail];
+  // the two post-demodulation stages hold samples that were scaled with the gain
+  // of their time, so their pipelines are carried, not re-derived (D(12,4): 8, D(40,2): 38)
+  int16_t fm_u[kWbU];
+  int16_t fm_v[kWbV + 2];
 
   // AM (M1/M2) and SSB (S1/S2): iq256 tails + 8 kS/s recurrences
   uint8_t am_tail[2 * kAmTail];
@@ -81,6 +85,8 @@ struct RxParams
   int32_t hal;                 // history samples re-derived for blocks b > 0
   int32_t warm;                // de-emphasis warm-up length (kWarm; tests shrink it)
   int32_t serial;              // 1: exact one-lane recurrence (replay path, n_blocks == 1)
+  int32_t src256;              // 1: the input IS the 256 kS/s mixed stream (inner demodulator API):
+                               //    2 bytes per sample, no front end, no squelch
   int32_t dbg_flags;           // timing experiments only (results are wrong when non-zero)
   int32_t stagger;             // start-up delay of odd dispatch layers, in units of s_sleep(127) (~8k cycles)
   uint32_t out_blocks;         // outputs are laid out [C][out_blocks][...]; this launch fills

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
   int32_t dbfs = P.dbfs[min(mean_mag, 127u)] - 42;
   dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
   const bool present = dbfs >= cfg.threshold;
-  const bool allowed = first ? (present || st->tracking != 0) : true;
+  // (the inner demodulator API has no squelch: X::acceptIqData always demodulates)
+  const bool allowed = P.src256 ? true : (first ? (present || st->tracking != 0) : true);
   if (tid == 0)
   {
     P.magnitude[X.ounit] = mean_mag;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
   }
   const bool last = (b + 1 == P.n_blocks);
   ChanState *so = P.state_out + c;
-  if (last && tid < 4)
+  if (last && tid < 4 && !P.src256)
   {
     reinterpret_cast<uint32_t *>(so->fe_tail)[tid] =
         reinterpret_cast<const uint32_t *>(blk + P.block_bytes - 16)[tid];
@@ -230,10 +231,37 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
       const uint32_t w = ((uint32_t)f2i16(kgain * d0) & 0xffffu) | ((uint32_t)f2i16(kgain * d1) << 16);
       lds[kUOff + q] = w;
     }
+    uint16_t *U16 = reinterpret_cast<uint16_t *>(lds + kUOff);
+    uint16_t *V16 = reinterpret_cast<uint16_t *>(lds + kVOff);
+    if (first)
+    {
+      // at the start of a call the two audio stages continue from their carried
+      // pipelines (their samples carry the gain of the time they were demodulated)
+      __syncthreads();
+      if (tid < kWbU)
+      {
+        U16[kUHist - kWbU + tid] = (uint16_t)st->fm_u[tid];
+      }
+      if (tid < kWbV)
+      {
+        V16[kVHist - kWbV + tid] = (uint16_t)st->fm_v[tid];
+      }
+    }
     __syncthreads();
-    stage_d12(lds, -kVHist, n16, tid);
+    stage_d12(lds, first ? 0 : -kVHist, n16, tid);
     __syncthreads();
     stage_d40(lds, n8, reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)n8), tid);
+    if (last)
+    {
+      if (tid < kWbU)
+      {
+        so->fm_u[tid] = (int16_t)U16[kUHist + n64 - kWbU + tid];
+      }
+      if (tid < kWbV)
+      {
+        so->fm_v[tid] = (int16_t)V16[kVHist + n16 - kWbV + tid];
+      }
+    }
     return;
   }
 
@@ -388,7 +416,7 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
   {
     // exact gate of a single-block call (Squelch::run): closed -> nothing happens
     const bool present = P.present[(size_t)c] != 0;
-    if (!(present || st->tracking != 0))
+    if (!P.src256 && !(present || st->tracking != 0))
     {
       return;
     }

@@ -459,6 +459,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // vector ALU work; reads past the end of the channel's input return zeros.
 __device__ __forceinline__ uint4 load_chunk(const StreamCtx &X, int chunk)
 {
+  if (X.P->src256)
+  {
+    // inner demodulator API: the stream is already at 256 kS/s, one (I,Q) byte pair per lane
+    const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 64 * chunk) * 2);
+    const uint32_t w = __builtin_amdgcn_raw_buffer_load_b16(X.rsrc, X.lane * 2, soff, 0);
+    return make_uint4(w, 0u, 0u, 0u);
+  }
   const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 64 * chunk) * 16);
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, X.lane * 16, soff, 0);
   return make_uint4(v.x, v.y, v.z, v.w);
@@ -507,16 +514,19 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   {
     return;
   }
-  FeCarry fc;
+  FeCarry fc = {0x00800080u, 0x00800080u, 0x00800080u};
   uint32_t c_theta = 0, c_p = 0;                         // lane 0: theta, b0*x of the sample before
   if (X.first && cbeg == 0)
   {
     // the stream continues from the previous call: carried state
-    fc = carry_from_16(*reinterpret_cast<const uint4 *>(X.st->fe_tail));
+    if (!P.src256)
+    {
+      fc = carry_from_16(*reinterpret_cast<const uint4 *>(X.st->fe_tail));
+    }
     c_theta = f2u(X.st->wb_theta);
     c_p = f2u(X.st->wb_p);
   }
-  else
+  else if (!P.src256)
   {
     // the three front-end carries depend on the 16 bytes before the run only
     const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 64 * cbeg) * 16 - 16);
@@ -531,9 +541,18 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
 
   // stage 1: raw chunk -> 256 kS/s sample, side outputs, atan2 gather issued
   auto front = [&](const uint4 raw, const int ch) -> float {
-    const uint32_t y3 = frontend(raw, fc);
-    const uint32_t mixed = mix_fs4(y3, mc);              // (q_idx << 16) | i_idx
-    if (!REPAIR)
+    uint32_t y3 = 0, mixed;
+    if (P.src256)
+    {
+      const uint32_t w = raw.x ^ 0x8080u;                // int8 -> (value + 128)
+      mixed = (w & 0xffu) | ((w & 0xff00u) << 8);
+    }
+    else
+    {
+      y3 = frontend(raw, fc);
+      mixed = mix_fs4(y3, mc);                           // (q_idx << 16) | i_idx
+    }
+    if (!REPAIR && !P.src256)
     {
       const uint32_t mag = magnitude(y3);
       magsum += (ch >= nskip) ? mag : 0u;
@@ -769,7 +788,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   // Squelch::run + SignalTracker::run: allowed = present || tracking.  For b > 0
   // the predecessor's `present` is not known here: the batch speculates "open"
   // and k_rx_epilogue verifies it.
-  const bool allowed = first ? (present || st->tracking != 0) : true;
+  // (the inner demodulator API has no squelch: X::acceptIqData always demodulates)
+  const bool allowed = P.src256 ? true : (first ? (present || st->tracking != 0) : true);
   if (tid == 0)
   {
     P.magnitude[X.ounit] = mean_mag;
@@ -778,7 +798,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 
   const bool last = (b + 1 == P.n_blocks);
   ChanState *so = P.state_out + c;
-  if (last && tid < 4)
+  if (last && tid < 4 && !P.src256)
   {
     // front-end carry for the next call: the last 16 raw bytes of this block
     reinterpret_cast<uint32_t *>(so->fe_tail)[tid] =
@@ -1139,6 +1159,8 @@ __global__ void k_rx_commit(const EpilogueParams E)
   else if (mode == 2)
   {
     for (int i = 0; i < 2 * kFmTail; i++) dst->fm_tail[i] = src->fm_tail[i];
+    for (int i = 0; i < kWbU; i++) dst->fm_u[i] = src->fm_u[i];
+    for (int i = 0; i < kWbV; i++) dst->fm_v[i] = src->fm_v[i];
   }
   else if (mode == 1)
   {

@@ -104,6 +104,19 @@ def test_mixed_mode_bank(oracle):
             assert (pcm[c, b, :npcm[c, b]] == want[b][0]).all(), (c, m, b)
 
 
+@pytest.mark.parametrize("mode", [AM, FM, WBFM, LSB])
+def test_gain_change_between_calls(oracle, mode):
+    """the decimator pipelines keep samples scaled with the OLD gain (FM/WBFM)"""
+    x = synth.make_input("lcg", 8, 4).reshape(1, 4, BLK)
+    rx = api.Rx(1); rx.set_mode(mode)
+    o = oracle.rx(); o.set_mode(mode)
+    for k, gain in enumerate([None, 777.0, None, 12345.0]):
+        if gain is not None:
+            rx.set_gain(mode, gain); o.set_gain(mode, gain)
+        got = rx.process_block(x[:, k:k + 1], 1)[0][0, 0]
+        assert (got == o.process(x[0, k])[0]).all(), (mode, k)
+
+
 def test_mode_switch_keeps_each_demodulators_state(oracle):
     x = synth.make_input("lcg", 5, 6).reshape(1, 6, BLK)
     rx = api.Rx(1)
@@ -281,3 +294,46 @@ def test_device_entry_and_sync(oracle):
         for b in range(B):
             assert (pcm[c, b] == want[b][0]).all() and int(d_mag[c, b]) == want[b][1]
     assert (d_np.cpu().numpy() == 512).all()
+
+
+# ---------------------------------------------------------------- inner boundary (per-demodulator API)
+@pytest.mark.parametrize("mode", [AM, FM, WBFM, LSB, USB])
+def test_inner_demod_api_matches_oracle(oracle, mode):
+    """X::acceptIqData on the 256 kS/s mixed stream, 32768-byte calls as IqDataProcessor
+    makes them, incl. resetDemodulator and setDemodulatorGain between calls."""
+    x = synth.lcg_bytes(21, 5 * 32768)
+    g, o = api.Demod(mode, 1), oracle.demod(mode)
+    for k in range(5):
+        if k == 2:
+            g.reset(); o.reset()
+        if k == 3:
+            g.set_gain(777.0); o.set_gain(777.0)
+        a = g.process(x[k * 32768:(k + 1) * 32768])
+        b = o.process(x[k * 32768:(k + 1) * 32768])
+        assert len(a) == 512 and (a == b).all(), (mode, k)
+
+
+def test_inner_demod_sideband_switch_and_sizes(oracle):
+    x = synth.lcg_bytes(3, 4 * 32768)
+    g, o = api.Demod(LSB, 1), oracle.demod(LSB)
+    off = 0
+    for n, lsb in [(32768, True), (4096, False), (128, False), (16384, True)]:
+        g.set_sideband(lsb); o.set_sideband(lsb)
+        a = g.process(x[off:off + n]); b = o.process(x[off:off + n])
+        assert (a == b).all(), n
+        off += n
+    with pytest.raises(api.HrfdError):
+        g.process(np.zeros(64, dtype=np.int8))          # multiples of 128 bytes only
+    with pytest.raises(api.HrfdError):
+        api.Demod(WBFM, 1).set_sideband(True)
+
+
+def test_inner_demod_many_channels(oracle):
+    C = 7
+    xs = np.stack([synth.lcg_bytes(40 + c, 2 * 32768) for c in range(C)])
+    g = api.Demod(WBFM, C)
+    got = [g.process(xs[:, k * 32768:(k + 1) * 32768]) for k in range(2)]
+    for c in range(C):
+        o = oracle.demod(WBFM)
+        for k in range(2):
+            assert (got[k][c] == o.process(xs[c, k * 32768:(k + 1) * 32768])).all()
