@@ -93,6 +93,18 @@ def load() -> C.CDLL:
     L.hrfd_demod_set_gain.argtypes = [_vp, C.c_uint32, C.c_float]
     L.hrfd_demod_set_sideband.argtypes = [_vp, C.c_uint32, C.c_int]
     L.hrfd_demod_process.argtypes = [_vp, _vp, C.c_uint32, _vp, _vp]
+    L.hrfd_mod_create.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(_vp)]
+    L.hrfd_mod_destroy.argtypes = [_vp]
+    L.hrfd_mod_reset.argtypes = [_vp, C.c_uint32]
+    L.hrfd_mod_set_sideband.argtypes = [_vp, C.c_uint32, C.c_int]
+    L.hrfd_mod_process.argtypes = [_vp, _vp, C.c_uint32, _vp, _u32p]
+    L.hrfd_mod_process_device.argtypes = [_vp, _vp, C.c_uint32, _vp, _vp]
+    L.hrfd_mod_sync.argtypes = [_vp]
+    L.hrfd_nco_create.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_int, C.POINTER(_vp)]
+    L.hrfd_nco_destroy.argtypes = [_vp]
+    L.hrfd_nco_set_frequency.argtypes = [_vp, C.c_uint32, C.c_float]
+    L.hrfd_nco_reset.argtypes = [_vp, C.c_uint32]
+    L.hrfd_nco_run.argtypes = [_vp, C.c_int, C.c_uint32, _vp, _vp]
     L.hrfd_q15_table.argtypes = [C.c_char_p, _i16p, C.c_int]
     L.hrfd_atan2_table.argtypes = [_f32p]
     L.hrfd_dbfs_table.argtypes = [_i32p]

@@ -183,8 +183,92 @@ class Demod:
         return pcm if self.n > 1 else pcm[0]
 
 
+MOD_SSB, MOD_INTERP = 1, 2
+
+
+class Mod:
+    """n_channels SSB modulators / interpolateSignal cascades (hrfd_mod_*)."""
+
+    def __init__(self, kind: int, n_channels: int = 1, device: int = -1):
+        self.L = _lib.load()
+        self.n = int(n_channels)
+        self.kind = kind
+        h = C.c_void_p()
+        check(self.L.hrfd_mod_create(kind, self.n, device, C.byref(h)), "hrfd_mod_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hrfd_mod_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self, channel=ALL):
+        check(self.L.hrfd_mod_reset(self.h, channel), "hrfd_mod_reset")
+
+    def set_sideband(self, lsb, channel=ALL):
+        check(self.L.hrfd_mod_set_sideband(self.h, channel, int(bool(lsb))), "hrfd_mod_set_sideband")
+
+    def process(self, pcm):
+        """SSB: int16 [C, n]; INTERP: int16 [C, 2n] IQ pairs -> int8 [C, 512 n]"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(self.n, -1)
+        n = pcm.shape[1] // (2 if self.kind == MOD_INTERP else 1)
+        out = np.zeros((self.n, 512 * n), dtype=np.int8)
+        ob = C.c_uint32(0)
+        check(self.L.hrfd_mod_process(self.h, _ptr(pcm), n, _ptr(out), C.byref(ob)), "hrfd_mod_process")
+        assert ob.value == 512 * n
+        return out if self.n > 1 else out[0]
+
+    def process_device(self, d_pcm, n, d_out, stream=None):
+        check(self.L.hrfd_mod_process_device(self.h, _ptr(d_pcm), n, _ptr(d_out), _ptr(stream)),
+              "hrfd_mod_process_device")
+
+    def sync(self):
+        check(self.L.hrfd_mod_sync(self.h), "hrfd_mod_sync")
+
+
+class Nco:
+    """n_channels oscillators (hrfd_nco_*; Nco::run / Nco::runFast)."""
+
+    def __init__(self, sample_rate: float, frequency: float, n_channels: int = 1, device: int = -1):
+        self.L = _lib.load()
+        self.n = int(n_channels)
+        h = C.c_void_p()
+        check(self.L.hrfd_nco_create(self.n, C.c_float(sample_rate), C.c_float(frequency), device, C.byref(h)),
+              "hrfd_nco_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hrfd_nco_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_frequency(self, f, channel=ALL):
+        check(self.L.hrfd_nco_set_frequency(self.h, channel, C.c_float(f)), "hrfd_nco_set_frequency")
+
+    def reset(self, channel=ALL):
+        check(self.L.hrfd_nco_reset(self.h, channel), "hrfd_nco_reset")
+
+    def run(self, count: int, fast: bool = False):
+        i = np.zeros((self.n, count), dtype=np.float32)
+        q = np.zeros((self.n, count), dtype=np.float32)
+        check(self.L.hrfd_nco_run(self.h, int(fast), count, _ptr(i), _ptr(q)), "hrfd_nco_run")
+        return (i, q) if self.n > 1 else (i[0], q[0])
+
+
 class Engine:
     """Factory with the interface tests/goldencheck.py expects."""
+
+    def ssbmod(self, lsb=True):
+        m = Mod(MOD_SSB, 1)
+        m.set_sideband(lsb)
+        return m
+
+    def interp(self):
+        return Mod(MOD_INTERP, 1)
 
     def rx(self):
         return SingleChannelRx()

@@ -1002,19 +1002,367 @@ extern "C" int hrfd_demod_process(hrfd_demod *dh, const int8_t *iq256k, uint32_t
   return HRFD_OK;
 }
 
-// ------------------------------------------------------------------ not yet built
-// Entry points of include/hrfd.h whose kernels are still being written.  They
-// fail loudly (HRFD_ESTATE) -- there is no CPU stand-in behind them.
-#define HRFD_TODO(name) return fail(HRFD_ESTATE, name ": this entry point is not built into libhrfd.so yet")
-extern "C" int hrfd_mod_create(int, uint32_t, int, hrfd_mod **) { HRFD_TODO("hrfd_mod_create"); }
-extern "C" int hrfd_mod_destroy(hrfd_mod *) { HRFD_TODO("hrfd_mod_destroy"); }
-extern "C" int hrfd_mod_reset(hrfd_mod *, uint32_t) { HRFD_TODO("hrfd_mod_reset"); }
-extern "C" int hrfd_mod_set_sideband(hrfd_mod *, uint32_t, int) { HRFD_TODO("hrfd_mod_set_sideband"); }
-extern "C" int hrfd_mod_process(hrfd_mod *, const int16_t *, uint32_t, int8_t *, uint32_t *) { HRFD_TODO("hrfd_mod_process"); }
-extern "C" int hrfd_mod_process_device(hrfd_mod *, const int16_t *, uint32_t, int8_t *, void *) { HRFD_TODO("hrfd_mod_process_device"); }
-extern "C" int hrfd_mod_sync(hrfd_mod *) { HRFD_TODO("hrfd_mod_sync"); }
-extern "C" int hrfd_nco_create(uint32_t, float, float, int, hrfd_nco **) { HRFD_TODO("hrfd_nco_create"); }
-extern "C" int hrfd_nco_destroy(hrfd_nco *) { HRFD_TODO("hrfd_nco_destroy"); }
-extern "C" int hrfd_nco_set_frequency(hrfd_nco *, uint32_t, float) { HRFD_TODO("hrfd_nco_set_frequency"); }
-extern "C" int hrfd_nco_reset(hrfd_nco *, uint32_t) { HRFD_TODO("hrfd_nco_reset"); }
-extern "C" int hrfd_nco_run(hrfd_nco *, int, uint32_t, float *, float *) { HRFD_TODO("hrfd_nco_run"); }
+// ------------------------------------------------------------------ transmit
+struct hrfd_mod
+{
+  int device = 0;
+  int kind = 0;
+  uint32_t n_channels = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t last_stream = nullptr;
+  int16_t *d_tail[2] = {nullptr, nullptr};   // ping-pong: [C][4][kModTail]
+  int cur = 0;
+  uint8_t *d_lsb = nullptr;
+  std::vector<uint8_t> h_lsb;
+  bool lsb_dirty = true;
+  std::mutex mu;
+  std::vector<uint32_t> resets;
+  // staging for the host entry
+  int16_t *d_in = nullptr;
+  int8_t *d_out = nullptr;
+  size_t cap_in = 0, cap_out = 0;
+};
+
+static int mod_free(hrfd_mod *h)
+{
+  if (h == nullptr)
+  {
+    return HRFD_OK;
+  }
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void *ptrs[] = {h->d_tail[0], h->d_tail[1], h->d_lsb, h->d_in, h->d_out};
+  for (void *p : ptrs)
+  {
+    if (p) (void)hipFree(p);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out)
+{
+  if (out == nullptr || n_channels == 0 || (kind != HRFD_MOD_SSB && kind != HRFD_MOD_INTERP))
+  {
+    return fail(HRFD_EINVAL, "hrfd_mod_create: kind must be HRFD_MOD_SSB or HRFD_MOD_INTERP, n_channels > 0");
+  }
+  *out = nullptr;
+  if (hrfd_device_count() <= 0)
+  {
+    return fail(HRFD_ENODEV, "hrfd_mod_create: no HIP device visible (this library has no CPU path)");
+  }
+  if (device < 0)
+  {
+    HIP_TRY(hipGetDevice(&device));
+  }
+  HIP_TRY(hipSetDevice(device));
+  hrfd_mod *h = new hrfd_mod;
+  h->device = device;
+  h->kind = kind;
+  h->n_channels = n_channels;
+  h->h_lsb.assign(n_channels, 1);                        // SsbModulator starts in LSB (SsbModulator.cc ctor)
+  const size_t tail_bytes = (size_t)n_channels * 4 * kModTail * sizeof(int16_t);
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail[0], tail_bytes);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_tail[1], tail_bytes);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_lsb, n_channels);
+  if (e == hipSuccess) e = hipMemset(h->d_tail[0], 0, tail_bytes);   // zero pipelines == resetModulator()
+  if (e == hipSuccess) e = hipMemset(h->d_tail[1], 0, tail_bytes);
+  if (e != hipSuccess)
+  {
+    const int rc = fail(HRFD_ENOMEM, "hrfd_mod_create: %s", hipGetErrorString(e));
+    mod_free(h);
+    return rc;
+  }
+  *out = h;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_mod_destroy(hrfd_mod *h) { return mod_free(h); }
+
+extern "C" int hrfd_mod_reset(hrfd_mod *h, uint32_t channel)
+{
+  if (h == nullptr || (channel != HRFD_ALL_CHANNELS && channel >= h->n_channels))
+  {
+    return fail(HRFD_EINVAL, "hrfd_mod_reset: bad handle or channel");
+  }
+  std::lock_guard<std::mutex> g(h->mu);
+  h->resets.push_back(channel);
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_mod_set_sideband(hrfd_mod *h, uint32_t channel, int lsb)
+{
+  if (h == nullptr || (channel != HRFD_ALL_CHANNELS && channel >= h->n_channels))
+  {
+    return fail(HRFD_EINVAL, "hrfd_mod_set_sideband: bad handle or channel");
+  }
+  std::lock_guard<std::mutex> g(h->mu);
+  for (uint32_t c = 0; c < h->n_channels; c++)
+  {
+    if (channel == HRFD_ALL_CHANNELS || channel == c)
+    {
+      h->h_lsb[c] = lsb ? 1 : 0;
+    }
+  }
+  h->lsb_dirty = true;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32_t n_per_channel,
+                                       int8_t *d_iq_out, void *stream)
+{
+  if (h == nullptr || d_pcm == nullptr || d_iq_out == nullptr || n_per_channel == 0)
+  {
+    return fail(HRFD_EINVAL, "hrfd_mod_process_device: NULL argument or n_per_channel == 0");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = (stream != nullptr) ? (hipStream_t)stream : h->stream;
+  {
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->lsb_dirty)
+    {
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipMemcpy(h->d_lsb, h->h_lsb.data(), h->n_channels, hipMemcpyHostToDevice));
+      h->lsb_dirty = false;
+    }
+    for (uint32_t ch : h->resets)
+    {
+      // SsbModulator::resetModulator: every pipeline back to zero
+      const size_t per = (size_t)4 * kModTail * sizeof(int16_t);
+      if (ch == HRFD_ALL_CHANNELS)
+      {
+        HIP_TRY(hipMemsetAsync(h->d_tail[h->cur], 0, per * h->n_channels, s));
+      }
+      else
+      {
+        HIP_TRY(hipMemsetAsync(h->d_tail[h->cur] + (size_t)ch * 4 * kModTail, 0, per, s));
+      }
+    }
+    h->resets.clear();
+  }
+  ModParams M;
+  M.in = d_pcm;
+  M.out = d_iq_out;
+  M.tail_in = h->d_tail[h->cur];
+  M.tail_out = h->d_tail[h->cur ^ 1];
+  M.lsb = h->d_lsb;
+  M.n = n_per_channel;
+  M.n_channels = h->n_channels;
+  const uint32_t tiles = (n_per_channel + kModTile - 1) / kModTile;
+  const uint32_t grid = h->n_channels * tiles;
+  if (h->kind == HRFD_MOD_SSB)
+  {
+    hipLaunchKernelGGL(k_mod<HRFD_MOD_SSB>, dim3(grid), dim3(kModThreads), 0, s, M);
+  }
+  else
+  {
+    hipLaunchKernelGGL(k_mod<HRFD_MOD_INTERP>, dim3(grid), dim3(kModThreads), 0, s, M);
+  }
+  HIP_TRY(hipGetLastError());
+  h->cur ^= 1;
+  h->last_stream = s;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_mod_sync(hrfd_mod *h)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL handle");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->last_stream ? h->last_stream : h->stream));
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_mod_process(hrfd_mod *h, const int16_t *pcm, uint32_t n_per_channel, int8_t *iq_out,
+                                uint32_t *out_bytes)
+{
+  if (h == nullptr || pcm == nullptr || iq_out == nullptr || n_per_channel == 0)
+  {
+    return fail(HRFD_EINVAL, "hrfd_mod_process: NULL argument or n_per_channel == 0");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t per_in = (size_t)n_per_channel * (h->kind == HRFD_MOD_INTERP ? 2 : 1) * sizeof(int16_t);
+  const size_t in_bytes = per_in * h->n_channels;
+  const size_t out_total = (size_t)h->n_channels * n_per_channel * 512;
+  int rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if ((rc = grow((void **)&h->d_in, &h->cap_in, in_bytes)) != HRFD_OK) return rc;
+  if ((rc = grow((void **)&h->d_out, &h->cap_out, out_total)) != HRFD_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(h->d_in, pcm, in_bytes, hipMemcpyHostToDevice, h->stream));
+  if ((rc = hrfd_mod_process_device(h, h->d_in, n_per_channel, h->d_out, h->stream)) != HRFD_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(iq_out, h->d_out, out_total, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (out_bytes != nullptr)
+  {
+    *out_bytes = n_per_channel << 9;                       // bytes per channel (SsbModulator.cc:512)
+  }
+  return HRFD_OK;
+}
+
+// ------------------------------------------------------------------ Nco
+struct hrfd_nco
+{
+  int device = 0;
+  uint32_t n_channels = 0;
+  float sample_rate = 0;
+  hipStream_t stream = nullptr;
+  float *d_acc = nullptr, *d_step = nullptr, *d_sin = nullptr, *d_cos = nullptr;
+  float *d_i = nullptr, *d_q = nullptr;
+  size_t cap_out = 0;
+  std::vector<float> h_step;
+  bool step_dirty = true;
+};
+
+static int nco_free(hrfd_nco *h)
+{
+  if (h == nullptr)
+  {
+    return HRFD_OK;
+  }
+  (void)hipSetDevice(h->device);
+  void *ptrs[] = {h->d_acc, h->d_step, h->d_sin, h->d_cos, h->d_i, h->d_q};
+  for (void *p : ptrs)
+  {
+    if (p) (void)hipFree(p);
+  }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_nco_create(uint32_t n_channels, float sample_rate, float frequency, int device,
+                               hrfd_nco **out)
+{
+  if (out == nullptr || n_channels == 0)
+  {
+    return fail(HRFD_EINVAL, "hrfd_nco_create: bad arguments");
+  }
+  *out = nullptr;
+  if (hrfd_device_count() <= 0)
+  {
+    return fail(HRFD_ENODEV, "hrfd_nco_create: no HIP device visible (this library has no CPU path)");
+  }
+  if (device < 0)
+  {
+    HIP_TRY(hipGetDevice(&device));
+  }
+  HIP_TRY(hipSetDevice(device));
+  hrfd_nco *h = new hrfd_nco;
+  h->device = device;
+  h->n_channels = n_channels;
+  h->sample_rate = sample_rate;
+  // PhaseAccumulator.cc:41: double expression stored to float
+  h->h_step.assign(n_channels, (float)((2 * M_PI * frequency) / sample_rate));
+  // Nco.cc:50-61: tables from a float angle accumulated by float increments; sin/cos
+  // of a float argument are sinf/cosf under the C++ overloads -> host libm
+  std::vector<float> st(16384), ct(16384);
+  {
+    const float inc = (float)(2 * M_PI / 16384);
+    float ang = (float)(-M_PI);
+    for (int i = 0; i < 16384; i++)
+    {
+      st[i] = sinf(ang);
+      ct[i] = cosf(ang);
+      ang += inc;
+    }
+  }
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_acc, sizeof(float) * n_channels);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_step, sizeof(float) * n_channels);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_sin, sizeof(float) * 16384);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_cos, sizeof(float) * 16384);
+  if (e == hipSuccess) e = hipMemset(h->d_acc, 0, sizeof(float) * n_channels);
+  if (e == hipSuccess) e = hipMemcpy(h->d_sin, st.data(), sizeof(float) * 16384, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_cos, ct.data(), sizeof(float) * 16384, hipMemcpyHostToDevice);
+  if (e != hipSuccess)
+  {
+    const int rc = fail(HRFD_ENOMEM, "hrfd_nco_create: %s", hipGetErrorString(e));
+    nco_free(h);
+    return rc;
+  }
+  *out = h;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_nco_destroy(hrfd_nco *h) { return nco_free(h); }
+
+extern "C" int hrfd_nco_set_frequency(hrfd_nco *h, uint32_t channel, float frequency)
+{
+  if (h == nullptr || (channel != HRFD_ALL_CHANNELS && channel >= h->n_channels))
+  {
+    return fail(HRFD_EINVAL, "hrfd_nco_set_frequency: bad handle or channel");
+  }
+  const float step = (float)((2 * M_PI * frequency) / h->sample_rate);   // PhaseAccumulator.cc:105
+  for (uint32_t c = 0; c < h->n_channels; c++)
+  {
+    if (channel == HRFD_ALL_CHANNELS || channel == c)
+    {
+      h->h_step[c] = step;
+    }
+  }
+  h->step_dirty = true;
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_nco_reset(hrfd_nco *h, uint32_t channel)
+{
+  if (h == nullptr || (channel != HRFD_ALL_CHANNELS && channel >= h->n_channels))
+  {
+    return fail(HRFD_EINVAL, "hrfd_nco_reset: bad handle or channel");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (channel == HRFD_ALL_CHANNELS)
+  {
+    HIP_TRY(hipMemset(h->d_acc, 0, sizeof(float) * h->n_channels));
+  }
+  else
+  {
+    HIP_TRY(hipMemset(h->d_acc + channel, 0, sizeof(float)));
+  }
+  return HRFD_OK;
+}
+
+extern "C" int hrfd_nco_run(hrfd_nco *h, int fast, uint32_t count, float *i_out, float *q_out)
+{
+  if (h == nullptr || i_out == nullptr || q_out == nullptr || count == 0)
+  {
+    return fail(HRFD_EINVAL, "hrfd_nco_run: bad arguments");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t bytes = sizeof(float) * (size_t)h->n_channels * count;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (bytes > h->cap_out)
+  {
+    size_t c1 = 0, c2 = 0;
+    int rc;
+    if ((rc = grow((void **)&h->d_i, &c1, bytes)) != HRFD_OK) return rc;
+    if ((rc = grow((void **)&h->d_q, &c2, bytes)) != HRFD_OK) return rc;
+    h->cap_out = bytes;
+  }
+  if (h->step_dirty)
+  {
+    HIP_TRY(hipMemcpy(h->d_step, h->h_step.data(), sizeof(float) * h->n_channels, hipMemcpyHostToDevice));
+    h->step_dirty = false;
+  }
+  NcoParams N;
+  N.acc = h->d_acc;
+  N.step = h->d_step;
+  N.sin_t = h->d_sin;
+  N.cos_t = h->d_cos;
+  N.i_out = h->d_i;
+  N.q_out = h->d_q;
+  N.n_channels = h->n_channels;
+  N.count = count;
+  N.fast = fast;
+  hipLaunchKernelGGL(k_nco, dim3((h->n_channels + 63) / 64), dim3(64), 0, h->stream, N);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(i_out, h->d_i, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(q_out, h->d_q, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return HRFD_OK;
+}

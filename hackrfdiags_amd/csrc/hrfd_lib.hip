@@ -3,4 +3,6 @@
 // / device link step is needed (plain `hipcc -c` + host link).
 #include "hrfd_rx_kernels.hip"
 #include "hrfd_rx_fir_kernels.hip"
+#include "../../include/hrfd.h"
+#include "hrfd_tx_kernels.hip"
 #include "hrfd_api.hip"

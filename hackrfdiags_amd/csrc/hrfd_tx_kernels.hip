@@ -1,0 +1,394 @@
+// hackrfdiags_amd/csrc/hrfd_tx_kernels.hip -- gfx950 transmit kernels.
+//
+//   k_mod<SSB>     SsbModulator::acceptData (SsbModulator.cc:455-470):
+//                  modulateSignal (:667-707): s = (int16)(pcm/2); I = delay line
+//                  (16 taps {0 x15, 1.0}; 1.0 quantises to -32768: I[n] = -s[n-15]),
+//                  Q = 31-tap Hilbert (negated for USB);
+//                  increaseSampleRate (:499-619): eight x2 Q15 polyphase stages
+//                  (Interpolator_int16.cc:398-418), (int8_t) narrowing, interleave.
+//   k_mod<INTERP>  signals/interpolateSignal.cc:250-374: int16 IQ pairs through the
+//                  same cascade with that tool's own (asymmetric) stage-1 table.
+//
+// Everything is integer FIR work (bit-exact), so blocks of one channel are
+// independent given enough input history: a workgroup owns a tile of 32 input
+// samples (16 KiB of output), re-derives the few history samples every stage
+// needs from the PCM just before the tile (from the carried tail at the start
+// of a call), keeps stages 1-5 in LDS and runs the last three x2 stages in
+// registers so that every lane ends with 16 contiguous output bytes
+// (8 IQ pairs): one coalesced 16-byte store per lane, write traffic only.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hrfd {
+
+constexpr int kModTile = 32;            // input samples per workgroup
+constexpr int kModThreads = 256;
+constexpr int kModTail = 64;            // carried input history per channel (>= 54)
+
+struct ModParams
+{
+  const int16_t *in;        // SSB: [C][n] PCM; INTERP: [C][2n] IQ pairs
+  int8_t *out;              // [C][512 n]
+  const int16_t *tail_in;   // [C][4][kModTail]: rows 0,1 the stage-0 source (SSB: scaled PCM in row 0),
+  int16_t *tail_out;        //   rows 2,3 the last kH0 samples of the I and Q rails as they were
+                            //   produced (the Q rail carries the sideband sign of its time)
+  const uint8_t *lsb;       // [C] sideband (SSB)
+  uint32_t n;               // input samples per channel
+  uint32_t n_channels;
+};
+
+// taps of the eight stages as the reference's constructors quantise them
+__constant__ constexpr int16_t kS1Ssb[40] = {
+    Q_AUDIO_D40[0],  Q_AUDIO_D40[1],  Q_AUDIO_D40[2],  Q_AUDIO_D40[3],  Q_AUDIO_D40[4],  Q_AUDIO_D40[5],
+    Q_AUDIO_D40[6],  Q_AUDIO_D40[7],  Q_AUDIO_D40[8],  Q_AUDIO_D40[9],  Q_AUDIO_D40[10], Q_AUDIO_D40[11],
+    Q_AUDIO_D40[12], Q_AUDIO_D40[13], Q_AUDIO_D40[14], Q_AUDIO_D40[15], Q_AUDIO_D40[16], Q_AUDIO_D40[17],
+    Q_AUDIO_D40[18], Q_AUDIO_D40[19], Q_AUDIO_D40[20], Q_AUDIO_D40[21], Q_AUDIO_D40[22], Q_AUDIO_D40[23],
+    Q_AUDIO_D40[24], Q_AUDIO_D40[25], Q_AUDIO_D40[26], Q_AUDIO_D40[27], Q_AUDIO_D40[28], Q_AUDIO_D40[29],
+    Q_AUDIO_D40[30], Q_AUDIO_D40[31], Q_AUDIO_D40[32], Q_AUDIO_D40[33], Q_AUDIO_D40[34], Q_AUDIO_D40[35],
+    Q_AUDIO_D40[36], Q_AUDIO_D40[37], Q_AUDIO_D40[38], Q_AUDIO_D40[39]};
+__constant__ constexpr int16_t kS1Interp[40] = {
+    Q_INTERPSIG_S1[0],  Q_INTERPSIG_S1[1],  Q_INTERPSIG_S1[2],  Q_INTERPSIG_S1[3],  Q_INTERPSIG_S1[4],
+    Q_INTERPSIG_S1[5],  Q_INTERPSIG_S1[6],  Q_INTERPSIG_S1[7],  Q_INTERPSIG_S1[8],  Q_INTERPSIG_S1[9],
+    Q_INTERPSIG_S1[10], Q_INTERPSIG_S1[11], Q_INTERPSIG_S1[12], Q_INTERPSIG_S1[13], Q_INTERPSIG_S1[14],
+    Q_INTERPSIG_S1[15], Q_INTERPSIG_S1[16], Q_INTERPSIG_S1[17], Q_INTERPSIG_S1[18], Q_INTERPSIG_S1[19],
+    Q_INTERPSIG_S1[20], Q_INTERPSIG_S1[21], Q_INTERPSIG_S1[22], Q_INTERPSIG_S1[23], Q_INTERPSIG_S1[24],
+    Q_INTERPSIG_S1[25], Q_INTERPSIG_S1[26], Q_INTERPSIG_S1[27], Q_INTERPSIG_S1[28], Q_INTERPSIG_S1[29],
+    Q_INTERPSIG_S1[30], Q_INTERPSIG_S1[31], Q_INTERPSIG_S1[32], Q_INTERPSIG_S1[33], Q_INTERPSIG_S1[34],
+    Q_INTERPSIG_S1[35], Q_INTERPSIG_S1[36], Q_INTERPSIG_S1[37], Q_INTERPSIG_S1[38], Q_INTERPSIG_S1[39]};
+
+// Q15 output of an interpolator phase: (16384 + sum) >> 15, low 16 bits
+__device__ __forceinline__ int q15(int acc) { return (int)(short)(acc >> 15); }
+
+// x2 stage with the 8-tap half-band prototype {-1445,0,9548,16384,9548,0,-1445,0}
+// (INTERP_HB8): phase 0 taps (h0,h2,h4,h6), phase 1 taps (h1,h3,h5,h7) = (0,16384,0,0).
+__device__ __forceinline__ void hb8(const int16_t *x, int n, int &y0, int &y1)
+{
+  const int acc = (1 << 14) + (int)Q_INTERP_HB8[0] * x[n] + (int)Q_INTERP_HB8[2] * x[n - 1] +
+                  (int)Q_INTERP_HB8[4] * x[n - 2] + (int)Q_INTERP_HB8[6] * x[n - 3];
+  y0 = q15(acc);
+  y1 = q15((1 << 14) + (int)Q_INTERP_HB8[1] * x[n] + (int)Q_INTERP_HB8[3] * x[n - 1] +
+           (int)Q_INTERP_HB8[5] * x[n - 2] + (int)Q_INTERP_HB8[7] * x[n - 3]);
+}
+
+// x2 stage with a 4-tap prototype {h0, h1, h2, 0}: phase 0 (h0,h2), phase 1 (h1,0)
+__device__ __forceinline__ void hb4(const int16_t (&h)[4], int xn, int xm1, int &y0, int &y1)
+{
+  y0 = q15((1 << 14) + (int)h[0] * xn + (int)h[2] * xm1);
+  y1 = q15((1 << 14) + (int)h[1] * xn + (int)h[3] * xm1);
+}
+
+// LDS layout per rail (int16), each stage with its history in front:
+//   x0 [24 + 32]   s1 [6 + 64]   s2 [4 + 128]   s3 [6 + 256]   s4 [4 + 512]   s5 [2 + 1024]
+constexpr int kH0 = 24, kH1 = 6, kH2 = 4, kH3 = 6, kH4 = 4, kH5 = 2;
+constexpr int kO0 = 0;
+constexpr int kO1 = kO0 + kH0 + kModTile;
+constexpr int kO2 = kO1 + kH1 + 2 * kModTile;
+constexpr int kO3 = kO2 + kH2 + 4 * kModTile;
+constexpr int kO4 = kO3 + kH3 + 8 * kModTile;
+constexpr int kO5 = kO4 + kH4 + 16 * kModTile;
+constexpr int kRail = kO5 + kH5 + 32 * kModTile + 6;
+
+template <int KIND>
+__global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
+{
+  __shared__ int16_t src[2][kModTail + kModTile];         // stage-0 source with history
+  __shared__ int16_t r[2][kRail];                         // the two rails, stages 0..5
+
+  const uint32_t tiles = (M.n + kModTile - 1) / kModTile;
+  const uint32_t c = blockIdx.x / tiles;
+  const uint32_t tile = blockIdx.x - c * tiles;
+  if (c >= M.n_channels)
+  {
+    return;
+  }
+  const int tid = threadIdx.x;
+  const int t0 = (int)tile * kModTile;                    // first input sample of the tile
+  const int n = (int)M.n;
+  const int16_t *in = M.in + (size_t)c * M.n * (KIND == HRFD_MOD_INTERP ? 2 : 1);
+  const int16_t *tin = M.tail_in + (size_t)c * 4 * kModTail;
+
+  // ---- stage-0 source: scaled PCM (SSB) or the IQ pair (INTERP), history first
+  for (int t = tid; t < kModTail + kModTile; t += kModThreads)
+  {
+    const int g = t0 - kModTail + t;                      // global input index
+    int a = 0, b = 0;
+    if (g < 0)
+    {
+      a = tin[kModTail + g];
+      b = tin[kModTail + kModTail + g];
+    }
+    else if (g < n)
+    {
+      if (KIND == HRFD_MOD_INTERP)
+      {
+        a = in[2 * g];
+        b = in[2 * g + 1];
+      }
+      else
+      {
+        // scaledSample = (float)pcm / 2; (int16_t) truncates toward zero (:679-686)
+        float f = (float)in[g];
+        f = f / 2.0f;
+        a = (int)f;
+      }
+    }
+    src[0][t] = (int16_t)a;
+    src[1][t] = (int16_t)b;
+  }
+  // the last tile of the call also leaves the new tail (the other buffer of the ping-pong)
+  if (tile + 1 == tiles)
+  {
+    int16_t *tout = M.tail_out + (size_t)c * 4 * kModTail;
+    for (int t = tid; t < kModTail; t += kModThreads)
+    {
+      const int g = n - kModTail + t;
+      int a = 0, b = 0;
+      if (g < 0)
+      {
+        const int o = kModTail + g;                       // still inside the old tail
+        a = tin[o];
+        b = tin[kModTail + o];
+      }
+      else if (KIND == HRFD_MOD_INTERP)
+      {
+        a = in[2 * g];
+        b = in[2 * g + 1];
+      }
+      else
+      {
+        float f = (float)in[g];
+        f = f / 2.0f;
+        a = (int)f;
+      }
+      tout[t] = (int16_t)a;
+      tout[kModTail + t] = (int16_t)b;
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 0: the two rails at the input rate, x0[j] for j in [-kH0, kModTile)
+  for (int t = tid; t < kH0 + kModTile; t += kModThreads)
+  {
+    const int j = t - kH0;
+    const int16_t *s0 = &src[0][kModTail + j];            // s[n], s0[-k] = s[n-k]
+    int iv, qv;
+    if (t0 + j < 0)
+    {
+      // before the call: the rails as the previous call produced them (a sideband
+      // switch between calls must not re-sign samples already in the pipelines)
+      iv = tin[2 * kModTail + kModTail + (t0 + j)];
+      qv = tin[3 * kModTail + kModTail + (t0 + j)];
+    }
+    else if (KIND == HRFD_MOD_INTERP)
+    {
+      iv = s0[0];
+      qv = src[1][kModTail + j];
+    }
+    else
+    {
+      // delay line: Q15 tap -32768 at k = 15 (FirFilter_int16.cc:151-224)
+      iv = q15((1 << 14) + (-32768) * (int)s0[-15]);
+      int acc = 1 << 14;
+#pragma unroll
+      for (int k = 0; k < N_SSB_HILBERT; k++)
+      {
+        acc += (int)kHilbert[k] * (int)s0[-k];
+      }
+      qv = q15(acc);
+      if (!M.lsb[c])
+      {
+        qv = (int)(short)(-qv);                           // USB: qPhaseShifted = -qPhaseShifted (:696-699)
+      }
+    }
+    r[0][kO0 + t] = (int16_t)iv;
+    r[1][kO0 + t] = (int16_t)qv;
+  }
+  __syncthreads();
+  if (tile + 1 == tiles)
+  {
+    // new rail tails: x0[g] for g in [n - kModTail, n); only the last kH0 are ever read
+    int16_t *tout = M.tail_out + (size_t)c * 4 * kModTail;
+    for (int t = tid; t < 2 * kModTail; t += kModThreads)
+    {
+      const int rail = t / kModTail, u = t - rail * kModTail;
+      const int j = (n - t0) - kModTail + u;              // tile-relative index
+      tout[(2 + rail) * kModTail + u] = (j >= -kH0) ? r[rail][kO0 + kH0 + j] : (int16_t)0;
+    }
+  }
+
+  // ---- stage 1: 40-tap prototype, x2; outputs m in [-kH1, 2*tile)
+  {
+    const int16_t *h = (KIND == HRFD_MOD_INTERP) ? kS1Interp : kS1Ssb;
+    for (int t = tid; t < 2 * (kH1 + 2 * kModTile); t += kModThreads)
+    {
+      const int rail = t & 1, u = t >> 1;
+      const int m = u - kH1;                              // output index at 16 kS/s
+      const int nn = m >> 1, ph = m & 1;                  // floor division (m may be negative)
+      const int16_t *x = &r[rail][kO0 + kH0 + nn];
+      int acc = 1 << 14;
+#pragma unroll
+      for (int j = 0; j < 20; j++)
+      {
+        acc += (int)h[ph + 2 * j] * (int)x[-j];
+      }
+      r[rail][kO1 + u] = (int16_t)q15(acc);
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: HB8, outputs m in [-kH2, 4*tile)
+  // (from here on a thread produces both phases of one input sample of one rail)
+  for (int t = tid; t < 2 * ((kH2 + 4 * kModTile) / 2); t += kModThreads)
+  {
+    const int rail = t & 1, u = t >> 1;                   // u: input sample slot
+    const int nn = u - kH2 / 2;                           // input index (16 kS/s)
+    int y0, y1;
+    hb8(&r[rail][kO1 + kH1], nn, y0, y1);
+    r[rail][kO2 + 2 * u] = (int16_t)y0;
+    r[rail][kO2 + 2 * u + 1] = (int16_t)y1;
+  }
+  __syncthreads();
+  // ---- stage 3: 4-tap HB3, outputs m in [-kH3, 8*tile)
+  for (int t = tid; t < 2 * ((kH3 + 8 * kModTile) / 2); t += kModThreads)
+  {
+    const int rail = t & 1, u = t >> 1;
+    const int nn = u - kH3 / 2;
+    const int16_t *x = &r[rail][kO2 + kH2];
+    int y0, y1;
+    hb4(Q_INTERP_HB3, x[nn], x[nn - 1], y0, y1);
+    r[rail][kO3 + 2 * u] = (int16_t)y0;
+    r[rail][kO3 + 2 * u + 1] = (int16_t)y1;
+  }
+  __syncthreads();
+  // ---- stage 4: HB8, outputs m in [-kH4, 16*tile)
+  for (int t = tid; t < 2 * ((kH4 + 16 * kModTile) / 2); t += kModThreads)
+  {
+    const int rail = t & 1, u = t >> 1;
+    const int nn = u - kH4 / 2;
+    int y0, y1;
+    hb8(&r[rail][kO3 + kH3], nn, y0, y1);
+    r[rail][kO4 + 2 * u] = (int16_t)y0;
+    r[rail][kO4 + 2 * u + 1] = (int16_t)y1;
+  }
+  __syncthreads();
+  // ---- stage 5: HB8, outputs m in [-kH5, 32*tile)
+  for (int t = tid; t < 2 * ((kH5 + 32 * kModTile) / 2); t += kModThreads)
+  {
+    const int rail = t & 1, u = t >> 1;
+    const int nn = u - kH5 / 2;
+    int y0, y1;
+    hb8(&r[rail][kO4 + kH4], nn, y0, y1);
+    r[rail][kO5 + 2 * u] = (int16_t)y0;
+    r[rail][kO5 + 2 * u + 1] = (int16_t)y1;
+  }
+  __syncthreads();
+
+  // ---- stages 6, 7, 8 in registers: one 256 kS/s sample j -> 8 output IQ pairs
+  const int valid = min(kModTile, n - t0);                // input samples really in this tile
+  int8_t *out = M.out + ((size_t)c * M.n + t0) * 512;
+  for (int j = tid; j < 32 * kModTile; j += kModThreads)
+  {
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int rail = 0; rail < 2; rail++)
+    {
+      const int16_t *x5 = &r[rail][kO5 + kH5];
+      const int xa = x5[j], xb = x5[j - 1], xc = x5[j - 2];
+      // stage 6 (HB3): y6[2j-1] (phase 1 of j-1), y6[2j], y6[2j+1]
+      int a0, a1, p0, p1;
+      hb4(Q_INTERP_HB3, xb, xc, p0, p1);                  // p1 = y6[2j-1]
+      hb4(Q_INTERP_HB3, xa, xb, a0, a1);                  // y6[2j], y6[2j+1]
+      // stage 7 (HB2): y7[4j-1] (phase 1 of y6[2j-1]), y7[4j..4j+3]
+      int b0, b1, b2, b3, q0, q1;
+      hb4(Q_INTERP_HB2, p1, p0, q0, q1);                  // q1 = y7[4j-1]
+      hb4(Q_INTERP_HB2, a0, p1, b0, b1);                  // y7[4j], y7[4j+1]
+      hb4(Q_INTERP_HB2, a1, a0, b2, b3);                  // y7[4j+2], y7[4j+3]
+      // stage 8 (HB1): y8[8j .. 8j+7], (int8_t) narrowing (:607-610)
+      int y[8];
+      hb4(Q_INTERP_HB1, b0, q1, y[0], y[1]);
+      hb4(Q_INTERP_HB1, b1, b0, y[2], y[3]);
+      hb4(Q_INTERP_HB1, b2, b1, y[4], y[5]);
+      hb4(Q_INTERP_HB1, b3, b2, y[6], y[7]);
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+      {
+        // byte 2k (I) or 2k+1 (Q) of the lane's 16 output bytes
+        w[k >> 1] |= ((uint32_t)y[k] & 0xffu) << (8 * (2 * (k & 1) + rail));
+      }
+    }
+    if (j < 32 * valid)
+    {
+      *reinterpret_cast<uint4 *>(out + (size_t)j * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+template __global__ void k_mod<HRFD_MOD_SSB>(const ModParams);
+template __global__ void k_mod<HRFD_MOD_INTERP>(const ModParams);
+
+} // namespace hrfd
+
+namespace hrfd {
+
+// =============================================================================
+//  Nco (Nco/Nco.cc, Nco/PhaseAccumulator.cc): one oscillator per thread
+// =============================================================================
+struct NcoParams
+{
+  float *acc;               // [C] phase accumulator
+  const float *step;        // [C] (float)((2*M_PI*f)/fs)
+  const float *sin_t;       // [16384] host-built (sinf of an accumulated float angle)
+  const float *cos_t;
+  float *i_out, *q_out;     // [C][count]
+  uint32_t n_channels, count;
+  int fast;
+};
+
+__global__ void k_nco(const NcoParams N)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N.n_channels)
+  {
+    return;
+  }
+  const double pi = 3.14159265358979323846, two_pi = 6.283185307179586476925286766559;
+  float acc = N.acc[c];
+  const float step = N.step[c];
+  for (uint32_t k = 0; k < N.count; k++)
+  {
+    // PhaseAccumulator::run (:157-181): return the current phase, then advance
+    // and wrap with double compares / double subtraction stored to float
+    const float phase = acc;
+    acc = acc + step;
+    while ((double)acc > pi)
+    {
+      acc = (float)((double)acc - two_pi);
+    }
+    while ((double)acc < -pi)
+    {
+      acc = (float)((double)acc + two_pi);
+    }
+    float iv, qv;
+    if (N.fast)
+    {
+      // Nco::runFast (:222-257): (int16_t)(phase * 16384 / (2*M_PI)) + 8192, clamped
+      const float scaled = phase * 16384.0f;
+      int idx = (int)(short)(int)((double)scaled / two_pi);
+      idx += 8192;
+      idx = max(0, min(16383, idx));
+      iv = N.cos_t[idx];
+      qv = N.sin_t[idx];
+    }
+    else
+    {
+      // Nco::run (:186-199) calls libm cosf/sinf; here: double-precision cos/sin
+      // rounded to float (agrees with glibc to within 1 ulp)
+      iv = (float)cos((double)phase);
+      qv = (float)sin((double)phase);
+    }
+    N.i_out[(size_t)c * N.count + k] = iv;
+    N.q_out[(size_t)c * N.count + k] = qv;
+  }
+  N.acc[c] = acc;
+}
+
+} // namespace hrfd
