@@ -1,0 +1,97 @@
+// IqDataProcessor.h -- drop-in replacement header: same class name and public
+// interface as radioDiags/hdr_diags/IqDataProcessor.h:23-60 of the reference.
+// acceptIqData runs the fused GPU chain of libhrfd.so (hrfd_rx_process_block):
+// x8 half-band decimation, Fs/4 mix, squelch, demodulation in one launch.
+#ifndef HRFD_SHIM_IQDATAPROCESSOR_H
+#define HRFD_SHIM_IQDATAPROCESSOR_H
+
+#include <stdint.h>
+
+#include "AmDemodulator.h"
+#include "FmDemodulator.h"
+#include "WbFmDemodulator.h"
+#include "SsbDemodulator.h"
+
+class IqDataProcessor
+{
+  public:
+
+  enum demodulatorType {None=0, Am=1, Fm=2, WbFm = 3, Lsb = 4, Usb = 5};
+
+  IqDataProcessor(char *hostIpAddress,int hostPort);
+  ~IqDataProcessor(void);
+
+  void setDemodulatorMode(demodulatorType mode);
+  void setAmDemodulator(AmDemodulator *demodulatorPtr);
+  void setFmDemodulator(FmDemodulator *demodulatorPtr);
+  void setWbFmDemodulator(WbFmDemodulator *demodulatorPtr);
+  void setSsbDemodulator(SsbDemodulator *demodulatorPtr);
+  void setSignalDetectThreshold(int32_t threshold);
+  uint32_t reduceSampleRate(int8_t *bufferPtr,uint32_t bufferLength);
+
+  void downconvertByFsOver4(int8_t *bufferPtr,uint32_t byteCount);
+  void upconvertByFsOver4(int8_t *bufferPtr,uint32_t byteCount);
+
+  void acceptIqData(unsigned long timeStamp,
+                    int8_t *bufferPtr,
+                    unsigned long byteCount);
+
+  void enableSignalNotification(void);
+  void disableSignalNotification(void);
+
+  void registerSignalStateCallback(
+      void (*signalCallbackPtr)(bool signalPresent,
+                                void *contextPtr),
+      void *contextPtr);
+
+  void enableSignalMagnitudeNotification(void);
+  void disableSignalMagnitudeNotification(void);
+
+  void registerSignalMagnitudeCallback(
+      void (*callbackPtr)(uint32_t signalMagnitude,void *contextPtr),
+      void *contextPtr);
+
+  void enableIqDump(void);
+  void disableIqDump(void);
+  bool isIqDumpEnabled(void);
+
+  // Not in the reference: where `enable iqdump` data goes.  The reference sends
+  // decimatedData by UDP (UdpClient::sendData); networking is outside the hot
+  // path, so the host application registers a sink and forwards it itself.
+  void registerIqDumpSink(void (*sinkPtr)(int8_t *bufferPtr,uint32_t byteCount,void *contextPtr),
+                          void *contextPtr);
+
+  void displayInternalInformation(void);
+
+  private:
+
+  void ensureHandle(void);
+  void pushGains(void);
+
+  hrfd_rx *handle;
+  demodulatorType demodulatorMode;
+  int32_t signalDetectThreshold;
+
+  AmDemodulator *amDemodulatorPtr;
+  FmDemodulator *fmDemodulatorPtr;
+  WbFmDemodulator *wbFmDemodulatorPtr;
+  SsbDemodulator *ssbDemodulatorPtr;
+
+  bool iqDumpEnabled;
+  void (*iqDumpSinkPtr)(int8_t *bufferPtr,uint32_t byteCount,void *contextPtr);
+  void *iqDumpContextPtr;
+
+  bool signalNotificationEnabled;
+  void *signalCallbackContextPtr;
+  void (*signalCallbackPtr)(bool signalPresent,void *contextPtr);
+
+  bool signalMagnitudeNotificationEnabled;
+  void *signalMagnitudeCallbackContextPtr;
+  void (*signalMagnitudeCallbackPtr)(uint32_t signalMagnitude,void *contextPtr);
+
+  float pushedGain[4];
+  int16_t pcmData[512];
+  int8_t decimatedData[32768];
+};
+
+#endif

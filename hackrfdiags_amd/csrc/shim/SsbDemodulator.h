@@ -1,0 +1,30 @@
+// SsbDemodulator.h -- drop-in replacement header: same class name and public
+// interface as radioDiags/SsbDemodulator/SsbDemodulator.h:24-34 of the reference,
+// implemented over the C ABI of libhrfd.so (hrfd_demod_*, include/hrfd.h).
+#ifndef HRFD_SHIM_SSBDEMODULATOR_H
+#define HRFD_SHIM_SSBDEMODULATOR_H
+
+#include "hrfd_shim_base.h"
+
+class SsbDemodulator : public hrfd_shim::DemodulatorBase
+{
+  public:
+
+  SsbDemodulator(void (*pcmCallbackPtr)(int16_t *bufferPtr,uint32_t bufferLength));
+  ~SsbDemodulator(void);
+
+  void resetDemodulator(void);
+  void setLsbDemodulationMode(void);
+  void setUsbDemodulationMode(void);
+  void setDemodulatorGain(float gain);
+  void acceptIqData(int8_t *bufferPtr,uint32_t bufferLength);
+  void displayInternalInformation(void);
+
+  bool isLsb(void) const { return lsb; }
+
+  private:
+
+  bool lsb;
+};
+
+#endif

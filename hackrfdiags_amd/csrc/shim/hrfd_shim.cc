@@ -1,0 +1,478 @@
+// hrfd_shim.cc -- the reference-named C++ classes (WbFmDemodulator, FmDemodulator,
+// AmDemodulator, SsbDemodulator, IqDataProcessor, SsbModulator, Nco) implemented
+// over the C ABI of libhrfd.so.  Plain host C++ (g++), no HIP in here: link with
+//     g++ ... hrfd_shim.cc -I include -I hackrfdiags_amd/csrc/shim -lhrfd -lamdhip64
+// in place of lib/lib{Am,Fm,WbFm,Ssb}Demodulator.a, libSsbModulator.a and
+// src_diags/IqDataProcessor.cc (radioDiags/buildRadioDiags.sh:50-66).
+// Like the reference, the classes have no error channel: a failing C-ABI call is
+// reported on stderr and aborts (there is no CPU fallback to hide behind).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "AmDemodulator.h"
+#include "FmDemodulator.h"
+#include "WbFmDemodulator.h"
+#include "SsbDemodulator.h"
+#include "IqDataProcessor.h"
+#include "SsbModulator.h"
+#include "Nco.h"
+
+// symbols of the host application the reference code also expects
+// (Radio.cc:15, diagUi.cc:2881)
+extern uint32_t radio_adjustableReceiveGainInDb;
+extern void nprintf(FILE *s,const char *formatPtr, ...);
+
+namespace hrfd_shim {
+
+void fatal(const char *what, int rc)
+{
+  fprintf(stderr, "libhrfd: %s failed (%d): %s\n", what, rc, hrfd_last_error());
+  abort();
+}
+
+DemodulatorBase::DemodulatorBase(int mode, float defaultGain,
+                                 void (*pcmCallbackPtr)(int16_t *bufferPtr,uint32_t bufferLength))
+{
+  this->mode = mode;
+  this->gain = defaultGain;
+  this->handle = NULL;
+  this->pcmCallbackPtr = pcmCallbackPtr;
+  memset(pcmData, 0, sizeof(pcmData));
+}
+
+DemodulatorBase::~DemodulatorBase(void)
+{
+  if (handle != NULL)
+  {
+    hrfd_demod_destroy(handle);
+  }
+}
+
+void DemodulatorBase::reset(void)
+{
+  if (handle != NULL)
+  {
+    int rc = hrfd_demod_reset(handle, 0);
+    if (rc != HRFD_OK) fatal("hrfd_demod_reset", rc);
+  }
+}
+
+void DemodulatorBase::setGain(float gain)
+{
+  this->gain = gain;
+  if (handle != NULL)
+  {
+    int rc = hrfd_demod_set_gain(handle, 0, gain);
+    if (rc != HRFD_OK) fatal("hrfd_demod_set_gain", rc);
+  }
+}
+
+void DemodulatorBase::setSideband(bool lsb)
+{
+  mode = lsb ? HRFD_MODE_LSB : HRFD_MODE_USB;
+  if (handle != NULL)
+  {
+    int rc = hrfd_demod_set_sideband(handle, 0, lsb ? 1 : 0);
+    if (rc != HRFD_OK) fatal("hrfd_demod_set_sideband", rc);
+  }
+}
+
+void DemodulatorBase::accept(int8_t *bufferPtr,uint32_t bufferLength)
+{
+  uint32_t sampleCount = 0;
+  int rc;
+
+  if (handle == NULL)
+  {
+    rc = hrfd_demod_create(mode, 1, -1, &handle);
+    if (rc != HRFD_OK) fatal("hrfd_demod_create", rc);
+    rc = hrfd_demod_set_gain(handle, 0, gain);
+    if (rc != HRFD_OK) fatal("hrfd_demod_set_gain", rc);
+  }
+  // 256 kS/s IQ in, PCM out; the reference's arrays hold at most 32768 bytes / 512 samples
+  rc = hrfd_demod_process(handle, bufferPtr, bufferLength, pcmData, &sampleCount);
+  if (rc != HRFD_OK) fatal("hrfd_demod_process", rc);
+  // sendPcmData: synchronously, on the caller's thread, buffer valid during the call
+  pcmCallbackPtr(pcmData, sampleCount);
+}
+
+void DemodulatorBase::deliverPcm(int16_t *bufferPtr,uint32_t bufferLength)
+{
+  pcmCallbackPtr(bufferPtr, bufferLength);
+}
+
+void DemodulatorBase::display(const char *name)
+{
+  nprintf(stderr, "\n--------------------------------------------\n");
+  nprintf(stderr, "%s Internal Information (libhrfd, MI355X)\n", name);
+  nprintf(stderr, "--------------------------------------------\n");
+  nprintf(stderr, "Demodulator Gain         : %f\n", gain);
+}
+
+} // namespace hrfd_shim
+
+using hrfd_shim::fatal;
+
+// ---------------------------------------------------------------- demodulators
+// default gains: WbFmDemodulator.cc:151, FmDemodulator.cc:173, AmDemodulator.cc:102
+WbFmDemodulator::WbFmDemodulator(void (*pcmCallbackPtr)(int16_t *bufferPtr,uint32_t bufferLength))
+  : DemodulatorBase(HRFD_MODE_WBFM, (float)(256000/(2 * M_PI)), pcmCallbackPtr) {}
+WbFmDemodulator::~WbFmDemodulator(void) {}
+void WbFmDemodulator::resetDemodulator(void) { reset(); }
+void WbFmDemodulator::setDemodulatorGain(float gain) { setGain(gain); }
+void WbFmDemodulator::acceptIqData(int8_t *bufferPtr,uint32_t bufferLength) { accept(bufferPtr, bufferLength); }
+void WbFmDemodulator::displayInternalInformation(void) { display("Wideband FM Demodulator"); }
+
+FmDemodulator::FmDemodulator(void (*pcmCallbackPtr)(int16_t *bufferPtr,uint32_t bufferLength))
+  : DemodulatorBase(HRFD_MODE_FM, (float)(64000/(2 * M_PI)), pcmCallbackPtr) {}
+FmDemodulator::~FmDemodulator(void) {}
+void FmDemodulator::resetDemodulator(void) { reset(); }
+void FmDemodulator::setDemodulatorGain(float gain) { setGain(gain); }
+void FmDemodulator::acceptIqData(int8_t *bufferPtr,uint32_t bufferLength) { accept(bufferPtr, bufferLength); }
+void FmDemodulator::displayInternalInformation(void) { display("FM Demodulator"); }
+
+AmDemodulator::AmDemodulator(void (*pcmCallbackPtr)(int16_t *bufferPtr,uint32_t bufferLength))
+  : DemodulatorBase(HRFD_MODE_AM, 300, pcmCallbackPtr) {}
+AmDemodulator::~AmDemodulator(void) {}
+void AmDemodulator::resetDemodulator(void) { reset(); }
+void AmDemodulator::setDemodulatorGain(float gain) { setGain(gain); }
+void AmDemodulator::acceptIqData(int8_t *bufferPtr,uint32_t bufferLength) { accept(bufferPtr, bufferLength); }
+void AmDemodulator::displayInternalInformation(void) { display("AM Demodulator"); }
+
+SsbDemodulator::SsbDemodulator(void (*pcmCallbackPtr)(int16_t *bufferPtr,uint32_t bufferLength))
+  : DemodulatorBase(HRFD_MODE_LSB, 300, pcmCallbackPtr) { lsb = true; }
+SsbDemodulator::~SsbDemodulator(void) {}
+void SsbDemodulator::resetDemodulator(void) { reset(); }
+void SsbDemodulator::setLsbDemodulationMode(void) { lsb = true; setSideband(true); }
+void SsbDemodulator::setUsbDemodulationMode(void) { lsb = false; setSideband(false); }
+void SsbDemodulator::setDemodulatorGain(float gain) { setGain(gain); }
+void SsbDemodulator::acceptIqData(int8_t *bufferPtr,uint32_t bufferLength) { accept(bufferPtr, bufferLength); }
+void SsbDemodulator::displayInternalInformation(void) { display("SSB Demodulator"); }
+
+// ---------------------------------------------------------------- IqDataProcessor
+IqDataProcessor::IqDataProcessor(char *hostIpAddress,int hostPort)
+{
+  (void)hostIpAddress;     // the UDP dump of the 256 kS/s stream is the host application's
+  (void)hostPort;          // business here: see registerIqDumpSink()
+  handle = NULL;
+  demodulatorMode = None;
+  signalDetectThreshold = -200;
+  amDemodulatorPtr = NULL;
+  fmDemodulatorPtr = NULL;
+  wbFmDemodulatorPtr = NULL;
+  ssbDemodulatorPtr = NULL;
+  iqDumpEnabled = false;
+  iqDumpSinkPtr = NULL;
+  iqDumpContextPtr = NULL;
+  signalNotificationEnabled = false;
+  signalCallbackPtr = NULL;
+  signalCallbackContextPtr = NULL;
+  signalMagnitudeNotificationEnabled = false;
+  signalMagnitudeCallbackPtr = NULL;
+  signalMagnitudeCallbackContextPtr = NULL;
+  for (int i = 0; i < 4; i++) pushedGain[i] = nanf("");
+}
+
+IqDataProcessor::~IqDataProcessor(void)
+{
+  if (handle != NULL)
+  {
+    hrfd_rx_destroy(handle);
+  }
+}
+
+void IqDataProcessor::ensureHandle(void)
+{
+  if (handle == NULL)
+  {
+    int rc = hrfd_rx_create(1, -1, &handle);
+    if (rc != HRFD_OK) fatal("hrfd_rx_create", rc);
+    rc = hrfd_rx_set_mode(handle, 0, (int)demodulatorMode);
+    if (rc != HRFD_OK) fatal("hrfd_rx_set_mode", rc);
+    rc = hrfd_rx_set_threshold(handle, 0, signalDetectThreshold);
+    if (rc != HRFD_OK) fatal("hrfd_rx_set_threshold", rc);
+  }
+}
+
+// the demodulator objects own the gain setting in the reference; mirror it into
+// the fused chain whenever it changed (the CLI thread calls setDemodulatorGain on them)
+void IqDataProcessor::pushGains(void)
+{
+  const hrfd_shim::DemodulatorBase *d[4] = {amDemodulatorPtr, fmDemodulatorPtr, wbFmDemodulatorPtr,
+                                            ssbDemodulatorPtr};
+  const int modes[4] = {HRFD_MODE_AM, HRFD_MODE_FM, HRFD_MODE_WBFM, HRFD_MODE_LSB};
+  for (int i = 0; i < 4; i++)
+  {
+    if (d[i] != NULL && !(d[i]->currentGain() == pushedGain[i]))
+    {
+      pushedGain[i] = d[i]->currentGain();
+      int rc = hrfd_rx_set_gain(handle, 0, modes[i], pushedGain[i]);
+      if (rc != HRFD_OK) fatal("hrfd_rx_set_gain", rc);
+    }
+  }
+}
+
+void IqDataProcessor::setDemodulatorMode(demodulatorType mode)
+{
+  demodulatorMode = mode;
+  if (mode == Lsb && ssbDemodulatorPtr != NULL) ssbDemodulatorPtr->setLsbDemodulationMode();
+  if (mode == Usb && ssbDemodulatorPtr != NULL) ssbDemodulatorPtr->setUsbDemodulationMode();
+  if (handle != NULL)
+  {
+    int rc = hrfd_rx_set_mode(handle, 0, (int)mode);
+    if (rc != HRFD_OK) fatal("hrfd_rx_set_mode", rc);
+  }
+}
+
+void IqDataProcessor::setAmDemodulator(AmDemodulator *demodulatorPtr) { amDemodulatorPtr = demodulatorPtr; }
+void IqDataProcessor::setFmDemodulator(FmDemodulator *demodulatorPtr) { fmDemodulatorPtr = demodulatorPtr; }
+void IqDataProcessor::setWbFmDemodulator(WbFmDemodulator *demodulatorPtr) { wbFmDemodulatorPtr = demodulatorPtr; }
+void IqDataProcessor::setSsbDemodulator(SsbDemodulator *demodulatorPtr) { ssbDemodulatorPtr = demodulatorPtr; }
+
+void IqDataProcessor::setSignalDetectThreshold(int32_t threshold)
+{
+  signalDetectThreshold = threshold;
+  if (handle != NULL)
+  {
+    int rc = hrfd_rx_set_threshold(handle, 0, threshold);
+    if (rc != HRFD_OK) fatal("hrfd_rx_set_threshold", rc);
+  }
+}
+
+void IqDataProcessor::acceptIqData(unsigned long timeStamp,
+                                   int8_t *bufferPtr,
+                                   unsigned long byteCount)
+{
+  uint32_t sampleCount = 0, signalMagnitude = 0;
+  uint8_t signalAllowed = 0;
+  (void)timeStamp;
+
+  ensureHandle();
+  pushGains();
+  // reduceSampleRate + upconvertByFsOver4 + Squelch::run + demodulator, one launch
+  int rc = hrfd_rx_process_block(handle, bufferPtr, (uint32_t)byteCount, 1,
+                                 radio_adjustableReceiveGainInDb, pcmData, &sampleCount,
+                                 &signalMagnitude, &signalAllowed,
+                                 iqDumpEnabled ? decimatedData : NULL);
+  if (rc != HRFD_OK) fatal("hrfd_rx_process_block", rc);
+
+  // same order as the reference (IqDataProcessor.cc:953-1034)
+  if (iqDumpEnabled && iqDumpSinkPtr != NULL)
+  {
+    iqDumpSinkPtr(decimatedData, (uint32_t)(byteCount / 8), iqDumpContextPtr);
+  }
+  if (signalNotificationEnabled && signalCallbackPtr != NULL)
+  {
+    signalCallbackPtr(signalAllowed != 0, signalCallbackContextPtr);
+  }
+  if (signalMagnitudeNotificationEnabled && signalMagnitudeCallbackPtr != NULL)
+  {
+    signalMagnitudeCallbackPtr(signalMagnitude, signalMagnitudeCallbackContextPtr);
+  }
+  if (signalAllowed && sampleCount > 0)
+  {
+    hrfd_shim::DemodulatorBase *d = NULL;
+    switch (demodulatorMode)
+    {
+      case Am: d = amDemodulatorPtr; break;
+      case Fm: d = fmDemodulatorPtr; break;
+      case WbFm: d = wbFmDemodulatorPtr; break;
+      case Lsb:
+      case Usb: d = ssbDemodulatorPtr; break;
+      default: break;
+    }
+    if (d != NULL)
+    {
+      d->deliverPcm(pcmData, sampleCount);
+    }
+  }
+}
+
+// Public in the reference but only meaningful through acceptIqData (decimatedData is
+// private there too): advances the decimators by running the front end alone.
+uint32_t IqDataProcessor::reduceSampleRate(int8_t *bufferPtr,uint32_t bufferLength)
+{
+  uint32_t sampleCount = 0;
+  ensureHandle();
+  int rc = hrfd_rx_set_mode(handle, 0, HRFD_MODE_NONE);
+  if (rc == HRFD_OK)
+  {
+    rc = hrfd_rx_process_block(handle, bufferPtr, bufferLength, 1, radio_adjustableReceiveGainInDb,
+                               pcmData, &sampleCount, NULL, NULL, decimatedData);
+  }
+  if (rc != HRFD_OK) fatal("reduceSampleRate", rc);
+  rc = hrfd_rx_set_mode(handle, 0, (int)demodulatorMode);
+  if (rc != HRFD_OK) fatal("hrfd_rx_set_mode", rc);
+  return bufferLength / 8;
+}
+
+// Stand-alone helpers of the reference (IqDataProcessor.cc:700-744, :771-815): a period-4
+// rotation of a caller-owned 256 kS/s buffer.  Not on the per-block path (the fused
+// kernel does its own rotation); stated here directly so that the symbol exists.
+void IqDataProcessor::upconvertByFsOver4(int8_t *bufferPtr,uint32_t byteCount)
+{
+  for (uint32_t i = 0; i < byteCount; i += 8)
+  {
+    int8_t x = bufferPtr[i + 2], y = bufferPtr[i + 3];
+    bufferPtr[i + 2] = (int8_t)-y; bufferPtr[i + 3] = x;
+    x = bufferPtr[i + 4]; y = bufferPtr[i + 5];
+    bufferPtr[i + 4] = (int8_t)-x; bufferPtr[i + 5] = (int8_t)-y;
+    x = bufferPtr[i + 6]; y = bufferPtr[i + 7];
+    bufferPtr[i + 6] = y; bufferPtr[i + 7] = (int8_t)-x;
+  }
+}
+
+void IqDataProcessor::downconvertByFsOver4(int8_t *bufferPtr,uint32_t byteCount)
+{
+  for (uint32_t i = 0; i < byteCount; i += 8)
+  {
+    int8_t x = bufferPtr[i + 2], y = bufferPtr[i + 3];
+    bufferPtr[i + 2] = y; bufferPtr[i + 3] = (int8_t)-x;
+    x = bufferPtr[i + 4]; y = bufferPtr[i + 5];
+    bufferPtr[i + 4] = (int8_t)-x; bufferPtr[i + 5] = (int8_t)-y;
+    x = bufferPtr[i + 6]; y = bufferPtr[i + 7];
+    bufferPtr[i + 6] = (int8_t)-y; bufferPtr[i + 7] = x;
+  }
+}
+
+void IqDataProcessor::enableSignalNotification(void) { signalNotificationEnabled = true; }
+void IqDataProcessor::disableSignalNotification(void) { signalNotificationEnabled = false; }
+void IqDataProcessor::registerSignalStateCallback(
+    void (*signalCallbackPtr)(bool signalPresent,void *contextPtr), void *contextPtr)
+{
+  this->signalCallbackContextPtr = contextPtr;
+  this->signalCallbackPtr = signalCallbackPtr;
+}
+void IqDataProcessor::enableSignalMagnitudeNotification(void) { signalMagnitudeNotificationEnabled = true; }
+void IqDataProcessor::disableSignalMagnitudeNotification(void) { signalMagnitudeNotificationEnabled = false; }
+void IqDataProcessor::registerSignalMagnitudeCallback(
+    void (*callbackPtr)(uint32_t signalMagnitude,void *contextPtr), void *contextPtr)
+{
+  this->signalMagnitudeCallbackContextPtr = contextPtr;
+  this->signalMagnitudeCallbackPtr = callbackPtr;
+}
+void IqDataProcessor::enableIqDump(void) { iqDumpEnabled = true; }
+void IqDataProcessor::disableIqDump(void) { iqDumpEnabled = false; }
+bool IqDataProcessor::isIqDumpEnabled(void) { return iqDumpEnabled; }
+void IqDataProcessor::registerIqDumpSink(
+    void (*sinkPtr)(int8_t *bufferPtr,uint32_t byteCount,void *contextPtr), void *contextPtr)
+{
+  iqDumpSinkPtr = sinkPtr;
+  iqDumpContextPtr = contextPtr;
+}
+
+void IqDataProcessor::displayInternalInformation(void)
+{
+  static const char *names[] = {"None", "AM", "FM", "WBFM", "LSB", "USB"};
+  nprintf(stderr, "\n--------------------------------------------\n");
+  nprintf(stderr, "IqDataProcessor Internal Information (libhrfd, MI355X)\n");
+  nprintf(stderr, "--------------------------------------------\n");
+  nprintf(stderr, "Demodulator Mode         : %s\n", names[(int)demodulatorMode]);
+  nprintf(stderr, "Signal Detect Threshold  : %d dBFs\n", signalDetectThreshold);
+  nprintf(stderr, "IQ Dump                  : %s\n", iqDumpEnabled ? "Enabled" : "Disabled");
+}
+
+// ---------------------------------------------------------------- SsbModulator
+SsbModulator::SsbModulator(void)
+{
+  lsbModulationMode = true;
+  handle = NULL;
+}
+
+SsbModulator::~SsbModulator(void)
+{
+  if (handle != NULL)
+  {
+    hrfd_mod_destroy(handle);
+  }
+}
+
+void SsbModulator::resetModulator(void)
+{
+  if (handle != NULL)
+  {
+    int rc = hrfd_mod_reset(handle, 0);
+    if (rc != HRFD_OK) fatal("hrfd_mod_reset", rc);
+  }
+}
+
+void SsbModulator::setLsbModulationMode(void)
+{
+  lsbModulationMode = true;
+  if (handle != NULL) hrfd_mod_set_sideband(handle, 0, 1);
+}
+
+void SsbModulator::setUsbModulationMode(void)
+{
+  lsbModulationMode = false;
+  if (handle != NULL) hrfd_mod_set_sideband(handle, 0, 0);
+}
+
+void SsbModulator::acceptData(int16_t *bufferPtr,
+                              uint32_t bufferLength,
+                              int8_t *outputBufferPtr,
+                              uint32_t *outputBufferLengthPtr)
+{
+  int rc;
+  if (handle == NULL)
+  {
+    rc = hrfd_mod_create(HRFD_MOD_SSB, 1, -1, &handle);
+    if (rc != HRFD_OK) fatal("hrfd_mod_create", rc);
+    hrfd_mod_set_sideband(handle, 0, lsbModulationMode ? 1 : 0);
+  }
+  rc = hrfd_mod_process(handle, bufferPtr, bufferLength, outputBufferPtr, outputBufferLengthPtr);
+  if (rc != HRFD_OK) fatal("hrfd_mod_process", rc);
+}
+
+void SsbModulator::displayInternalInformation(void)
+{
+  nprintf(stderr, "\n--------------------------------------------\n");
+  nprintf(stderr, "SSB Modulator Internal Information (libhrfd, MI355X)\n");
+  nprintf(stderr, "--------------------------------------------\n");
+  nprintf(stderr, "Modulation Mode          : %s\n", lsbModulationMode ? "LSB" : "USB");
+}
+
+// ---------------------------------------------------------------- Nco
+Nco::Nco(float sampleRate,float frequency)
+{
+  this->sampleRate = sampleRate;
+  this->frequency = frequency;
+  handle = NULL;
+  int rc = hrfd_nco_create(1, sampleRate, frequency, -1, &handle);
+  if (rc != HRFD_OK) fatal("hrfd_nco_create", rc);
+}
+
+Nco::~Nco(void)
+{
+  if (handle != NULL)
+  {
+    hrfd_nco_destroy(handle);
+  }
+}
+
+void Nco::setFrequency(float frequency)
+{
+  this->frequency = frequency;
+  int rc = hrfd_nco_set_frequency(handle, 0, frequency);
+  if (rc != HRFD_OK) fatal("hrfd_nco_set_frequency", rc);
+}
+
+void Nco::reset(void)
+{
+  int rc = hrfd_nco_reset(handle, 0);
+  if (rc != HRFD_OK) fatal("hrfd_nco_reset", rc);
+}
+
+void Nco::run(float *iValuePtr,float *qValuePtr)
+{
+  int rc = hrfd_nco_run(handle, 0, 1, iValuePtr, qValuePtr);
+  if (rc != HRFD_OK) fatal("hrfd_nco_run", rc);
+}
+
+void Nco::runFast(float *iValuePtr,float *qValuePtr)
+{
+  int rc = hrfd_nco_run(handle, 1, 1, iValuePtr, qValuePtr);
+  if (rc != HRFD_OK) fatal("hrfd_nco_run", rc);
+}

@@ -1,0 +1,91 @@
+// tests/cpp/shim_demo.cc -- a miniature of the reference application's receive wiring
+// (radioApp.cc:103-111,238-242; Radio.cc:164-203; DataConsumer.cc:341) on top of the
+// drop-in shim classes: blocks of int8 IQ on stdin -> PCM on stdout, driven through
+//   IqDataProcessor::acceptIqData            (outer boundary, argv[2] == "outer")
+//   XDemodulator::acceptIqData on 256 kS/s   (inner boundary, argv[2] == "inner")
+// usage: shim_demo <mode 1..5> <outer|inner> <block_bytes>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <vector>
+
+#include "IqDataProcessor.h"
+#include "SsbModulator.h"
+
+uint32_t radio_adjustableReceiveGainInDb = 0;          // Radio.cc:15
+void nprintf(FILE *s, const char *formatPtr, ...)      // diagUi.cc:2881
+{
+  va_list ap;
+  va_start(ap, formatPtr);
+  vfprintf(s, formatPtr, ap);
+  va_end(ap);
+}
+
+static void processPcmData(int16_t *bufferPtr, uint32_t bufferLength)   // radioApp.cc:103
+{
+  fwrite(bufferPtr, sizeof(int16_t), bufferLength, stdout);
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 4)
+  {
+    fprintf(stderr, "usage: %s <mode> <outer|inner|ssbmod> <block_bytes>\n", argv[0]);
+    return 2;
+  }
+  const int mode = atoi(argv[1]);
+  const bool outer = strcmp(argv[2], "outer") == 0;
+  const size_t blockBytes = (size_t)atoi(argv[3]);
+  std::vector<int8_t> buf(blockBytes);
+
+  if (strcmp(argv[2], "ssbmod") == 0)
+  {
+    // transmit: 512 PCM samples per call -> 262144 bytes of IQ (BasebandDataProcessor.cc:682)
+    SsbModulator mod;
+    if (mode == 5) mod.setUsbModulationMode();
+    std::vector<int16_t> pcm(512);
+    std::vector<int8_t> iq(262144);
+    while (fread(pcm.data(), 2, 512, stdin) == 512)
+    {
+      uint32_t outBytes = 0;
+      mod.acceptData(pcm.data(), 512, iq.data(), &outBytes);
+      fwrite(iq.data(), 1, outBytes, stdout);
+    }
+    return 0;
+  }
+
+  static char ip[] = "127.0.0.1";
+  IqDataProcessor proc(ip, 8001);
+  AmDemodulator am(processPcmData);
+  FmDemodulator fm(processPcmData);
+  WbFmDemodulator wbfm(processPcmData);
+  SsbDemodulator ssb(processPcmData);
+  proc.setAmDemodulator(&am);
+  proc.setFmDemodulator(&fm);
+  proc.setWbFmDemodulator(&wbfm);
+  proc.setSsbDemodulator(&ssb);
+  proc.setDemodulatorMode((IqDataProcessor::demodulatorType)mode);
+
+  unsigned long timeStamp = 0;
+  while (fread(buf.data(), 1, blockBytes, stdin) == blockBytes)
+  {
+    if (outer)
+    {
+      proc.acceptIqData(timeStamp++, buf.data(), blockBytes);
+    }
+    else
+    {
+      switch (mode)
+      {
+        case 1: am.acceptIqData(buf.data(), (uint32_t)blockBytes); break;
+        case 2: fm.acceptIqData(buf.data(), (uint32_t)blockBytes); break;
+        case 3: wbfm.acceptIqData(buf.data(), (uint32_t)blockBytes); break;
+        default: ssb.acceptIqData(buf.data(), (uint32_t)blockBytes); break;
+      }
+    }
+  }
+  proc.displayInternalInformation();
+  return 0;
+}
