@@ -116,6 +116,65 @@ def cpu_baseline(seconds, threads):
     }
 
 
+def bench_ssbmod(args, api, device, rank, world, dist):
+    """BASELINE config 5: `channels` SSB modulators, 512 PCM samples (64 ms) per block,
+    `blocks` blocks per step -> int8 IQ at 2.048 MS/s.  Unit of work: one output IQ sample."""
+    from hackrfdiags_amd import shard
+    C, B = args.channels, args.blocks
+    n = 512 * B
+    gen = torch.Generator(device=device)
+    gen.manual_seed(7 + rank)
+    pcm = torch.randint(-32768, 32768, (C, n), dtype=torch.int16, device=device, generator=gen)
+    out = torch.empty((C, 512 * n), dtype=torch.int8, device=device)
+    m = api.Mod(api.MOD_SSB, C, device=device.index)
+    stream = torch.cuda.Stream(device=device)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record(stream)
+        m.process_device(pcm.data_ptr(), n, out.data_ptr(), stream=stream.cuda_stream)
+        if i is not None:
+            ev[i][1].record(stream)
+
+    for _ in range(args.warmup):
+        step()
+    m.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    stream.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device)
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    samples = C * n * 256
+    value = world * samples * args.steps / elapsed / 1e6
+    algo_bytes = C * n * (2 + 512)
+    mean_ms = float(np.mean(kernel_ms))
+    achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
+    if rank == 0:
+        print(json.dumps({
+            "metric": "IQ MSamples/s modulated (8 kS/s PCM -> 2.048 MS/s int8 IQ, SSB) per GPU; % HBM roofline",
+            "value": round(value, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int16 PCM -> Q15 int32 -> int8 IQ", "data": "synthetic",
+            "config": {"workload": f"{C} SSB modulator channels per GPU (BASELINE config 5), {B} blocks of 512 PCM "
+                                   f"samples per step, 8-stage x256 half-band interpolator", "channels_per_gpu": C,
+                       "blocks_per_step": B},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "hrfd::k_mod<1>",
+                         "kernel_ms_mean": round(mean_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
+        }), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +183,11 @@ def main():
     ap.add_argument("--channels", type=int, default=256, help="channels per GPU (BASELINE config 2)")
     ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
     ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")
+    ap.add_argument("--workload", choices=["wbfm", "mixed", "ssbmod"], default="wbfm",
+                    help="wbfm = BASELINE config 2 (the headline); mixed = config 3 (AM+FM+WBFM+SSB bank, "
+                         "per-mode dispatch); ssbmod = config 5 (SSB modulator, 8-stage x256 interpolator)")
+    ap.add_argument("--scatter", action="store_true",
+                    help="N > 1 only: all IQ starts on rank 0 and is scattered over RCCL inside the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -140,7 +204,10 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
 
-    from hackrfdiags_amd import api
+    from hackrfdiags_amd import api, shard
+
+    if args.workload == "ssbmod":
+        return bench_ssbmod(args, api, device, rank, world, dist)
 
     C, B = args.channels, args.blocks
     gen = make_fm_batch if args.signal == "fmtone" else make_random_batch
@@ -149,10 +216,21 @@ def main():
     n_pcm = torch.zeros((C, B), dtype=torch.int32, device=device)
     rx = api.Rx(C, device=local_rank)
     rx.set_mode(api.WBFM)
+    if args.workload == "mixed":
+        # BASELINE config 3: equal quarters of AM, FM, WBFM and SSB channels
+        for c in range(C):
+            rx.set_mode([api.AM, api.FM, api.WBFM, api.LSB][(4 * c) // C], channel=c)
     stream = torch.cuda.Stream(device=device)
+    iq_root = None
+    if args.scatter and world > 1:
+        # the north star's "per-channel scatter": every rank's IQ starts on rank 0
+        iq_root = torch.cat([iq] * world, dim=0) if rank == 0 else None
     rx.debug_enable_timing(max(args.steps, 1))
 
     def step():
+        if iq_root is not None or (args.scatter and world > 1):
+            with torch.cuda.stream(stream):
+                iq.copy_(shard.scatter_iq(iq_root, world * C, B, BLOCK, device))
         rx.process_device(iq.data_ptr(), B * BLOCK, BLOCK, B, pcm.data_ptr(), d_n_pcm=n_pcm.data_ptr(),
                           stream=stream.cuda_stream)
 
@@ -173,10 +251,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, device)
 
     rx.sync()
     counters = rx.debug_counters()
@@ -205,8 +280,12 @@ def main():
             "dtype": "int8 IQ -> Q15 int16/int32 + f32 recurrence -> int16 PCM",
             "data": "synthetic",
             "config": {
-                "workload": f"{C} concurrent WBFM channels per GPU at 2.048 MS/s (BASELINE config 2), "
-                            f"{B} blocks of 262144 B per channel per step, input resident in HBM",
+                "workload": (f"{C} concurrent WBFM channels per GPU at 2.048 MS/s (BASELINE config 2), "
+                             if args.workload == "wbfm" else
+                             f"mixed-mode bank {C // 4} AM + {C // 4} FM + {C // 4} WBFM + {C // 4} SSB per GPU "
+                             f"(BASELINE config 3), ") +
+                            f"{B} blocks of 262144 B per channel per step, input resident in HBM"
+                            + (", IQ scattered from rank 0 over RCCL each step" if args.scatter and world > 1 else ""),
                 "channels_per_gpu": C, "blocks_per_step": B, "signal": args.signal,
                 "parallelism": f"channels sharded, {world} rank(s), no data-path collective",
             },
@@ -219,7 +298,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None,
-                "kernel": "hrfd::k_rx_wbfm<3>",
+                "kernel": "hrfd::k_rx_wbfm<3>" if args.workload == "wbfm" else "all demodulator kernels of a step",
                 "kernel_ms_mean": round(mean_ms, 4),
                 "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "algorithmic_bytes_per_launch": algo_bytes,

@@ -749,10 +749,9 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   E.chk_pub = h->d_chk_pub;
   E.chk_spec = h->d_chk_spec;
   E.counters = h->d_counters;
-  const uint32_t eg = (h->n_channels + 255u) / 256u;
-  hipLaunchKernelGGL(k_rx_epilogue, dim3(eg), dim3(256), 0, s, E);
+  hipLaunchKernelGGL(k_rx_epilogue, dim3(h->n_channels), dim3(64), 0, s, E);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_rx_commit, dim3(eg), dim3(256), 0, s, E);
+  hipLaunchKernelGGL(k_rx_commit, dim3(h->n_channels), dim3(64), 0, s, E);
   HIP_TRY(hipGetLastError());
   h->last_stream = s;
   return HRFD_OK;

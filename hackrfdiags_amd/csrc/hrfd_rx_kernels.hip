@@ -1060,62 +1060,74 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 
 // =============================================================================
 //  epilogue: squelch tracker over the batch, verification of both speculations,
-//  n_pcm / allowed outputs.  One thread per channel.
+//  n_pcm / allowed outputs.  One wave per channel, one lane per block.
 // =============================================================================
-__global__ void k_rx_epilogue(const EpilogueParams E)
+__global__ __launch_bounds__(64) void k_rx_epilogue(const EpilogueParams E)
 {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.x;
+  const int lane = threadIdx.x;
   if (c >= E.n_channels)
   {
     return;
   }
   const int mode = E.cfg[c].mode;
-  bool prev = E.state[c].tracking != 0;
+  uint32_t carry = E.state[c].tracking != 0 ? 1u : 0u;    // `present` of the block before
   uint32_t gate_viol = 0, spec_viol = 0;
-  for (uint32_t b = 0; b < E.n_blocks; b++)
+  for (uint32_t b0 = 0; b0 < E.n_blocks; b0 += 64)
   {
+    const uint32_t b = b0 + lane;
+    const bool in = b < E.n_blocks;
     const size_t unit = (size_t)c * E.n_blocks + b;
     const size_t ounit = (size_t)c * E.out_blocks + E.out_b0 + b;
-    const bool present = E.present[unit] != 0;
-    const bool allowed = present || prev;                 // Squelch.cc:227-273
-    prev = present;                                       // SignalTracker.cc:104-146
-    const bool demod = allowed && mode != 0;
-    if (E.allowed != nullptr)
+    const uint32_t present = in ? (uint32_t)(E.present[unit] != 0) : 0u;
+    const uint32_t prev = shr1(present, carry);           // lane 0 <- carried
+    const bool allowed = (present | prev) != 0;           // Squelch.cc:227-273, SignalTracker.cc:104-146
+    if (in)
     {
-      E.allowed[ounit] = allowed ? 1 : 0;
-    }
-    if (E.n_pcm != nullptr)
-    {
-      E.n_pcm[ounit] = demod ? E.n_pcm_per_block : 0u;
-    }
-    if (E.n_blocks > 1 && mode != 0 && !allowed)
-    {
-      gate_viol++;                                        // the batch assumed every gate open
-    }
-    if (b > 0 && mode == 3)
-    {
-      if (!same_trajectory(E.chk_spec[unit], E.chk_pub[unit - 1]))
+      const bool demod = allowed && mode != 0;
+      if (E.allowed != nullptr)
       {
-        spec_viol++;
+        E.allowed[ounit] = allowed ? 1 : 0;
+      }
+      if (E.n_pcm != nullptr)
+      {
+        E.n_pcm[ounit] = demod ? E.n_pcm_per_block : 0u;
+      }
+      // the batch assumed every gate open
+      gate_viol += (E.n_blocks > 1 && mode != 0 && !allowed) ? 1u : 0u;
+      if (b > 0 && mode == 3)
+      {
+        spec_viol += same_trajectory(E.chk_spec[unit], E.chk_pub[unit - 1]) ? 0u : 1u;
       }
     }
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)present, 63);
   }
-  if (gate_viol)
+  for (int off = 32; off > 0; off >>= 1)
   {
-    atomicAdd(&E.counters[kCntGate], gate_viol);
+    gate_viol += __shfl_down(gate_viol, off);
+    spec_viol += __shfl_down(spec_viol, off);
   }
-  if (spec_viol)
+  if (lane == 0)
   {
-    atomicAdd(&E.counters[kCntSpec], spec_viol);
+    if (gate_viol)
+    {
+      atomicAdd(&E.counters[kCntGate], gate_viol);
+    }
+    if (spec_viol)
+    {
+      atomicAdd(&E.counters[kCntSpec], spec_viol);
+    }
   }
 }
 
-// commit the pending per-channel state when the whole call verified clean
-__global__ void k_rx_commit(const EpilogueParams E)
+// commit the pending per-channel state when the whole call verified clean.
+// One wave per channel; the lanes copy the mode's section in parallel.
+__global__ __launch_bounds__(64) void k_rx_commit(const EpilogueParams E)
 {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = blockIdx.x;
+  const int lane = threadIdx.x;
   const bool clean = (E.counters[kCntGate] | E.counters[kCntSpec]) == 0u;
-  if (c == 0)
+  if (c == 0 && lane == 0)
   {
     E.counters[kCntCommit] = clean ? 1u : 0u;
     E.counters[kCntTotRepair] += E.counters[kCntRepair];
@@ -1130,54 +1142,46 @@ __global__ void k_rx_commit(const EpilogueParams E)
   const ChanState *src = E.state_out + c;
   const int mode = E.cfg[c].mode;
   // tracker over the batch; was the last block demodulated?
-  bool prev = dst->tracking != 0;
-  bool allowed = false;
-  for (uint32_t b = 0; b < E.n_blocks; b++)
-  {
-    const bool present = E.present[(size_t)c * E.n_blocks + b] != 0;
-    allowed = present || prev;
-    prev = present;
-  }
-  dst->tracking = prev ? 1u : 0u;
-  for (int i = 0; i < 16; i++)
-  {
-    dst->fe_tail[i] = src->fe_tail[i];
-  }
-  if (!allowed)
-  {
-    return;                                              // demodulator state frozen
-  }
-  if (mode == 3)
-  {
-    dst->wb_theta = src->wb_theta;
-    dst->wb_p = src->wb_p;
-    dst->wb_y = src->wb_y;
-    for (int i = 0; i < kWbS; i++) dst->wb_s[i] = src->wb_s[i];
-    for (int i = 0; i < kWbU; i++) dst->wb_u[i] = src->wb_u[i];
-    for (int i = 0; i < kWbV; i++) dst->wb_v[i] = src->wb_v[i];
-  }
-  else if (mode == 2)
-  {
-    for (int i = 0; i < 2 * kFmTail; i++) dst->fm_tail[i] = src->fm_tail[i];
-    for (int i = 0; i < kWbU; i++) dst->fm_u[i] = src->fm_u[i];
-    for (int i = 0; i < kWbV; i++) dst->fm_v[i] = src->fm_v[i];
-  }
-  else if (mode == 1)
-  {
-    for (int i = 0; i < 2 * kAmTail; i++) dst->am_tail[i] = src->am_tail[i];
-    dst->am_x1 = src->am_x1;
-    dst->am_y1 = src->am_y1;
-  }
-  else if (mode == 4 || mode == 5)
-  {
-    for (int i = 0; i < 2 * kAmTail; i++) dst->ssb_tail[i] = src->ssb_tail[i];
-    dst->ssb_x1 = src->ssb_x1;
-    dst->ssb_y1 = src->ssb_y1;
-    for (int i = 0; i < kSsbHist; i++)
+  const uint32_t nb = E.n_blocks;
+  const bool p_last = E.present[(size_t)c * nb + nb - 1] != 0;
+  const bool p_prev = (nb >= 2) ? (E.present[(size_t)c * nb + nb - 2] != 0) : (dst->tracking != 0);
+  const bool allowed = p_last || p_prev;
+  auto copy = [&](void *d, const void *s, int bytes) {    // sections are 2-byte aligned
+    uint16_t *dd = reinterpret_cast<uint16_t *>(d);
+    const uint16_t *ss = reinterpret_cast<const uint16_t *>(s);
+    for (int i = lane; i < bytes / 2; i += 64)
     {
-      dst->ssb_i[i] = src->ssb_i[i];
-      dst->ssb_q[i] = src->ssb_q[i];
+      dd[i] = ss[i];
     }
+  };
+  copy(dst->fe_tail, src->fe_tail, 16);
+  if (allowed)                                            // else: demodulator state frozen
+  {
+    if (mode == 3)
+    {
+      copy(&dst->wb_theta, &src->wb_theta, 3 * (int)sizeof(float));
+      copy(dst->wb_s, src->wb_s, (int)(sizeof(dst->wb_s) + sizeof(dst->wb_u) + sizeof(dst->wb_v)));
+    }
+    else if (mode == 2)
+    {
+      copy(dst->fm_tail, src->fm_tail, (int)(sizeof(dst->fm_tail) + sizeof(dst->fm_u) + sizeof(dst->fm_v)));
+    }
+    else if (mode == 1)
+    {
+      copy(dst->am_tail, src->am_tail, (int)sizeof(dst->am_tail));
+      copy(&dst->am_x1, &src->am_x1, 2 * (int)sizeof(float));
+    }
+    else if (mode == 4 || mode == 5)
+    {
+      copy(dst->ssb_tail, src->ssb_tail, (int)sizeof(dst->ssb_tail));
+      copy(&dst->ssb_x1, &src->ssb_x1, 2 * (int)sizeof(float));
+      copy(dst->ssb_i, src->ssb_i, (int)(sizeof(dst->ssb_i) + sizeof(dst->ssb_q)));
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);                          // all lanes read `tracking` above
+  if (lane == 0)
+  {
+    dst->tracking = p_last ? 1u : 0u;
   }
 }
 
