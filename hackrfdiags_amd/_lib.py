@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libhrfd.so")
+# HRFD_LIB selects another build of the same library (tools/gpu_ab.py compares tuning variants)
+LIB_PATH = os.environ.get("HRFD_LIB") or os.path.join(PKG_DIR, "lib", "libhrfd.so")
 
 _i16p = C.POINTER(C.c_int16)
 _u32p = C.POINTER(C.c_uint32)
@@ -82,6 +83,8 @@ def load() -> C.CDLL:
                                          _vp, _vp, _vp, _vp, _vp, _vp]
     L.hrfd_rx_sync.argtypes = [_vp, _u32p]
     L.hrfd_rx_debug_set_warm.argtypes = [_vp, C.c_int]
+    L.hrfd_rx_debug_set_atan.argtypes = [_vp, C.c_int]
+    L.hrfd_rx_debug_atan_eval.argtypes = [_vp, _f32p]
     L.hrfd_rx_debug_counters.argtypes = [_vp, _u32p]
     L.hrfd_rx_debug_set_stagger.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_stamps.argtypes = [_vp, C.c_uint32, _vp]

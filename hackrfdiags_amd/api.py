@@ -83,6 +83,16 @@ class Rx:
         return int(v.value)
 
     # test hooks
+    def debug_set_atan(self, mode: int):
+        """-1 automatic, 0 force the atan2 table gather, 1 require the arithmetic atan2 kernel."""
+        check(self.L.hrfd_rx_debug_set_atan(self.h, int(mode)), "hrfd_rx_debug_set_atan")
+
+    def debug_atan_eval(self):
+        """The arithmetic atan2 of the WBFM kernel over all (q, i): float32 [256][256]."""
+        out = np.zeros((256, 256), dtype=np.float32)
+        check(self.L.hrfd_rx_debug_atan_eval(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "hrfd_rx_debug_atan_eval")
+        return out
+
     def debug_set_warm(self, warm: int):
         check(self.L.hrfd_rx_debug_set_warm(self.h, warm), "hrfd_rx_debug_set_warm")
 

@@ -18,8 +18,10 @@
 #include "hrfd_tables.h"
 
 namespace hrfd {
-template <int MODE> __global__ void k_rx_wbfm(const RxParams);
-template <int MODE> __global__ void k_rx_fir(const RxParams);
+template <int MODE, bool S256, bool ARITH> __global__ void k_rx_wbfm(const RxParams);
+__global__ void k_build_atan_corr(const float *, const float *, uint8_t *, uint32_t *);
+__global__ void k_atan_eval(const uint8_t *, const float *, float *);
+template <int MODE, bool S256> __global__ void k_rx_fir(const RxParams);
 template <int MODE> __global__ void k_rx_post(const RxParams);
 __global__ void k_rx_epilogue(const EpilogueParams);
 __global__ void k_rx_commit(const EpilogueParams);
@@ -149,6 +151,10 @@ struct hrfd_rx
   ChanState *d_state = nullptr;
   ChanState *d_state_out = nullptr;
   float *d_lut = nullptr;
+  uint8_t *d_atcorr = nullptr;         // arithmetic atan2 (theta_arith): correction bytes, 1/a
+  float *d_atinv = nullptr;
+  bool arith_ok = false;               // corrections fit: k_rx_wbfm computes theta instead of gathering it
+  int atan_mode = -1;                  // test hook: -1 auto, 0 force the table gather, 1 require arithmetic
   int32_t *d_dbfs = nullptr;
   uint32_t *d_counters = nullptr;
   uint32_t *d_lists = nullptr;         // [6][n_channels] channel ids grouped by mode
@@ -195,7 +201,7 @@ static int rx_free(hrfd_rx *h)
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_dbfs, h->d_counters,
+  void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_dbfs, h->d_counters,
                   h->d_lists, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
                   h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq};
   for (void *p : ptrs)
@@ -260,6 +266,8 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && alloc((void **)&h->d_state, sizeof(ChanState) * n_channels);
   ok = ok && alloc((void **)&h->d_state_out, sizeof(ChanState) * n_channels);
   ok = ok && alloc((void **)&h->d_lut, sizeof(float) * 65536);
+  ok = ok && alloc((void **)&h->d_atcorr, kCorrBytes);
+  ok = ok && alloc((void **)&h->d_atinv, sizeof(float) * kInvEntries);
   ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
   ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * kNumCounters);
   ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 6 * n_channels);
@@ -290,13 +298,73 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   if (e == hipSuccess) e = hipMemcpy(h->d_lut, lut.data(), sizeof(float) * 65536, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_dbfs, dbfs, sizeof(dbfs), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(h->d_counters, 0, sizeof(uint32_t) * kNumCounters);
+  // arithmetic atan2: reciprocals from the host (correctly rounded), correction bytes derived on
+  // the device from the table just uploaded, with the kernel's own arithmetic (k_build_atan_corr)
+  float inv[kInvEntries];
+  memset(inv, 0, sizeof(inv));
+  for (int a = 1; a <= 128; a++)
+  {
+    inv[a] = 1.0f / (float)a;
+  }
+  uint32_t bad = 0;
+  if (e == hipSuccess) e = hipMemcpy(h->d_atinv, inv, sizeof(inv), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+  {
+    hipLaunchKernelGGL(k_build_atan_corr, dim3((kCorrBytes + 255) / 256), dim3(256), 0, 0, h->d_lut, h->d_atinv,
+                       h->d_atcorr, h->d_counters + kCntScratch);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(&bad, h->d_counters + kCntScratch, sizeof(bad), hipMemcpyDeviceToHost);
   if (e != hipSuccess)
   {
     rc = fail(HRFD_ENODEV, "hrfd_rx_create: initial upload failed: %s", hipGetErrorString(e));
     rx_free(h);
     return rc;
   }
+  h->arith_ok = (bad == 0);
   *out = h;
+  return HRFD_OK;
+}
+
+// test hook: the arithmetic atan2 evaluated on the device for all 65536 (q, i) pairs, in the
+// layout of hrfd_atan2_table(); must equal that table bit for bit when the corrections fit
+extern "C" int hrfd_rx_debug_atan_eval(hrfd_rx *h, float *out65536)
+{
+  if (h == nullptr || out65536 == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_atan_eval: NULL");
+  }
+  if (!h->arith_ok)
+  {
+    return fail(HRFD_ESTATE, "hrfd_rx_debug_atan_eval: the atan2 corrections do not fit 2 bits on this device");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  float *d = nullptr;
+  HIP_TRY(hipMalloc((void **)&d, sizeof(float) * 65536));
+  hipLaunchKernelGGL(k_atan_eval, dim3(256), dim3(256), 0, 0, h->d_atcorr, h->d_atinv, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(out65536, d, sizeof(float) * 65536, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess)
+  {
+    return fail(HRFD_ENODEV, "hrfd_rx_debug_atan_eval: %s", hipGetErrorString(e));
+  }
+  return HRFD_OK;
+}
+
+// test hook: -1 automatic (arithmetic atan2 when its corrections fit), 0 force the table gather,
+// 1 require the arithmetic kernel (fails if the corrections did not fit)
+extern "C" int hrfd_rx_debug_set_atan(hrfd_rx *h, int mode)
+{
+  if (h == nullptr || mode < -1 || mode > 1)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_set_atan: -1, 0 or 1");
+  }
+  if (mode == 1 && !h->arith_ok)
+  {
+    return fail(HRFD_ESTATE, "hrfd_rx_debug_set_atan: the atan2 corrections do not fit 2 bits on this device");
+  }
+  h->atan_mode = mode;
   return HRFD_OK;
 }
 
@@ -664,6 +732,8 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.iq256 = d_iq256;
   P.ssb_iq = h->d_ssb_iq;
   P.atan2_lut = h->d_lut;
+  P.at_corr = h->d_atcorr;
+  P.at_inv = h->d_atinv;
   P.dbfs = h->d_dbfs;
   P.chk_pub = h->d_chk_pub;
   P.chk_spec = h->d_chk_spec;
@@ -689,11 +759,22 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     P.dbg = (h->d_dbg != nullptr && (size_t)grid * 8 <= h->dbg_cap && m == HRFD_MODE_WBFM) ? h->d_dbg : nullptr;
     if (m == HRFD_MODE_NONE)
     {
-      hipLaunchKernelGGL(k_rx_wbfm<0>, dim3(grid), dim3(kThreads), 0, s, P);
+      hipLaunchKernelGGL((k_rx_wbfm<0, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     else
     {
-      hipLaunchKernelGGL(k_rx_wbfm<3>, dim3(grid), dim3(kThreads), 0, s, P);
+      if (opt.src256)
+      {
+        hipLaunchKernelGGL((k_rx_wbfm<3, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else if (h->arith_ok && h->atan_mode != 0)
+      {
+        hipLaunchKernelGGL((k_rx_wbfm<3, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_wbfm<3, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
     }
     HIP_TRY(hipGetLastError());
   }
@@ -712,16 +793,37 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
     if (m == HRFD_MODE_FM)
     {
-      hipLaunchKernelGGL(k_rx_fir<2>, dim3(grid), dim3(kThreads), 0, s, P);
+      if (opt.src256)
+      {
+        hipLaunchKernelGGL((k_rx_fir<2, true>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_fir<2, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
     }
     else if (m == HRFD_MODE_AM)
     {
-      hipLaunchKernelGGL(k_rx_fir<1>, dim3(grid), dim3(kThreads), 0, s, P);
+      if (opt.src256)
+      {
+        hipLaunchKernelGGL((k_rx_fir<1, true>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_fir<1, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
       hipLaunchKernelGGL(k_rx_post<1>, dim3(n), dim3(256), 0, s, P);
     }
     else
     {
-      hipLaunchKernelGGL(k_rx_fir<4>, dim3(grid), dim3(kThreads), 0, s, P);
+      if (opt.src256)
+      {
+        hipLaunchKernelGGL((k_rx_fir<4, true>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_fir<4, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
       hipLaunchKernelGGL(k_rx_post<4>, dim3(n), dim3(256), 0, s, P);
     }
     HIP_TRY(hipGetLastError());

@@ -20,6 +20,10 @@ constexpr int kHist = 704;                    // exact history kept in front of 
 constexpr int kMaxHal = 1600;                 // >= kWarm - origin for every block size, multiple of 64
 constexpr int kNeedHist = 644;                // first history sample the integer stages read
 constexpr int kMaxNV = kMaxN256 + kMaxHal;    // floats of the v/y stream in LDS
+// arithmetic atan2 (theta_arith in hrfd_rx_kernels.hip)
+constexpr int kTriEntries = 129 * 130 / 2;    // (a, b) with 0 <= b <= a <= 128
+constexpr int kCorrBytes = 8448;              // kTriEntries padded to 16-byte copies
+constexpr int kInvEntries = 132;              // 1/a for a = 0..128 (entry 0 is 0), padded
 
 // carried history sizes of the integer stages ("carried state")
 constexpr int kWbS = 4, kWbU = 8, kWbV = 38;  // WBFM: last N-M inputs of D(8,4), D(12,4), D(40,2)
@@ -103,6 +107,8 @@ struct RxParams
   int8_t *iq256;               // optional [C][n_blocks][2*n256]
   int16_t *ssb_iq;             // SSB scratch [C][n_blocks][2][n256/32]: 8 kS/s I and Q rails
   const float *atan2_lut;      // [256][256]
+  const uint8_t *at_corr;      // arithmetic atan2: correction bytes [kCorrBytes] and 1/a [kInvEntries]
+  const float *at_inv;
   const int32_t *dbfs;         // [257]
   float *chk_pub;              // [C][n_blocks] y at (n256 - kHist + 59) of this block
   float *chk_spec;             // [C][n_blocks] y at (-kHist + 59) as speculated by this block
@@ -135,6 +141,7 @@ constexpr int kCntSticky = 4;  // counters from here on are never reset (totals 
 constexpr int kCntTotRepair = 4;
 constexpr int kCntTotViol = 5; // launches whose state was NOT committed
 constexpr int kCntTotLaunch = 6;
+constexpr int kCntScratch = 7;  // k_build_atan_corr's violation count (hrfd_rx_create only)
 constexpr int kNumCounters = 8;
 
 } // namespace hrfd

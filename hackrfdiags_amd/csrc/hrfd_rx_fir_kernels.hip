@@ -45,7 +45,7 @@ __device__ __forceinline__ int fir_dot(const uint32_t *x, const RevTaps<N> &t, i
   return acc;
 }
 
-template <int MODE>
+template <int MODE, bool S256>
 __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
 {
   __shared__ __attribute__((aligned(16))) uint32_t lds[kFirDwords];
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
     uint32_t e[4];
     if (P.iq256 != nullptr)
     {
-      produce_stream<MODE, false, true>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<MODE, false, true, S256>(X, c0, c1, X.vstart, n256, magsum, e);
     }
     else
     {
-      produce_stream<MODE, false, false>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<MODE, false, false, S256>(X, c0, c1, X.vstart, n256, magsum, e);
     }
   }
   for (int off = 32; off > 0; off >>= 1)
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
   dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
   const bool present = dbfs >= cfg.threshold;
   // (the inner demodulator API has no squelch: X::acceptIqData always demodulates)
-  const bool allowed = P.src256 ? true : (first ? (present || st->tracking != 0) : true);
+  const bool allowed = S256 ? true : (first ? (present || st->tracking != 0) : true);
   if (tid == 0)
   {
     P.magnitude[X.ounit] = mean_mag;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
   }
   const bool last = (b + 1 == P.n_blocks);
   ChanState *so = P.state_out + c;
-  if (last && tid < 4 && !P.src256)
+  if (last && tid < 4 && !S256)
   {
     reinterpret_cast<uint32_t *>(so->fe_tail)[tid] =
         reinterpret_cast<const uint32_t *>(blk + P.block_bytes - 16)[tid];
@@ -586,9 +586,12 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
   }
 }
 
-template __global__ void k_rx_fir<1>(const RxParams);
-template __global__ void k_rx_fir<2>(const RxParams);
-template __global__ void k_rx_fir<4>(const RxParams);
+template __global__ void k_rx_fir<1, false>(const RxParams);
+template __global__ void k_rx_fir<1, true>(const RxParams);
+template __global__ void k_rx_fir<2, false>(const RxParams);
+template __global__ void k_rx_fir<2, true>(const RxParams);
+template __global__ void k_rx_fir<4, false>(const RxParams);
+template __global__ void k_rx_fir<4, true>(const RxParams);
 template __global__ void k_rx_post<1>(const RxParams);
 template __global__ void k_rx_post<4>(const RxParams);
 

@@ -30,7 +30,15 @@
 #include <stdint.h>
 
 #include "hrfd_device.h"
+#include <type_traits>
+#include <utility>
 #include "hrfd_tables.h"
+#ifdef HRFD_ABLATE
+#define HRFD_ABLATE_EARLY HRFD_ABLATE
+#else
+#define HRFD_ABLATE_EARLY 0
+#endif
+
 
 namespace hrfd {
 
@@ -188,6 +196,77 @@ __device__ __forceinline__ uint32_t magnitude(uint32_t y3)
   const s2 ad = __builtin_elementwise_max(d, nd);
   const uint32_t ai = (uint32_t)(uint16_t)ad.x, aq = (uint32_t)(uint16_t)ad.y;
   return max(ai, aq) + (min(ai, aq) >> 1);
+}
+
+// ---- arithmetic atan2 ---------------------------------------------------------
+// The reference looks theta up in a 256 x 256 float table built with libm
+// (WbFmDemodulator.cc:137-148).  A divergent table gather costs the texture
+// path ~250 cycles per wave (measured, tools/ubench/stream_gather_asm.hip),
+// which made it the bound of the whole kernel.  Instead theta is computed:
+//   a = max(|i|,|q|), b = min(|i|,|q|), r = b/a, phi = r + r^3 P(r^2)  (~1 ulp)
+//   theta0 = phi | pi/2 - phi | pi - phi | pi - (pi/2 - phi)   by octant,
+// then made bit-identical to the table with a 2-bit correction per
+// (a, b, octant class) -- 8385 bytes, resident in LDS -- and the sign of q.
+// The correction bytes are derived on the device at hrfd_rx_create() from the
+// very table they replace, with this very function (k_build_atan_corr), so the
+// result is the table's by construction; if a correction does not fit 2 bits the
+// library keeps the gather kernel.
+constexpr float kAtanC[8] = {-0.333329797f, 0.199902073f, -0.141844273f, 0.105678506f, -0.0735382065f, 0.0409709625f, -0.0150405606f, 0.00259946357f};
+constexpr float kPiF = 3.14159274f, kPi2F = 1.57079637f;
+
+// approximate theta for q >= 0, and the bit offset of its 2-bit correction
+struct AtanApprox
+{
+  float theta0;
+  uint32_t shift;
+};
+
+__device__ __forceinline__ AtanApprox atan2_approx(uint32_t a, uint32_t b, bool swap, bool negi, float inv_a)
+{
+  const float bf = (float)b, af = (float)a;
+  const float r0 = bf * inv_a;
+  const float e = __builtin_fmaf(-af, r0, bf);
+  const float r = __builtin_fmaf(e, inv_a, r0);         // b / a, correctly rounded
+  const float s = r * r;
+  float p = kAtanC[7];
+#pragma unroll
+  for (int k = 6; k >= 0; k--)
+  {
+    p = __builtin_fmaf(p, s, kAtanC[k]);
+  }
+  const float t = r * s;
+  const float phi = __builtin_fmaf(t, p, r);
+  float v = swap ? (kPi2F - phi) : phi;
+  v = negi ? (kPiF - v) : v;
+  AtanApprox o;
+  o.theta0 = v;
+  o.shift = (swap ? 2u : 0u) | (negi ? 4u : 0u);
+  return o;
+}
+
+// mixed = (q_idx << 16) | i_idx (offset binary); corr / inv are the LDS copies
+__device__ __forceinline__ float theta_arith(uint32_t mixed, const uint8_t *corr, const float *inv)
+{
+  const s2 d = as_s2(mixed) - as_s2(0x00800080u);
+  const s2 nd = as_s2(0u) - d;
+  const s2 ad = __builtin_elementwise_max(d, nd);
+  const uint32_t ai = (uint32_t)(uint16_t)ad.x, aq = (uint32_t)(uint16_t)ad.y;
+  const bool swap = aq > ai;
+  const uint32_t a = max(ai, aq), b = min(ai, aq);
+  const uint32_t tri = ((a * a + a) >> 1) + b;
+#if (HRFD_ABLATE_EARLY & 64)
+  const uint32_t code8 = 0x55u + (tri & 0u);                // TIMING EXPERIMENT ONLY: no LDS reads
+  const float inv_a = 0.0078125f;
+#else
+  const uint32_t code8 = corr[tri];
+  const float inv_a = inv[a];
+#endif
+  const bool negi = (mixed & 0x00000080u) == 0u;
+  const AtanApprox ap = atan2_approx(a, b, swap, negi, inv_a);
+  const uint32_t code = (code8 >> ap.shift) & 3u;
+  uint32_t bits = f2u(ap.theta0) + 1u - code;            // code = (approx - exact) + 1 in ulps
+  bits |= (~mixed << 8) & 0x80000000u;                   // q < 0: atan2(-q, i) = -atan2(q, i)
+  return u2f(bits);
 }
 
 // deltaTheta wrap (WbFmDemodulator.cc:417-425).  The reference compares the
@@ -449,25 +528,36 @@ struct StreamCtx
   int hal, vstart, n256;
   int lane;
   int qoff;                      // FIR modes: int16 index of the Q rail inside lds (I rail at 0)
+  const uint8_t *atc;            // arithmetic atan2: LDS copies of the correction bytes and of 1/a
+  const float *ati;
   bool first;
 };
+
+// cache policy bits of the streaming loads (bit 0 sc0, bit 1 nt, bit 4 sc1)
+#ifndef HRFD_STREAM_AUX
+#define HRFD_STREAM_AUX 0
+#endif
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // One 1 KiB chunk of raw input (64 lanes x 16 bytes) as a buffer load: the lane
 // offset is a constant VGPR, the chunk offset a scalar, so a load costs no
 // vector ALU work; reads past the end of the channel's input return zeros.
+template <bool S256>
 __device__ __forceinline__ uint4 load_chunk(const StreamCtx &X, int chunk)
 {
-  if (X.P->src256)
+  if (S256)
   {
     // inner demodulator API: the stream is already at 256 kS/s, one (I,Q) byte pair per lane
     const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 64 * chunk) * 2);
     const uint32_t w = __builtin_amdgcn_raw_buffer_load_b16(X.rsrc, X.lane * 2, soff, 0);
     return make_uint4(w, 0u, 0u, 0u);
   }
+#if (HRFD_ABLATE_EARLY & 128)
+  return make_uint4(X.lane * 0x01010101u + chunk, X.lane * 0x3010501u, chunk * 0x10101u, X.lane ^ chunk);   // TIMING EXPERIMENT ONLY: no HBM reads
+#endif
   const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 64 * chunk) * 16);
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, X.lane * 16, soff, 0);
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, X.lane * 16, soff, HRFD_STREAM_AUX);
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
@@ -499,13 +589,40 @@ __device__ __forceinline__ float numerator_p(float theta, float theta_prev, floa
 // compiler can place counted s_waitcnt vmcnt(N).  The raw load of chunk i+kDepth
 // is issued as soon as chunk i has been consumed, and the atan2 table gather of
 // chunk i is in flight while chunk i-1 is finished.
-constexpr int kDepth = 4;
+// Timing ablations (tools/gpu_ab.py) are compile-time only, -DHRFD_ABLATE=<bit mask>: as
+// run-time flags they put branches into the chunk loop and force vmcnt(0) waits.  Results
+// are wrong when the mask is non-zero.
+#ifndef HRFD_ABLATE
+#define HRFD_ABLATE 0
+#endif
+__device__ __forceinline__ constexpr bool ablate(const RxParams &, int bit) { return (HRFD_ABLATE & bit) != 0; }
 
-template <int MODE, bool REPAIR, bool DUMP>
+#ifndef HRFD_SCHED_FENCE
+#define HRFD_SCHED_FENCE 1
+#endif
+#ifndef HRFD_DEPTH
+#define HRFD_DEPTH 4
+#endif
+constexpr int kDepth = HRFD_DEPTH;     // raw chunks in flight per wave
+#ifndef HRFD_LOOK
+#define HRFD_LOOK 2
+#endif
+constexpr int kLook = HRFD_LOOK;    // chunks between issuing a table gather and using its result (< kDepth)
+
+// calls f(std::integral_constant<int, r>) for the run-time residue r in [0, sizeof...(Rs))
+template <typename F, int... Rs>
+__device__ __forceinline__ void dispatch_residue(const int r, F &f, std::integer_sequence<int, Rs...>)
+{
+  ((r == Rs ? (f(std::integral_constant<int, Rs>{}), 0) : 0), ...);
+}
+
+template <int MODE, bool REPAIR, bool DUMP, bool S256, bool ARITH = false>
 __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0, const int c1,
                                                const int wlo, const int whi, uint32_t &magsum,
                                                uint32_t (&edge)[4])
 {
+  // chunks between issuing a table gather and using its result; computed thetas need none
+  constexpr int LOOK = ARITH ? 0 : kLook;
   const RxParams &P = *X.P;
   const int lane = X.lane;
   const MixConst mc = mix_const(lane & 3);               // position & 3 (chunks are 64-aligned)
@@ -519,14 +636,14 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   if (X.first && cbeg == 0)
   {
     // the stream continues from the previous call: carried state
-    if (!P.src256)
+    if (!S256)
     {
       fc = carry_from_16(*reinterpret_cast<const uint4 *>(X.st->fe_tail));
     }
     c_theta = f2u(X.st->wb_theta);
     c_p = f2u(X.st->wb_p);
   }
-  else if (!P.src256)
+  else if (!S256)
   {
     // the three front-end carries depend on the 16 bytes before the run only
     const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 64 * cbeg) * 16 - 16);
@@ -542,17 +659,25 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   // stage 1: raw chunk -> 256 kS/s sample, side outputs, atan2 gather issued
   auto front = [&](const uint4 raw, const int ch) -> float {
     uint32_t y3 = 0, mixed;
-    if (P.src256)
+    if (S256)
     {
       const uint32_t w = raw.x ^ 0x8080u;                // int8 -> (value + 128)
       mixed = (w & 0xffu) | ((w & 0xff00u) << 8);
     }
     else
     {
-      y3 = frontend(raw, fc);
-      mixed = mix_fs4(y3, mc);                           // (q_idx << 16) | i_idx
+      if (ablate(P, 32))                                 // TIMING EXPERIMENT ONLY: no front-end arithmetic
+      {
+        y3 = raw.x ^ raw.y ^ raw.z ^ raw.w;
+        mixed = y3 & 0x00ff00ffu;
+      }
+      else
+      {
+        y3 = frontend(raw, fc);
+        mixed = mix_fs4(y3, mc);                         // (q_idx << 16) | i_idx
+      }
     }
-    if (!REPAIR && !P.src256)
+    if (!REPAIR && !S256)
     {
       const uint32_t mag = magnitude(y3);
       magsum += (ch >= nskip) ? mag : 0u;
@@ -574,12 +699,16 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
     {
       return 0.0f;
     }
+    if (ARITH)
+    {
+      return theta_arith(mixed, X.atc, X.ati);
+    }
     uint32_t idx = __builtin_amdgcn_perm(0u, mixed, 0x0c0c0200u);   // (q_idx << 8) | i_idx
-    if (P.dbg_flags & 1)                                    // TIMING EXPERIMENT ONLY: coalesced fake index
+    if (ablate(P, 1))                                    // TIMING EXPERIMENT ONLY: coalesced fake index
     {
       idx = (idx & 0xff00u) | (uint32_t)lane;
     }
-    if (P.dbg_flags & 16)                                   // TIMING EXPERIMENT ONLY: no gather at all
+    if (ablate(P, 16))                                   // TIMING EXPERIMENT ONLY: no gather at all
     {
       return u2f(idx);
     }
@@ -587,7 +716,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   };
   // stage 2: phase difference, +-pi wrap, gain, de-emphasis numerator, LDS store
   auto finish = [&](const float theta, const int ch, const bool store) {
-    if (P.dbg_flags & 8)                                    // TIMING EXPERIMENT ONLY: no theta-domain math
+    if (ablate(P, 8))                                    // TIMING EXPERIMENT ONLY: no theta-domain math
     {
       X.lds[X.vstart + 64 * ch + lane + X.hal] = f2u(theta);
       return;
@@ -605,25 +734,53 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
     }
   };
 
+  const int n = c1 - cbeg;                               // chunks in this run, >= 1
+  if (n <= LOOK)
+  {
+    // a run too short for the pipeline: one chunk at a time
+    for (int j = 0; j < n; j++)
+    {
+      const float t = front(load_chunk<S256>(X, cbeg + j), cbeg + j);
+      if (MODE == 3)
+      {
+        finish(t, cbeg + j, j == 0 ? !REPAIR : true);
+        if (!REPAIR && j == 0)
+        {
+          edge[0] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(t), 0);
+          edge[1] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(t), 1);
+        }
+        if (!REPAIR && j == n - 1)
+        {
+          edge[2] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(t), 62);
+          edge[3] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(t), 63);
+        }
+      }
+    }
+    return;
+  }
+  // The pipelined path.  Everything up to the main loop is branch-free so that the
+  // compiler's s_waitcnt bookkeeping reaches the loop header with exactly the pending
+  // loads the loop body leaves behind (a conditional prologue makes it drain the
+  // pipeline once per loop iteration).
   float th[kDepth];
   uint4 q[kDepth];
+  // chunk j lives in slot (j - cbeg) % kDepth, both for its raw data and its theta
 #pragma unroll
   for (int k = 0; k < kDepth; k++)
   {
-    q[k] = load_chunk(X, cbeg + k);                      // chunk cbeg + k lives in slot k
+    q[k] = load_chunk<S256>(X, cbeg + k);
     th[k] = 0.0f;
   }
-  // prologue: two fronts, then the first finish (peeled: it yields the leading edge)
-  th[0] = front(q[0], cbeg);
-  q[0] = load_chunk(X, cbeg + kDepth);
-  const int n = c1 - cbeg;                               // chunks in this run, >= 1
-  float th_last = th[0];
-  if (n >= 2)
+  // prologue: LOOK fronts, nothing finished yet
+#pragma unroll
+  for (int k = 0; k < LOOK; k++)
   {
-    th[1] = front(q[1], cbeg + 1);
-    q[1] = load_chunk(X, cbeg + 1 + kDepth);
-    th_last = th[1];
+    th[k] = front(q[k], cbeg + k);
+    q[k] = load_chunk<S256>(X, cbeg + k + kDepth);
   }
+  // first step, peeled: it yields the leading edge
+  th[LOOK % kDepth] = front(q[LOOK % kDepth], cbeg + LOOK);
+  q[LOOK % kDepth] = load_chunk<S256>(X, cbeg + LOOK + kDepth);
   if (MODE == 3)
   {
     finish(th[0], cbeg, !REPAIR);
@@ -633,60 +790,162 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
       edge[1] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th[0]), 1);
     }
   }
-  // main loop: chunk ch+k uses slot (2+k) % kDepth; branch-free groups of kDepth
-  int ch = cbeg + 2;
-  for (; ch + kDepth <= c1; ch += kDepth)
+  // main loop: front chunk fr+k (slot (LOOK+1+k) % kDepth), finish chunk fr+k-LOOK
+  // (slot (1+k) % kDepth); branch-free groups of kDepth
+  int fr = cbeg + LOOK + 1;
+  for (; fr + kDepth <= c1; fr += kDepth)
   {
 #pragma unroll
     for (int k = 0; k < kDepth; k++)
     {
-      const int slot = (2 + k) % kDepth;
-      th[slot] = front(q[slot], ch + k);
-      q[slot] = load_chunk(X, ch + k + kDepth);          // refill this slot
+      const int sf = (LOOK + 1 + k) % kDepth;
+      th[sf] = front(q[sf], fr + k);
+      q[sf] = load_chunk<S256>(X, fr + k + kDepth);            // refill this slot
       if (MODE == 3)
       {
-        finish(th[(slot + kDepth - 1) % kDepth], ch + k - 1, true);
+        finish(th[(1 + k) % kDepth], fr + k - LOOK, true);
       }
+#if HRFD_SCHED_FENCE
+      if ((k + 1) % HRFD_SCHED_FENCE == 0)
+      // one chunk at a time: without the fence the scheduler hoists the front ends of all
+      // kDepth chunks to the top of the loop body, which needs every prefetched chunk at once
+      // (s_waitcnt vmcnt(0)) and leaves the refills a few instructions of lead time
+      {
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     }
   }
-  if (n >= 2)
-  {
-    th_last = th[1];                                     // chunk ch-1 always sits in slot 1 here
-  }
-  // remainder (0..kDepth-1 chunks), then the last finish (trailing edge)
-  const int rem = c1 - ch;
+  // remainder: 0..kDepth-1 more fronts, each with its finish
 #pragma unroll
   for (int k = 0; k < kDepth - 1; k++)
   {
-    if (k < rem)
+    if (fr + k < c1)
     {
-      const int slot = (2 + k) % kDepth;
-      th[slot] = front(q[slot], ch + k);
+      const int sf = (LOOK + 1 + k) % kDepth;
+      th[sf] = front(q[sf], fr + k);
       if (MODE == 3)
       {
-        finish(th[(slot + kDepth - 1) % kDepth], ch + k - 1, true);
+        finish(th[(1 + k) % kDepth], fr + k - LOOK, true);
       }
-      th_last = th[slot];
     }
   }
-  if (MODE == 3)
-  {
-    if (n >= 2)
+  // drain: the last min(LOOK, n-1) chunks are fronted but not finished.  Their slots depend
+  // on n mod kDepth; one specialisation per residue keeps every slot index a constant (a
+  // run-time select chain makes the compiler spill th[] to scratch).
+  auto drain = [&](auto residue) {
+    constexpr int R = decltype(residue)::value;          // n % kDepth
+#pragma unroll
+    for (int d = LOOK; d >= 1; d--)
     {
-      finish(th_last, c1 - 1, true);
+      if (n - d >= 1)
+      {
+        finish(th[(R - d + 2 * kDepth) % kDepth], c1 - d, true);
+      }
     }
     if (!REPAIR)
     {
+      const float th_last = th[(R - 1 + kDepth) % kDepth];
       edge[2] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last), 62);
       edge[3] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last), 63);
     }
+  };
+  if (MODE == 3)
+  {
+    const int res = n % kDepth;
+    dispatch_residue(res, drain, std::make_integer_sequence<int, kDepth>{});
   }
 }
 
-template <int MODE>
+// Derives the correction bytes of theta_arith() from the reference table itself.
+// One thread per (a, b): for each of the four octant classes that exist for it,
+// code = (approx - table) + 1 must lie in 0..3; the mirrored entry (q < 0) must be
+// the exact negation.  bad[0] counts violations (then the gather kernel is used).
+__global__ void k_build_atan_corr(const float *lut, const float *inv, uint8_t *corr, uint32_t *bad)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= kCorrBytes)
+  {
+    return;
+  }
+  if (t >= kTriEntries)
+  {
+    corr[t] = 0;
+    return;
+  }
+  // t = a (a + 1) / 2 + b
+  int a = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((a + 1) * (a + 2) / 2 <= t) a++;
+  while (a * (a + 1) / 2 > t) a--;
+  const int b = t - a * (a + 1) / 2;
+  uint32_t byte = 0, nbad = 0;
+  for (int v = 0; v < 4; v++)
+  {
+    const bool swap = (v & 1) != 0, negi = (v & 2) != 0;
+    const int mi = swap ? b : a, mq = swap ? a : b;      // |i|, |q|
+    if (swap && !(b < a))
+    {
+      continue;                                          // ties are classified swap = 0
+    }
+    const int i = negi ? -mi : mi;
+    if (negi ? (mi == 0) : (mi == 128))
+    {
+      continue;                                          // i = -0 / i = +128 do not exist
+    }
+    const AtanApprox ap = atan2_approx((uint32_t)a, (uint32_t)b, swap, negi, inv[a]);
+    bool have = false;
+    for (int sgn = 0; sgn < 2; sgn++)
+    {
+      const int q = sgn ? -mq : mq;
+      if (q > 127 || (sgn && mq == 0))
+      {
+        continue;
+      }
+      uint32_t ex = f2u(lut[(q + 128) * 256 + (i + 128)]);
+      if (sgn)
+      {
+        ex ^= 0x80000000u;                               // table must be odd in q
+      }
+      const int32_t code = (int32_t)(f2u(ap.theta0) - ex) + 1;
+      if (code < 0 || code > 3)
+      {
+        nbad++;
+        continue;
+      }
+      if (have && ((byte >> ap.shift) & 3u) != (uint32_t)code)
+      {
+        nbad++;
+      }
+      byte |= (uint32_t)code << ap.shift;
+      have = true;
+    }
+  }
+  corr[t] = (uint8_t)byte;
+  if (nbad)
+  {
+    atomicAdd(bad, nbad);
+  }
+}
+
+// test hook (hrfd_rx_debug_atan_eval): theta_arith over the whole (q, i) domain, table layout
+__global__ void k_atan_eval(const uint8_t *corr, const float *inv, float *out)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;       // (q_idx << 8) | i_idx
+  if (t < 65536u)
+  {
+    out[t] = theta_arith(((t >> 8) << 16) | (t & 0xffu), corr, inv);
+  }
+}
+
+template <int MODE, bool S256, bool ARITH>
 __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 {
   __shared__ __attribute__((aligned(16))) uint32_t lds[kMaxNV];
+  // arithmetic atan2 tables (zero-sized in the gather build of the kernel)
+  __shared__ __attribute__((aligned(16))) uint8_t atcorr[ARITH ? kCorrBytes : 16];
+  __shared__ __attribute__((aligned(16))) float atinv[ARITH ? kInvEntries : 4];
+  static_assert(sizeof(uint32_t) * kMaxNV + kCorrBytes + sizeof(float) * kInvEntries + 512 <= 81920,
+                "two workgroups per CU need <= 80 KiB of LDS each");
   __shared__ uint32_t red[kWaves];
   __shared__ float tailcarry[2];        // theta, b0*x of the block's last sample
   __shared__ uint32_t edges[kWaves][4]; // per run: theta of its first two and last two samples
@@ -726,6 +985,23 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   X.n256 = n256;
   X.lane = lane;
   X.first = first;
+  X.atc = atcorr;
+  X.ati = atinv;
+  if (ARITH)
+  {
+    // 8.5 KiB of atan2 correction bytes and reciprocals, L2-resident: one 16-byte copy per thread
+    static_assert(kCorrBytes / 16 + kInvEntries / 4 <= kThreads, "one copy per thread");
+    if (tid < kCorrBytes / 16)
+    {
+      reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr)[tid];
+    }
+    else if (tid < kCorrBytes / 16 + kInvEntries / 4)
+    {
+      const int j = tid - kCorrBytes / 16;
+      reinterpret_cast<uint4 *>(atinv)[j] = reinterpret_cast<const uint4 *>(P.at_inv)[j];
+    }
+    __syncthreads();
+  }
   const int8_t *blk = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)b * P.block_bytes;
 
 #define HRFD_STAMP(i)                                                         \
@@ -752,11 +1028,11 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
     uint32_t e[4] = {0u, 0u, 0u, 0u};
     if (P.iq256 != nullptr)
     {
-      produce_stream<MODE, false, true>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<MODE, false, true, S256, ARITH>(X, c0, c1, X.vstart, n256, magsum, e);
     }
     else
     {
-      produce_stream<MODE, false, false>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<MODE, false, false, S256, ARITH>(X, c0, c1, X.vstart, n256, magsum, e);
     }
     if (MODE == 3 && lane < 4)
     {
@@ -789,7 +1065,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   // the predecessor's `present` is not known here: the batch speculates "open"
   // and k_rx_epilogue verifies it.
   // (the inner demodulator API has no squelch: X::acceptIqData always demodulates)
-  const bool allowed = P.src256 ? true : (first ? (present || st->tracking != 0) : true);
+  const bool allowed = S256 ? true : (first ? (present || st->tracking != 0) : true);
   if (tid == 0)
   {
     P.magnitude[X.ounit] = mean_mag;
@@ -798,7 +1074,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 
   const bool last = (b + 1 == P.n_blocks);
   ChanState *so = P.state_out + c;
-  if (last && tid < 4 && !P.src256)
+  if (last && tid < 4 && !S256)
   {
     // front-end carry for the next call: the last 16 raw bytes of this block
     reinterpret_cast<uint32_t *>(so->fe_tail)[tid] =
@@ -867,7 +1143,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
         }
       }
     }
-    else if (!(P.dbg_flags & 2))                           // (flag 2: TIMING EXPERIMENT ONLY, skip phase B)
+    else if (!(ablate(P, 2)))                           // (flag 2: TIMING EXPERIMENT ONLY, skip phase B)
     {
       const int s = origin + lane * T;
       float y = first ? st->wb_y : 0.0f;
@@ -907,7 +1183,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
         const int rc0 = (sj - X.vstart) >> 6;
         const int rc1 = (sj + T - X.vstart + 63) >> 6;
         uint32_t dummy_mag = 0, dummy_e[4];
-        produce_stream<MODE, true, false>(X, rc0, rc1, sj, sj + T, dummy_mag, dummy_e);
+        produce_stream<MODE, true, false, S256, ARITH>(X, rc0, rc1, sj, sj + T, dummy_mag, dummy_e);
         // re-run the tile from the true y[sj - 1] = final y of lane j-1
         const float y_true = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y), j - 1));
         if (lane == j)
@@ -947,7 +1223,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
     P.chk_pub[unit] = u2f(lds[n256 + chk + hal]);
   }
 
-  if (P.dbg_flags & 4)                                     // TIMING EXPERIMENT ONLY: skip phase C
+  if (ablate(P, 4))                                     // TIMING EXPERIMENT ONLY: skip phase C
   {
     return;
   }
@@ -1186,7 +1462,9 @@ __global__ __launch_bounds__(64) void k_rx_commit(const EpilogueParams E)
 }
 
 // explicit instantiations used by the host side
-template __global__ void k_rx_wbfm<0>(const RxParams);
-template __global__ void k_rx_wbfm<3>(const RxParams);
+template __global__ void k_rx_wbfm<0, false, false>(const RxParams);
+template __global__ void k_rx_wbfm<3, false, false>(const RxParams);
+template __global__ void k_rx_wbfm<3, false, true>(const RxParams);
+template __global__ void k_rx_wbfm<3, true, false>(const RxParams);
 
 } // namespace hrfd

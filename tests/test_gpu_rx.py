@@ -337,3 +337,40 @@ def test_inner_demod_many_channels(oracle):
         o = oracle.demod(WBFM)
         for k in range(2):
             assert (got[k][c] == o.process(xs[c, k * 32768:(k + 1) * 32768])).all()
+
+
+# ---------------------------------------------------------------- arithmetic atan2
+def test_arithmetic_atan2_equals_table_everywhere():
+    """k_rx_wbfm computes theta (polynomial + 2-bit correction from LDS) instead of
+    gathering it from the reference's 256 x 256 table: every one of the 65536 (q, i)
+    entries must be the table's float, bit for bit."""
+    rx = api.Rx(1)
+    rx.debug_set_atan(1)                         # raises if the corrections did not fit
+    got = rx.debug_atan_eval()
+    want = api.atan2_table()
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("kind", ["lcg", "fmtone", "dc_neg", "impulse", "fullscale"])
+def test_atan2_kernels_agree(oracle, kind):
+    """both builds of the WBFM kernel (table gather, arithmetic) against the oracle"""
+    C, B = 2, 3
+    if kind == "fullscale":
+        # every byte at +-127/-128: the decimated samples reach the table's rim
+        rng = np.random.default_rng(5)
+        xs = rng.choice(np.array([-128, -127, 127], dtype=np.int8), size=(C, B, BLK))
+        # long runs so that the half-band stages pass the extremes through
+        xs = np.repeat(xs[:, :, ::64], 64, axis=2).copy()
+    else:
+        xs = np.stack([synth.make_input(kind, 90 + c, B) for c in range(C)]).reshape(C, B, BLK)
+    out = []
+    for mode in (0, 1):
+        rx = api.Rx(C)
+        rx.set_mode(api.WBFM)
+        rx.debug_set_atan(mode)
+        out.append(rx.process_block(xs, B)[0])
+    assert (out[0] == out[1]).all()
+    for c in range(C):
+        want = _oracle_stream(oracle, WBFM, xs[c], B)
+        for b in range(B):
+            assert (out[1][c, b] == want[b][0]).all(), (c, b)

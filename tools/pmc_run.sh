@@ -2,7 +2,7 @@
 # usage: tools/pmc_run.sh "<counters>" <tag>   (runs on the GPU box; PMC only, no trace flags besides kernel-trace)
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$2
-rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu > $OUT.log 2>&1
+timeout 200 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu > $OUT.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 fs=glob.glob("$OUT/**/*counter_collection.csv", recursive=True)

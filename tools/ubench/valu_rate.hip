@@ -11,14 +11,19 @@
   {                                                                               \
     unsigned a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3; \
     unsigned b0 = 0x00010002, b1 = 0x00030004;                                    \
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                     \
     unsigned long long t0 = __builtin_readcyclecounter();                         \
     for (int i = 0; i < iters; i++)                                               \
     {                                                                             \
       REP16(body)                                                                 \
     }                                                                             \
     unsigned long long t1 = __builtin_readcyclecounter();                         \
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                     \
     if ((threadIdx.x & 63) == 0)                                                  \
+    {                                                                             \
       out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;           \
+      out[8192 + blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = r1 - r0;    \
+    }                                                                             \
     if (a0 + a1 + a2 + a3 == 0x12345678) out[0] = b0 + b1;                        \
   }
 
@@ -43,21 +48,31 @@ KERNEL(k_dep_mulf, asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %0, %0, %4\n v
 KERNEL(k_dep_pk, asm volatile("v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %0, %0, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
 
 typedef void (*kern_t)(unsigned long long *, int);
+// grid = 512 workgroups of 1024 threads = 8 waves on every SIMD of the chip; wall clock by
+// HIP events -> ns per wave-instruction per SIMD (a SIMD16 at 2.4 GHz would give 1.67 ns)
 static void run(const char *name, kern_t k, int threads)
 {
-  unsigned long long *d, h[4096];
+  static unsigned long long h[16384];
+  unsigned long long *d;
   hipMalloc(&d, sizeof(h));
   const int iters = 2000;
-  hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, d, iters);
-  hipLaunchKernelGGL(k, dim3(256), dim3(threads), 0, 0, d, iters);
+  const int grid = (threads == 1024) ? 512 : 256;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(threads), 0, 0, d, iters);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(threads), 0, 0, d, iters);
+  hipEventRecord(e1, 0);
   hipDeviceSynchronize();
-  hipMemcpy(h, d, sizeof(unsigned long long) * 256 * (threads / 64), hipMemcpyDeviceToHost);
-  double sum = 0; int n = 256 * (threads / 64);
-  for (int i = 0; i < n; i++) sum += (double)h[i];
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  double sum = 0, rsum = 0; int n = grid * (threads / 64);
+  for (int i = 0; i < n; i++) { sum += (double)h[i]; rsum += (double)h[8192 + i]; }
   const double per_wave = sum / n / (iters * 64.0);          // ticks per instruction as seen by one wave
-  const int waves_per_simd = threads / 256;
-  printf("%-14s %4d thr/WG: %6.2f ticks/instr/wave -> %5.2f ticks/instr/SIMD\n", name, threads, per_wave,
-         per_wave / (waves_per_simd ? waves_per_simd : 1));
+  const double waves_per_simd = (double)grid * (threads / 64) / 1024.0;
+  const double instr_per_simd = waves_per_simd * iters * 64.0;
+  printf("%-14s %4d thr/WG x %d: %6.2f ticks/instr/wave; wall %.3f ms -> %5.2f ns/instr/SIMD (%.2f cycles at 2.4 GHz); s_memtime/s_memrealtime = %.2f\n", name, threads, grid,
+         per_wave, ms, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4, sum / rsum);
   hipFree(d);
 }
 #define RUN(k) run(#k, k, 256); run(#k, k, 1024);
