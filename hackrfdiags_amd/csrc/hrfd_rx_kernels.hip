@@ -69,25 +69,44 @@ __device__ __forceinline__ uint32_t lane63(uint32_t v)
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// ---- half-band /2 stage on packed (I,Q), offset-binary domain ---------------
+// ---- half-band /2 stages on (I,Q) pairs, offset-binary domain ----------------
 // Reference: y = (16384 + h0*(a+c) + 16384*b) >> 15 with h0 = 8192 + d
 // (Decimator_int16.cc:176-249 with the 3-tap tables of IqDataProcessor.cc:8-27).
-// With a' = a+128 etc. and T = a'+c':  y' = y+128 = (T + 2b' + ((D*T + K) >> SH)) >> 2,
-// where (D*T + K) >> SH == floor((d*(T-256) + 16384) / 8192).  Every intermediate
-// fits int16, so the stage runs on v_pk_* with I and Q in the two halves: six
-// packed instructions per output pair.
+// With a' = a+128 etc. and T = a'+c':  4*(y+128) + rem = T + 2b' + k(T), where
+//   k(T) = floor((d*(T-256) + 16384) / 8192)
+//        = 1 + (T >> 8)                     h0 = 8206 (d = 14)
+//        = (57 T + 1792) >> 13              h0 = 8249 (d = 57)
+//        = ((29 T + 2816) >> 10) - 8        h0 = 8424 (d = 232)
+// I sits in bits 0..15 and Q in bits 16..31 of one register.  Every field stays
+// in 0..2053, so plain 32-bit adds and (shift, mask) pairs act on both fields at
+// once; those are 32-bit-encoded VOP2 instructions, which gfx950 issues at about
+// twice the rate of the 64-bit-encoded packed-math ones (tools/ubench/valu_rate.hip).
+// Only the two multiplies remain v_pk_mad_u16.  The last stage adds 4*256 so that
+// no field goes negative; the (int8_t) narrowing of IqDataProcessor.cc:458,489
+// keeps the low byte only, which that does not touch.
 // Checked exhaustively against the direct form in tests/test_abi_and_tables.py.
-template <int D, int K, int SH>
-__device__ __forceinline__ s2 halfband(s2 a, s2 b, s2 c)
+__device__ __forceinline__ uint32_t hb1_sum(uint32_t a, uint32_t b, uint32_t c)
 {
-  const s2 t = a + c;
-  const s2 k = (t * (short)D + (short)K) >> (short)SH;
-  const s2 u = b * (short)2 + t;
-  return (u + k) >> (short)2;
+  const uint32_t t = a + c;
+  const uint32_t h = (t >> 8) & 0x00010001u;
+  return t + ((b << 1) | 0x00010001u) + h;
 }
-#define HB1(a, b, c) halfband<14, 12800, 13>(a, b, c)   /* h0 = 8206 */
-#define HB2(a, b, c) halfband<57, 1792, 13>(a, b, c)    /* h0 = 8249 */
-#define HB3(a, b, c) halfband<29, -5376, 10>(a, b, c)   /* h0 = 8424 = 8192 + 8*29 */
+// b2 = 2 b' (form_b2 of the previous stage)
+__device__ __forceinline__ uint32_t hb2_sum(uint32_t a, uint32_t b2, uint32_t c)
+{
+  const uint32_t t = a + c;
+  const uint32_t k = (as_u32(as_s2(t) * (short)57 + (short)1792) >> 13) & 0x00070007u;
+  return t + b2 + k;
+}
+__device__ __forceinline__ uint32_t hb3_sum(uint32_t a, uint32_t b2, uint32_t c)
+{
+  const uint32_t t = a + c;
+  const uint32_t k = (as_u32(as_s2(t) * (short)29 + (short)2816) >> 10) & 0x003f003fu;
+  return t + b2 + k + 0x03f803f8u;                       // (-8 + 4*256) per field
+}
+// a stage's sum as the next stage's outer tap (y') or centre tap (2 y')
+__device__ __forceinline__ uint32_t form_ac(uint32_t s) { return (s >> 2) & 0x00ff00ffu; }
+__device__ __forceinline__ uint32_t form_b2(uint32_t s) { return (s >> 1) & 0x01fe01feu; }
 
 // Carry between consecutive 1 KiB chunks of one wave: lane 0 of each register
 // holds the value of the previous chunk's last lane.
@@ -104,31 +123,31 @@ __device__ __forceinline__ uint32_t frontend(const uint4 raw, FeCarry &c)
 {
   const uint32_t r0 = raw.x ^ 0x80808080u, r1 = raw.y ^ 0x80808080u;
   const uint32_t r2 = raw.z ^ 0x80808080u, r3 = raw.w ^ 0x80808080u;
-  // zero-extend bytes (I0,Q0,I1,Q1) into two packed pairs
-  const s2 x0 = as_s2(__builtin_amdgcn_perm(0u, r0, 0x0c010c00u));
-  const s2 x1 = as_s2(__builtin_amdgcn_perm(0u, r0, 0x0c030c02u));
-  const s2 x2 = as_s2(__builtin_amdgcn_perm(0u, r1, 0x0c010c00u));
-  const s2 x3 = as_s2(__builtin_amdgcn_perm(0u, r1, 0x0c030c02u));
-  const s2 x4 = as_s2(__builtin_amdgcn_perm(0u, r2, 0x0c010c00u));
-  const s2 x5 = as_s2(__builtin_amdgcn_perm(0u, r2, 0x0c030c02u));
-  const s2 x6 = as_s2(__builtin_amdgcn_perm(0u, r3, 0x0c010c00u));
-  const s2 x7 = as_s2(__builtin_amdgcn_perm(0u, r3, 0x0c030c02u));
+  // zero-extend bytes (I0,Q0,I1,Q1) into two (I,Q) pairs
+  const uint32_t x0 = __builtin_amdgcn_perm(0u, r0, 0x0c010c00u);
+  const uint32_t x1 = __builtin_amdgcn_perm(0u, r0, 0x0c030c02u);
+  const uint32_t x2 = __builtin_amdgcn_perm(0u, r1, 0x0c010c00u);
+  const uint32_t x3 = __builtin_amdgcn_perm(0u, r1, 0x0c030c02u);
+  const uint32_t x4 = __builtin_amdgcn_perm(0u, r2, 0x0c010c00u);
+  const uint32_t x5 = __builtin_amdgcn_perm(0u, r2, 0x0c030c02u);
+  const uint32_t x6 = __builtin_amdgcn_perm(0u, r3, 0x0c010c00u);
+  const uint32_t x7 = __builtin_amdgcn_perm(0u, r3, 0x0c030c02u);
 
-  const s2 xm1 = as_s2(shr1(as_u32(x7), c.x7));
-  c.x7 = ror1(as_u32(x7));
-  const s2 y10 = HB1(xm1, x0, x1);
-  const s2 y11 = HB1(x1, x2, x3);
-  const s2 y12 = HB1(x3, x4, x5);
-  const s2 y13 = HB1(x5, x6, x7);
+  const uint32_t xm1 = shr1(x7, c.x7);
+  c.x7 = ror1(x7);
+  const uint32_t y10b = form_b2(hb1_sum(xm1, x0, x1));
+  const uint32_t y11 = form_ac(hb1_sum(x1, x2, x3));
+  const uint32_t y12b = form_b2(hb1_sum(x3, x4, x5));
+  const uint32_t y13 = form_ac(hb1_sum(x5, x6, x7));
 
-  const s2 y1m1 = as_s2(shr1(as_u32(y13), c.y13));
-  c.y13 = ror1(as_u32(y13));
-  const s2 y20 = HB2(y1m1, y10, y11);
-  const s2 y21 = HB2(y11, y12, y13);
+  const uint32_t y1m1 = shr1(y13, c.y13);
+  c.y13 = ror1(y13);
+  const uint32_t y20b = form_b2(hb2_sum(y1m1, y10b, y11));
+  const uint32_t y21 = form_ac(hb2_sum(y11, y12b, y13));
 
-  const s2 y2m1 = as_s2(shr1(as_u32(y21), c.y21));
-  c.y21 = ror1(as_u32(y21));
-  return as_u32(HB3(y2m1, y20, y21));
+  const uint32_t y2m1 = shr1(y21, c.y21);
+  c.y21 = ror1(y21);
+  return hb3_sum(y2m1, y20b, y21) >> 2;                  // low byte of each half significant
 }
 
 // The carry that a chunk boundary needs is a function of the 16 bytes before
@@ -137,20 +156,20 @@ __device__ __forceinline__ FeCarry carry_from_16(const uint4 raw)
 {
   const uint32_t r0 = raw.x ^ 0x80808080u, r1 = raw.y ^ 0x80808080u;
   const uint32_t r2 = raw.z ^ 0x80808080u, r3 = raw.w ^ 0x80808080u;
-  const s2 x1 = as_s2(__builtin_amdgcn_perm(0u, r0, 0x0c030c02u));
-  const s2 x2 = as_s2(__builtin_amdgcn_perm(0u, r1, 0x0c010c00u));
-  const s2 x3 = as_s2(__builtin_amdgcn_perm(0u, r1, 0x0c030c02u));
-  const s2 x4 = as_s2(__builtin_amdgcn_perm(0u, r2, 0x0c010c00u));
-  const s2 x5 = as_s2(__builtin_amdgcn_perm(0u, r2, 0x0c030c02u));
-  const s2 x6 = as_s2(__builtin_amdgcn_perm(0u, r3, 0x0c010c00u));
-  const s2 x7 = as_s2(__builtin_amdgcn_perm(0u, r3, 0x0c030c02u));
-  const s2 y11 = HB1(x1, x2, x3);
-  const s2 y12 = HB1(x3, x4, x5);
-  const s2 y13 = HB1(x5, x6, x7);
+  const uint32_t x1 = __builtin_amdgcn_perm(0u, r0, 0x0c030c02u);
+  const uint32_t x2 = __builtin_amdgcn_perm(0u, r1, 0x0c010c00u);
+  const uint32_t x3 = __builtin_amdgcn_perm(0u, r1, 0x0c030c02u);
+  const uint32_t x4 = __builtin_amdgcn_perm(0u, r2, 0x0c010c00u);
+  const uint32_t x5 = __builtin_amdgcn_perm(0u, r2, 0x0c030c02u);
+  const uint32_t x6 = __builtin_amdgcn_perm(0u, r3, 0x0c010c00u);
+  const uint32_t x7 = __builtin_amdgcn_perm(0u, r3, 0x0c030c02u);
+  const uint32_t y11 = form_ac(hb1_sum(x1, x2, x3));
+  const uint32_t y12b = form_b2(hb1_sum(x3, x4, x5));
+  const uint32_t y13 = form_ac(hb1_sum(x5, x6, x7));
   FeCarry c;
-  c.x7 = as_u32(x7);
-  c.y13 = as_u32(y13);
-  c.y21 = as_u32(HB2(y11, y12, y13));
+  c.x7 = x7;
+  c.y13 = y13;
+  c.y21 = form_ac(hb2_sum(y11, y12b, y13));
   return c;
 }
 
@@ -187,8 +206,9 @@ __device__ __forceinline__ uint32_t mix_fs4(uint32_t y3, const MixConst mc)
 }
 
 // max(|I|,|Q|) + (min(|I|,|Q|) >> 1) of the int8 values (SignalDetector.cc:226-241);
-// |-128| = 128 as in the reference's uint8.  Rotation invariant, so taken from
-// the unrotated pair.
+// |-128| = 128 as in the reference's uint8.  Rotation invariant (the Fs/4 mixer only
+// swaps and negates, and -(-128) wraps to -128), so it is taken from the rotated pair,
+// whose |i|, |q| the arithmetic atan2 needs anyway.
 __device__ __forceinline__ uint32_t magnitude(uint32_t y3)
 {
   const s2 d = as_s2(y3 & 0x00ff00ffu) - as_s2(0x00800080u);
@@ -679,7 +699,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
     }
     if (!REPAIR && !S256)
     {
-      const uint32_t mag = magnitude(y3);
+      const uint32_t mag = magnitude(mixed);             // rotation invariant: shares |i|, |q| with theta_arith
       magsum += (ch >= nskip) ? mag : 0u;
       if (DUMP && dump != nullptr && ch >= nskip)        // optional `enable iqdump` stream
       {

@@ -61,16 +61,45 @@ def test_host_built_tables_match_oracle(lib, oracle):
 
 
 def test_halfband_offset_domain_formula():
-    """The packed 16-bit form the kernel uses for the three half-band stages
-    (hrfd_rx_kernels.hip, halfband<D,K,SH>) equals the reference's Q15 form for
-    every reachable input, and never leaves the int16 range."""
-    for h0, d, k, sh, rng in [(8206, 14, 12800, 13, 129), (8249, 57, 1792, 13, 130), (8424, 29, -5376, 10, 132)]:
-        s = np.arange(-2 * rng, 2 * rng + 1)[:, None]      # a + c
-        b = np.arange(-rng, rng + 1)[None, :]
-        direct = (16384 + h0 * s + 16384 * b) >> 15
-        t = s + 256
-        kk = t * d + k
-        assert kk.min() >= -32768 and kk.max() <= 32767
-        u = t + 2 * (b + 128) + (kk >> sh)
-        assert u.min() >= -32768 and u.max() <= 32767
-        assert ((u >> 2) - 128 == direct).all(), h0
+    """The 32-bit SWAR form the kernel uses for the three half-band stages
+    (hrfd_rx_kernels.hip, hb1_sum / hb2_sum / hb3_sum with I in bits 0..15 and Q in
+    bits 16..31 of one register) equals the reference's Q15 form for every input
+    triple, on both fields at once, and no field ever borrows from or carries into
+    its neighbour."""
+    A = np.arange(-128, 128, dtype=np.int64)
+    a, b, c = np.meshgrid(A, A, A, indexing="ij")
+    qa, qb, qc = c[::-1, ::-1, ::-1], a[::-1, ::-1, ::-1], b[::-1, ::-1, ::-1]   # a different triple in the Q field
+
+    def pack(i, q):
+        return ((i + 128) | ((q + 128) << 16)).astype(np.uint32)
+
+    def direct(h0, x, y, z):
+        return (16384 + h0 * (x + z) + 16384 * y) >> 15
+
+    def pk_mad(t, d, k):                                   # v_pk_mad_u16, per 16-bit field
+        lo = (t & M(0xFFFF)).astype(np.int64) * d + k
+        hi = (t >> M(16)).astype(np.int64) * d + k
+        assert lo.max() < 65536 and hi.max() < 65536 and lo.min() >= 0 and hi.min() >= 0
+        return (lo | (hi << 16)).astype(np.uint32)
+
+    pa, pb, pc = pack(a, qa), pack(b, qb), pack(c, qc)
+    M = np.uint32
+    # stage 1
+    t = pa + pc
+    s1 = t + ((pb << M(1)) | M(0x00010001)) + ((t >> M(8)) & M(0x00010001))
+    ac = (s1 >> M(2)) & M(0x00FF00FF)
+    b2 = (s1 >> M(1)) & M(0x01FE01FE)
+    assert ((ac & M(0xFFFF)).astype(np.int64) - 128 == direct(8206, a, b, c)).all()
+    assert ((ac >> M(16)).astype(np.int64) - 128 == direct(8206, qa, qb, qc)).all()
+    assert (b2 == M(2) * ac).all()
+    # stage 2 (its inputs are stage-1 outputs: -128..127 again)
+    s2 = t + (pb << M(1)) + ((pk_mad(t, 57, 1792) >> M(13)) & M(0x00070007))
+    ac = (s2 >> M(2)) & M(0x00FF00FF)
+    assert ((ac & M(0xFFFF)).astype(np.int64) - 128 == direct(8249, a, b, c)).all()
+    assert ((ac >> M(16)).astype(np.int64) - 128 == direct(8249, qa, qb, qc)).all()
+    assert (((s2 >> M(1)) & M(0x01FE01FE)) == M(2) * ac).all()
+    # stage 3: the result is narrowed to int8 (IqDataProcessor.cc:458,489): low byte only
+    s3 = t + (pb << M(1)) + ((pk_mad(t, 29, 2816) >> M(10)) & M(0x003F003F)) + M(0x03F803F8)
+    y = s3 >> M(2)
+    assert ((y & M(0xFF)).astype(np.int64) == ((direct(8424, a, b, c) + 128) & 0xFF)).all()
+    assert (((y >> M(16)) & M(0xFF)).astype(np.int64) == ((direct(8424, qa, qb, qc) + 128) & 0xFF)).all()
