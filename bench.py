@@ -175,6 +175,23 @@ def bench_ssbmod(args, api, device, rank, world, dist):
         dist.destroy_process_group()
 
 
+def pmc_traffic_bytes(args, C, B):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_round.sh
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs of this same command; the summary
+    is committed under profiles/).  gfx950: FETCH_SIZE counts 64 B per 128-B request for wide
+    coalesced reads, hence the factor 2 (MI355X_MICROARCH.md).  None when the workload differs
+    from the profiled one."""
+    if args.workload != "wbfm" or (C, B) != (256, 16):
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_pmc_traffic_wbfm256x16.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return int(t["FETCH_SIZE"]["mean"] * 1024 * 2 + t["WRITE_SIZE"]["mean"] * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,8 +314,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
-                "kernel": "hrfd::k_rx_wbfm<3>" if args.workload == "wbfm" else "all demodulator kernels of a step",
+                "traffic": pmc_traffic_bytes(args, C, B),
+                "kernel": ("hrfd::k_rx_wbfm<3, false, true> (arithmetic atan2)" if args.workload == "wbfm"
+                           else "all demodulator kernels of a step"),
                 "kernel_ms_mean": round(mean_ms, 4),
                 "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "algorithmic_bytes_per_launch": algo_bytes,

@@ -33,6 +33,9 @@
 #include <type_traits>
 #include <utility>
 #include "hrfd_tables.h"
+#ifndef HRFD_IIR_U
+#define HRFD_IIR_U 8
+#endif
 #ifdef HRFD_ABLATE
 #define HRFD_ABLATE_EARLY HRFD_ABLATE
 #else
@@ -225,7 +228,7 @@ __device__ __forceinline__ uint32_t magnitude(uint32_t y3)
 // which made it the bound of the whole kernel.  Instead theta is computed:
 //   a = max(|i|,|q|), b = min(|i|,|q|), r = b/a, phi = r + r^3 P(r^2)  (~1 ulp)
 //   theta0 = phi | pi/2 - phi | pi - phi | pi - (pi/2 - phi)   by octant,
-// then made bit-identical to the table with a 2-bit correction per
+// then made bit-identical to the table with a 2-bit (signed) correction per
 // (a, b, octant class) -- 8385 bytes, resident in LDS -- and the sign of q.
 // The correction bytes are derived on the device at hrfd_rx_create() from the
 // very table they replace, with this very function (k_build_atan_corr), so the
@@ -283,29 +286,30 @@ __device__ __forceinline__ float theta_arith(uint32_t mixed, const uint8_t *corr
 #endif
   const bool negi = (mixed & 0x00000080u) == 0u;
   const AtanApprox ap = atan2_approx(a, b, swap, negi, inv_a);
-  const uint32_t code = (code8 >> ap.shift) & 3u;
-  uint32_t bits = f2u(ap.theta0) + 1u - code;            // code = (approx - exact) + 1 in ulps
-  bits |= (~mixed << 8) & 0x80000000u;                   // q < 0: atan2(-q, i) = -atan2(q, i)
-  return u2f(bits);
+  // 2-bit two's complement field: (exact - approx) in ulps, -2..1
+  const int32_t fix = __builtin_amdgcn_sbfe((int32_t)code8, ap.shift, 2u);
+  const uint32_t bits = f2u(ap.theta0) + (uint32_t)fix;
+  // q < 0 (bit 23 of `mixed` clear): atan2(-q, i) = -atan2(q, i); theta0 >= 0, so set the sign:
+  // bits | (~(mixed << 8) & 0x80000000) as one three-input bit operation
+  return u2f(__builtin_amdgcn_bitop3_b32(bits, mixed << 8, 0x80000000u, 0xF2));
 }
 
 // deltaTheta wrap (WbFmDemodulator.cc:417-425).  The reference compares the
 // float against the double M_PI: (double)d > M_PI  <=>  d >= 0x1.921fb6p+1f,
 // and subtracts 2*M_PI in double before rounding back to float.  |d| <= 2*pi,
-// so one correction suffices and at most one of the two loops runs.
+// so one correction suffices.  The double subtraction is replaced by two float
+// ones, (d -+ C_HI) -+ C_LO with C_HI + C_LO = 2*M_PI to float precision: the first
+// is exact (Sterbenz), the second rounds once, and tools/proofs/wrap_float.c shows
+// over all 4.0e8 wrapping pairs of table thetas that it rounds to the same float.
 __device__ __forceinline__ float wrap_pi(float d)
 {
-  const float pi_up = 3.14159274101257324e+00f;       // smallest float > M_PI
-  const double two_pi = 6.283185307179586476925286766559;
-  const bool need = fabsf(d) >= pi_up;
-  // wave-uniform skip: FM signals rarely wrap, and the double path is slow
-  if (__builtin_amdgcn_ballot_w64(need) != 0ull)
-  {
-    const double adj = (d > 0.0f) ? -two_pi : two_pi;
-    const float w = (float)((double)d + adj);
-    d = need ? w : d;
-  }
-  return d;
+  const float pi_up = 3.14159274101257324e+00f;          // smallest float > M_PI
+  const uint32_t c_hi = 0x40c90fdbu;                     // (float)(2*M_PI)
+  const uint32_t c_lo = 0xb43bbd2eu;                     // (float)(2*M_PI - C_HI) = -0x1.777a5cp-23
+  const uint32_t sg = f2u(d) & 0x80000000u;
+  const float u = d - u2f(c_hi | sg);
+  const float w = u - u2f(c_lo ^ sg);
+  return (fabsf(d) >= pi_up) ? w : d;
 }
 
 // (int16_t)f the way x86-64 does it (cvttss2si, then the low 16 bits): NaN and
@@ -462,7 +466,7 @@ __device__ __forceinline__ float iir_run(const uint32_t *in, uint32_t *out, cons
                                          const int kskip, float y)
 {
   const float a1 = DEEMPH_A1;
-  constexpr int U = 8;
+  constexpr int U = HRFD_IIR_U;                        // steps per prefetched group
   auto step = [&](float vv, int k) {
     const float r = a1 * y;
     const float yn = vv - r;
@@ -879,7 +883,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
 
 // Derives the correction bytes of theta_arith() from the reference table itself.
 // One thread per (a, b): for each of the four octant classes that exist for it,
-// code = (approx - table) + 1 must lie in 0..3; the mirrored entry (q < 0) must be
+// fix = table - approx (in ulps) must lie in -2..1 (a 2-bit two's complement field); the mirrored entry (q < 0) must be
 // the exact negation.  bad[0] counts violations (then the gather kernel is used).
 __global__ void k_build_atan_corr(const float *lut, const float *inv, uint8_t *corr, uint32_t *bad)
 {
@@ -926,12 +930,13 @@ __global__ void k_build_atan_corr(const float *lut, const float *inv, uint8_t *c
       {
         ex ^= 0x80000000u;                               // table must be odd in q
       }
-      const int32_t code = (int32_t)(f2u(ap.theta0) - ex) + 1;
-      if (code < 0 || code > 3)
+      const int32_t fix = (int32_t)(ex - f2u(ap.theta0));  // exact - approx in ulps
+      if (fix < -2 || fix > 1)
       {
         nbad++;
         continue;
       }
+      const int32_t code = fix & 3;
       if (have && ((byte >> ap.shift) & 3u) != (uint32_t)code)
       {
         nbad++;
