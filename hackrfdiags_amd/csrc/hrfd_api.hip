@@ -441,9 +441,9 @@ extern "C" int hrfd_rx_reset_demod(hrfd_rx *h, uint32_t channel, int mode)
 // the speculation-failure / replay path can be exercised.
 extern "C" int hrfd_rx_debug_set_warm(hrfd_rx *h, int warm)
 {
-  if (h == nullptr || warm < 0 || warm > kWarm)
+  if (h == nullptr || warm < 0 || warm > kWarm || (warm & 1))
   {
-    return fail(HRFD_EINVAL, "hrfd_rx_debug_set_warm: 0..%d", kWarm);
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_set_warm: even, 0..%d", kWarm);
   }
   h->warm = warm;
   return HRFD_OK;
@@ -629,12 +629,16 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   // 64 de-emphasis tiles end at n256; tile 0 is sacrificial, tile 1 must start at
   // or before the first history sample the integer stages read (-kNeedHist).
   int tile = (int)((n256 + kNeedHist + 62) / 63);
-  if ((tile & 1) == 0)
+  while ((tile & 3) != 2)
   {
-    tile++;                                              // odd lane stride: no LDS bank conflicts
+    // tile = 2 (mod 4): every lane's range starts on an even dword (64-bit LDS accesses in the
+    // recurrence) and lanes 0..31 fall into 32 different 8-byte banks (tile / 2 is odd)
+    tile++;
   }
   const int origin = (int)n256 - 64 * tile;
-  const int hal = ((h->warm - origin) + 63) / 64 * 64;
+  // history produced in front of the block: tile 1's warm-up is the earliest sample anybody
+  // reads (tile 0 is never materialised: its lane shadows tile 1)
+  const int hal = ((h->warm - (origin + tile)) + 63) / 64 * 64;
   if (hal > kMaxHal)
   {
     return fail(HRFD_EINVAL, "internal: history %d exceeds %d", hal, kMaxHal);

@@ -17,7 +17,7 @@ constexpr int kWaves = kThreads / 64;
 constexpr int kMaxN256 = 16384;               // 262144-byte block
 constexpr int kWarm = 512;                    // de-emphasis warm-up (P(miss) ~1e-5 per tile)
 constexpr int kHist = 704;                    // exact history kept in front of a block (>= 644)
-constexpr int kMaxHal = 1600;                 // >= kWarm - origin for every block size, multiple of 64
+constexpr int kMaxHal = 1664;                 // >= kWarm - origin for every block size, multiple of 64
 constexpr int kNeedHist = 644;                // first history sample the integer stages read
 constexpr int kMaxNV = kMaxN256 + kMaxHal;    // floats of the v/y stream in LDS
 // arithmetic atan2 (theta_arith in hrfd_rx_kernels.hip)

@@ -467,65 +467,57 @@ __device__ __forceinline__ float iir_run(const uint32_t *in, uint32_t *out, cons
 {
   const float a1 = DEEMPH_A1;
   constexpr int U = HRFD_IIR_U;                        // steps per prefetched group
+  static_assert(U % 2 == 0, "groups are read as 64-bit pairs");
   auto step = [&](float vv, int k) {
     const float r = a1 * y;
     const float yn = vv - r;
     y = (!SKIP || k >= kskip) ? yn : y;
   };
+  // Every lane's range starts on an even dword (rx_launch keeps the tile length, the warm-up
+  // and the history even) and groups start at multiples of U: 64-bit LDS accesses, half as
+  // many LDS instructions between the dependent multiply-subtract pairs.
+  auto load_group = [&](float (&g)[U], int at) {
+    const uint2 *p2 = reinterpret_cast<const uint2 *>(in + at);
+#pragma unroll
+    for (int j = 0; j < U / 2; j++)
+    {
+      const uint2 w = p2[j];
+      g[2 * j] = u2f(w.x);
+      g[2 * j + 1] = u2f(w.y);
+    }
+  };
+  auto run_group = [&](const float (&g)[U], int at) {
+    uint2 *o2 = reinterpret_cast<uint2 *>(out + at);
+#pragma unroll
+    for (int j = 0; j < U / 2; j++)
+    {
+      step(g[2 * j], at + 2 * j);
+      const float y0 = y;
+      step(g[2 * j + 1], at + 2 * j + 1);
+      if (STORE)
+      {
+        o2[j] = make_uint2(f2u(y0), f2u(y));
+      }
+    }
+  };
   int k = 0;
   float ga[U], gb[U];
   if (count >= U)
   {
-#pragma unroll
-    for (int j = 0; j < U; j++)
-    {
-      ga[j] = u2f(in[j]);
-    }
+    load_group(ga, 0);
   }
-  // two groups per iteration: (ga: steps k..k+7, gb: k+8..k+15)
+  // two groups per iteration: (ga: steps k..k+U-1, gb: k+U..k+2U-1)
   for (; k + 3 * U <= count; k += 2 * U)
   {
-#pragma unroll
-    for (int j = 0; j < U; j++)
-    {
-      gb[j] = u2f(in[k + U + j]);
-    }
-#pragma unroll
-    for (int j = 0; j < U; j++)
-    {
-      step(ga[j], k + j);
-      if (STORE)
-      {
-        out[k + j] = f2u(y);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < U; j++)
-    {
-      ga[j] = u2f(in[k + 2 * U + j]);
-    }
-#pragma unroll
-    for (int j = 0; j < U; j++)
-    {
-      step(gb[j], k + U + j);
-      if (STORE)
-      {
-        out[k + U + j] = f2u(y);
-      }
-    }
+    load_group(gb, k + U);
+    run_group(ga, k);
+    load_group(ga, k + 2 * U);
+    run_group(gb, k + U);
   }
-  // here ga holds steps k..k+7 when k + U <= count
+  // here ga holds steps k..k+U-1 when k + U <= count
   if (k + U <= count)
   {
-#pragma unroll
-    for (int j = 0; j < U; j++)
-    {
-      step(ga[j], k + j);
-      if (STORE)
-      {
-        out[k + j] = f2u(y);
-      }
-    }
+    run_group(ga, k);
     k += U;
   }
   for (; k < count; k++)
@@ -554,6 +546,7 @@ struct StreamCtx
   int qoff;                      // FIR modes: int16 index of the Q rail inside lds (I rail at 0)
   const uint8_t *atc;            // arithmetic atan2: LDS copies of the correction bytes and of 1/a
   const float *ati;
+  uint4 tab;                     // this thread's 16 bytes of them, loaded at kernel entry (in flight)
   bool first;
 };
 
@@ -633,6 +626,25 @@ constexpr int kDepth = HRFD_DEPTH;     // raw chunks in flight per wave
 #endif
 constexpr int kLook = HRFD_LOOK;    // chunks between issuing a table gather and using its result (< kDepth)
 
+// The atan2 correction bytes and reciprocals (8.5 KiB, L2-resident) were requested at kernel
+// entry, one 16-byte piece per thread; they go to LDS once the first raw chunks of the run
+// are in flight, so that their latency and the raw stream's first miss overlap.  Every wave of
+// the workgroup calls this exactly once (it contains the barrier).
+__device__ __forceinline__ void publish_atan_tables(const StreamCtx &X)
+{
+  static_assert(kCorrBytes / 16 + kInvEntries / 4 <= kThreads, "one copy per thread");
+  const int tid = threadIdx.x;
+  if (tid < kCorrBytes / 16)
+  {
+    reinterpret_cast<uint4 *>(const_cast<uint8_t *>(X.atc))[tid] = X.tab;
+  }
+  else if (tid < kCorrBytes / 16 + kInvEntries / 4)
+  {
+    reinterpret_cast<uint4 *>(const_cast<float *>(X.ati))[tid - kCorrBytes / 16] = X.tab;
+  }
+  __syncthreads();
+}
+
 // calls f(std::integral_constant<int, r>) for the run-time residue r in [0, sizeof...(Rs))
 template <typename F, int... Rs>
 __device__ __forceinline__ void dispatch_residue(const int r, F &f, std::integer_sequence<int, Rs...>)
@@ -653,6 +665,10 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   const int cbeg = REPAIR ? c0 - 1 : c0;
   if (cbeg >= c1)
   {
+    if (ARITH && !REPAIR)
+    {
+      publish_atan_tables(X);
+    }
     return;
   }
   FeCarry fc = {0x00800080u, 0x00800080u, 0x00800080u};
@@ -794,6 +810,10 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   {
     q[k] = load_chunk<S256>(X, cbeg + k);
     th[k] = 0.0f;
+  }
+  if (ARITH && !REPAIR)
+  {
+    publish_atan_tables(X);
   }
   // prologue: LOOK fronts, nothing finished yet
 #pragma unroll
@@ -1012,20 +1032,21 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   X.first = first;
   X.atc = atcorr;
   X.ati = atinv;
+  // the dBFS table (128 entries are reachable) rides in two registers per lane, so that the
+  // squelch decision after phase A does not wait for a global load
+  const int dbfs_lo = P.dbfs[lane], dbfs_hi = P.dbfs[64 + lane];
+  X.tab = make_uint4(0u, 0u, 0u, 0u);
   if (ARITH)
   {
-    // 8.5 KiB of atan2 correction bytes and reciprocals, L2-resident: one 16-byte copy per thread
-    static_assert(kCorrBytes / 16 + kInvEntries / 4 <= kThreads, "one copy per thread");
+    // request this thread's piece of the atan2 tables now; produce_stream publishes them to LDS
     if (tid < kCorrBytes / 16)
     {
-      reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr)[tid];
+      X.tab = reinterpret_cast<const uint4 *>(P.at_corr)[tid];
     }
     else if (tid < kCorrBytes / 16 + kInvEntries / 4)
     {
-      const int j = tid - kCorrBytes / 16;
-      reinterpret_cast<uint4 *>(atinv)[j] = reinterpret_cast<const uint4 *>(P.at_inv)[j];
+      X.tab = reinterpret_cast<const uint4 *>(P.at_inv)[tid - kCorrBytes / 16];
     }
-    __syncthreads();
   }
   const int8_t *blk = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)b * P.block_bytes;
 
@@ -1083,7 +1104,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   }
   const uint32_t mean_mag = total / (uint32_t)n256;      // SignalDetector.cc:255
   // DbfsCalculator::convertMagnitudeToDbFs (:111-147) with a 7-bit full scale
-  int32_t dbfs = P.dbfs[min(mean_mag, 127u)] - 42;
+  const int ms = __builtin_amdgcn_readfirstlane((int)min(mean_mag, 127u));
+  int32_t dbfs = ((ms < 64) ? __builtin_amdgcn_readlane(dbfs_lo, ms) : __builtin_amdgcn_readlane(dbfs_hi, ms - 64)) - 42;
   dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
   const bool present = dbfs >= cfg.threshold;
   // Squelch::run + SignalTracker::run: allowed = present || tracking.  For b > 0
@@ -1117,9 +1139,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   // y when the stream start lies inside its window), then its own tile.  A lane
   // whose warmed-up y[s-1] is not bit-identical to its left neighbour's final y
   // has not re-synchronised: its tile is re-derived and re-run from the true
-  // value (rare: DESIGN.md gives the measured rates).  Tile 0 is sacrificial (it
-  // lies before the first history sample anybody reads) so that the chain is
-  // anchored on a lane with warm + T samples behind it.
+  // value (rare: DESIGN.md gives the measured rates).  Tile 0 would lie before the
+  // first history sample anybody reads (-kNeedHist is in tile 1): it is skipped.
   const int T = P.tile;
   const int origin = P.origin;
   const int warm = P.warm;
@@ -1170,7 +1191,9 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
     }
     else if (!(ablate(P, 2)))                           // (flag 2: TIMING EXPERIMENT ONLY, skip phase B)
     {
-      const int s = origin + lane * T;
+      // tile 0 would lie before the first history sample anybody reads: it is not
+      // materialised, lane 0 shadows lane 1 (same reads, same values written)
+      const int s = origin + max(lane, 1) * T;
       float y = first ? st->wb_y : 0.0f;
       // In a first block positions n < 0 do not exist: those steps are skipped
       // (y keeps the carried value).  kskip = steps to skip, counted from the
@@ -1191,10 +1214,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
         y_spec = y;
         y = iir_run<true, false>(yp, yp, T, 0, y);
       }
-      // Anchors: lane 0 (tile 0 is sacrificial; the chain behind it is checked
+      // Anchors: lanes 0 and 1 (tile 1 is the first one; the chain behind it is checked
       // across blocks by k_rx_epilogue) and, in a first block, lanes whose
       // window contains the true stream state (s - warm <= 0).
-      const bool anchored = (lane == 0) || (first && (s - warm) <= 0);
+      const bool anchored = (lane <= 1) || (first && (s - warm) <= 0);
       const float y_left = u2f(shr1(f2u(y), f2u(y_spec)));
       unsigned long long bad = __ballot(!anchored && !same_trajectory(y_left, y_spec));
       uint32_t repairs = 0;
