@@ -126,7 +126,9 @@ def bench_ssbmod(args, api, device, rank, world, dist):
     gen.manual_seed(7 + rank)
     pcm = torch.randint(-32768, 32768, (C, n), dtype=torch.int16, device=device, generator=gen)
     out = torch.empty((C, 512 * n), dtype=torch.int8, device=device)
-    m = api.Mod(api.MOD_SSB, C, device=device.index)
+    kind = {"ssbmod": api.MOD_SSB, "ammod": api.MOD_AM, "fmmod": api.MOD_FM}[args.workload]
+    kname = {"ssbmod": "SSB", "ammod": "AM", "fmmod": "FM"}[args.workload]
+    m = api.Mod(kind, C, device=device.index)
     stream = torch.cuda.Stream(device=device)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -160,15 +162,16 @@ def bench_ssbmod(args, api, device, rank, world, dist):
     achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
     if rank == 0:
         print(json.dumps({
-            "metric": "IQ MSamples/s modulated (8 kS/s PCM -> 2.048 MS/s int8 IQ, SSB) per GPU; % HBM roofline",
+            "metric": f"IQ MSamples/s modulated (8 kS/s PCM -> 2.048 MS/s int8 IQ, {kname}) per GPU; % HBM roofline",
             "value": round(value, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int16 PCM -> Q15 int32 -> int8 IQ", "data": "synthetic",
-            "config": {"workload": f"{C} SSB modulator channels per GPU (BASELINE config 5), {B} blocks of 512 PCM "
+            "config": {"workload": f"{C} {kname} modulator channels per GPU (BASELINE config 5), {B} blocks of 512 PCM "
                                    f"samples per step, 8-stage x256 half-band interpolator", "channels_per_gpu": C,
                        "blocks_per_step": B},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "hrfd::k_mod<1>",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "hrfd::k_mod<1>" if args.workload == "ssbmod" else "k_am_rails / k_fm_phase + k_fm_rails, then hrfd::k_mod<100>",
                          "kernel_ms_mean": round(mean_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
         }), flush=True)
     if dist is not None:
@@ -200,7 +203,7 @@ def main():
     ap.add_argument("--channels", type=int, default=256, help="channels per GPU (BASELINE config 2)")
     ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
     ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")
-    ap.add_argument("--workload", choices=["wbfm", "mixed", "ssbmod"], default="wbfm",
+    ap.add_argument("--workload", choices=["wbfm", "mixed", "ssbmod", "ammod", "fmmod"], default="wbfm",
                     help="wbfm = BASELINE config 2 (the headline); mixed = config 3 (AM+FM+WBFM+SSB bank, "
                          "per-mode dispatch); ssbmod = config 5 (SSB modulator, 8-stage x256 interpolator)")
     ap.add_argument("--scatter", action="store_true",
@@ -223,7 +226,7 @@ def main():
 
     from hackrfdiags_amd import api, shard
 
-    if args.workload == "ssbmod":
+    if args.workload in ("ssbmod", "ammod", "fmmod"):
         return bench_ssbmod(args, api, device, rank, world, dist)
 
     C, B = args.channels, args.blocks

@@ -100,6 +100,8 @@ def load() -> C.CDLL:
     L.hrfd_mod_destroy.argtypes = [_vp]
     L.hrfd_mod_reset.argtypes = [_vp, C.c_uint32]
     L.hrfd_mod_set_sideband.argtypes = [_vp, C.c_uint32, C.c_int]
+    L.hrfd_mod_set_modulation_index.argtypes = [_vp, C.c_uint32, C.c_float]
+    L.hrfd_mod_set_deviation.argtypes = [_vp, C.c_uint32, C.c_float]
     L.hrfd_mod_process.argtypes = [_vp, _vp, C.c_uint32, _vp, _u32p]
     L.hrfd_mod_process_device.argtypes = [_vp, _vp, C.c_uint32, _vp, _vp]
     L.hrfd_mod_sync.argtypes = [_vp]

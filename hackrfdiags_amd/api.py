@@ -193,7 +193,7 @@ class Demod:
         return pcm if self.n > 1 else pcm[0]
 
 
-MOD_SSB, MOD_INTERP = 1, 2
+MOD_SSB, MOD_INTERP, MOD_AM, MOD_FM = 1, 2, 3, 4
 
 
 class Mod:
@@ -220,8 +220,18 @@ class Mod:
     def set_sideband(self, lsb, channel=ALL):
         check(self.L.hrfd_mod_set_sideband(self.h, channel, int(bool(lsb))), "hrfd_mod_set_sideband")
 
+    def set_modulation_index(self, index, channel=ALL):
+        check(self.L.hrfd_mod_set_modulation_index(self.h, channel, float(index)), "hrfd_mod_set_modulation_index")
+
+    def set_deviation(self, deviation_hz, channel=ALL):
+        check(self.L.hrfd_mod_set_deviation(self.h, channel, float(deviation_hz)), "hrfd_mod_set_deviation")
+
+    def set_param(self, value, channel=ALL):
+        """the kind's parameter: AM modulation index / FM deviation (mirrors tests.reflib._Mod)"""
+        (self.set_modulation_index if self.kind == MOD_AM else self.set_deviation)(value, channel)
+
     def process(self, pcm):
-        """SSB: int16 [C, n]; INTERP: int16 [C, 2n] IQ pairs -> int8 [C, 512 n]"""
+        """SSB / AM / FM: int16 [C, n]; INTERP: int16 [C, 2n] IQ pairs -> int8 [C, 512 n]"""
         pcm = np.ascontiguousarray(pcm, dtype=np.int16).reshape(self.n, -1)
         n = pcm.shape[1] // (2 if self.kind == MOD_INTERP else 1)
         out = np.zeros((self.n, 512 * n), dtype=np.int8)
@@ -279,6 +289,12 @@ class Engine:
 
     def interp(self):
         return Mod(MOD_INTERP, 1)
+
+    def ammod(self):
+        return Mod(MOD_AM, 1)
+
+    def fmmod(self):
+        return Mod(MOD_FM, 1)
 
     def rx(self):
         return SingleChannelRx()

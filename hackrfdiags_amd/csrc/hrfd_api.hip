@@ -1122,6 +1122,13 @@ struct hrfd_mod
   bool lsb_dirty = true;
   std::mutex mu;
   std::vector<uint32_t> resets;
+  // AM / FM: per-channel parameter (modulation index / deviation), FM phase accumulators, and
+  // the baseband rails of a call
+  float *d_param = nullptr, *d_acc = nullptr, *d_phase = nullptr;
+  int16_t *d_rails = nullptr;
+  size_t cap_phase = 0, cap_rails = 0;
+  std::vector<float> h_param;
+  bool param_dirty = true;
   // staging for the host entry
   int16_t *d_in = nullptr;
   int8_t *d_out = nullptr;
@@ -1136,7 +1143,7 @@ static int mod_free(hrfd_mod *h)
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->d_tail[0], h->d_tail[1], h->d_lsb, h->d_in, h->d_out};
+  void *ptrs[] = {h->d_tail[0], h->d_tail[1], h->d_lsb, h->d_in, h->d_out, h->d_param, h->d_acc, h->d_phase, h->d_rails};
   for (void *p : ptrs)
   {
     if (p) (void)hipFree(p);
@@ -1148,9 +1155,10 @@ static int mod_free(hrfd_mod *h)
 
 extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out)
 {
-  if (out == nullptr || n_channels == 0 || (kind != HRFD_MOD_SSB && kind != HRFD_MOD_INTERP))
+  if (out == nullptr || n_channels == 0 ||
+      (kind != HRFD_MOD_SSB && kind != HRFD_MOD_INTERP && kind != HRFD_MOD_AM && kind != HRFD_MOD_FM))
   {
-    return fail(HRFD_EINVAL, "hrfd_mod_create: kind must be HRFD_MOD_SSB or HRFD_MOD_INTERP, n_channels > 0");
+    return fail(HRFD_EINVAL, "hrfd_mod_create: kind must be HRFD_MOD_SSB, _INTERP, _AM or _FM, n_channels > 0");
   }
   *out = nullptr;
   if (hrfd_device_count() <= 0)
@@ -1174,6 +1182,11 @@ extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_m
   if (e == hipSuccess) e = hipMalloc((void **)&h->d_lsb, n_channels);
   if (e == hipSuccess) e = hipMemset(h->d_tail[0], 0, tail_bytes);   // zero pipelines == resetModulator()
   if (e == hipSuccess) e = hipMemset(h->d_tail[1], 0, tail_bytes);
+  // AmModulator.cc:218 modulationIndex = 0.8; FmModulator.cc:218 frequencyDeviation = 3500, Nco phase 0
+  h->h_param.assign(n_channels, kind == HRFD_MOD_FM ? 3500.0f : (float)0.8);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_param, sizeof(float) * n_channels);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_acc, sizeof(float) * n_channels);
+  if (e == hipSuccess) e = hipMemset(h->d_acc, 0, sizeof(float) * n_channels);
   if (e != hipSuccess)
   {
     const int rc = fail(HRFD_ENOMEM, "hrfd_mod_create: %s", hipGetErrorString(e));
@@ -1215,6 +1228,45 @@ extern "C" int hrfd_mod_set_sideband(hrfd_mod *h, uint32_t channel, int lsb)
   return HRFD_OK;
 }
 
+// AmModulator::setModulationIndex (AmModulator.cc:329-336): accepted when 0 <= index <= 1
+extern "C" int hrfd_mod_set_modulation_index(hrfd_mod *h, uint32_t channel, float index)
+{
+  if (h == nullptr || h->kind != HRFD_MOD_AM || (channel != HRFD_ALL_CHANNELS && channel >= h->n_channels))
+  {
+    return fail(HRFD_EINVAL, "hrfd_mod_set_modulation_index: needs an AM modulator handle and a valid channel");
+  }
+  std::lock_guard<std::mutex> g(h->mu);
+  for (uint32_t c = 0; c < h->n_channels; c++)
+  {
+    if ((channel == HRFD_ALL_CHANNELS || channel == c) && (index >= 0) && (index <= 1))
+    {
+      h->h_param[c] = index;
+    }
+  }
+  h->param_dirty = true;
+  return HRFD_OK;
+}
+
+// FmModulator::setFrequencyDeviation (FmModulator.cc:336-346).  As in the reference the range
+// test looks at the CURRENT deviation, not at the new one (kept: it is the observable behaviour).
+extern "C" int hrfd_mod_set_deviation(hrfd_mod *h, uint32_t channel, float deviation)
+{
+  if (h == nullptr || h->kind != HRFD_MOD_FM || (channel != HRFD_ALL_CHANNELS && channel >= h->n_channels))
+  {
+    return fail(HRFD_EINVAL, "hrfd_mod_set_deviation: needs an FM modulator handle and a valid channel");
+  }
+  std::lock_guard<std::mutex> g(h->mu);
+  for (uint32_t c = 0; c < h->n_channels; c++)
+  {
+    if ((channel == HRFD_ALL_CHANNELS || channel == c) && (h->h_param[c] >= 0) && (h->h_param[c] <= 3500))
+    {
+      h->h_param[c] = deviation;
+    }
+  }
+  h->param_dirty = true;
+  return HRFD_OK;
+}
+
 extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32_t n_per_channel,
                                        int8_t *d_iq_out, void *stream)
 {
@@ -1231,6 +1283,12 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
       HIP_TRY(hipStreamSynchronize(s));
       HIP_TRY(hipMemcpy(h->d_lsb, h->h_lsb.data(), h->n_channels, hipMemcpyHostToDevice));
       h->lsb_dirty = false;
+    }
+    if (h->param_dirty)
+    {
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipMemcpy(h->d_param, h->h_param.data(), sizeof(float) * h->n_channels, hipMemcpyHostToDevice));
+      h->param_dirty = false;
     }
     for (uint32_t ch : h->resets)
     {
@@ -1257,7 +1315,39 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
   M.n_channels = h->n_channels;
   const uint32_t tiles = (n_per_channel + kModTile - 1) / kModTile;
   const uint32_t grid = h->n_channels * tiles;
-  if (h->kind == HRFD_MOD_SSB)
+  if (h->kind == HRFD_MOD_AM || h->kind == HRFD_MOD_FM)
+  {
+    // baseband rails first (k_am_rails / k_fm_phase + k_fm_rails), then the shared x256 cascade
+    const size_t samples = (size_t)n_per_channel * h->n_channels;
+    int rc;
+    if (samples * 4 > h->cap_rails || (h->kind == HRFD_MOD_FM && samples * 4 > h->cap_phase))
+    {
+      HIP_TRY(hipStreamSynchronize(s));
+      if ((rc = grow((void **)&h->d_rails, &h->cap_rails, samples * 4)) != HRFD_OK) return rc;
+      if (h->kind == HRFD_MOD_FM && (rc = grow((void **)&h->d_phase, &h->cap_phase, samples * 4)) != HRFD_OK) return rc;
+    }
+    BaseParams B;
+    B.pcm = d_pcm;
+    B.rails = h->d_rails;
+    B.param = h->d_param;
+    B.acc = h->d_acc;
+    B.phase = h->d_phase;
+    B.n = n_per_channel;
+    B.n_channels = h->n_channels;
+    const uint32_t gs = (uint32_t)((samples + 255) / 256);
+    if (h->kind == HRFD_MOD_AM)
+    {
+      hipLaunchKernelGGL(k_am_rails, dim3(gs), dim3(256), 0, s, B);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_fm_phase, dim3((h->n_channels + 63) / 64), dim3(64), 0, s, B);
+      hipLaunchKernelGGL(k_fm_rails, dim3(gs), dim3(256), 0, s, B);
+    }
+    M.in = h->d_rails;
+    hipLaunchKernelGGL(k_mod<HRFD_MOD_RAILS>, dim3(grid), dim3(kModThreads), 0, s, M);
+  }
+  else if (h->kind == HRFD_MOD_SSB)
   {
     hipLaunchKernelGGL(k_mod<HRFD_MOD_SSB>, dim3(grid), dim3(kModThreads), 0, s, M);
   }

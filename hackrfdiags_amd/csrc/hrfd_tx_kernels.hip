@@ -21,6 +21,7 @@
 
 namespace hrfd {
 
+constexpr int HRFD_MOD_RAILS = 100;     // internal kind: int16 (I,Q) rails in, modulator tables
 constexpr int kModTile = 32;            // input samples per workgroup
 constexpr int kModThreads = 256;
 constexpr int kModTail = 64;            // carried input history per channel (>= 54)
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   __shared__ int16_t src[2][kModTail + kModTile];         // stage-0 source with history
   __shared__ int16_t r[2][kRail];                         // the two rails, stages 0..5
 
+  // INTERP and RAILS take int16 (I,Q) pairs; RAILS (the AM / FM modulators' baseband, produced by
+  // k_am_rails / k_fm_rails) runs them through the modulators' stage-1 table, INTERP through
+  // interpolateSignal's own
+  constexpr bool kPairs = (KIND == HRFD_MOD_INTERP) || (KIND == HRFD_MOD_RAILS);
   const uint32_t tiles = (M.n + kModTile - 1) / kModTile;
   const uint32_t c = blockIdx.x / tiles;
   const uint32_t tile = blockIdx.x - c * tiles;
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   const int tid = threadIdx.x;
   const int t0 = (int)tile * kModTile;                    // first input sample of the tile
   const int n = (int)M.n;
-  const int16_t *in = M.in + (size_t)c * M.n * (KIND == HRFD_MOD_INTERP ? 2 : 1);
+  const int16_t *in = M.in + (size_t)c * M.n * (kPairs ? 2 : 1);
   const int16_t *tin = M.tail_in + (size_t)c * 4 * kModTail;
 
   // ---- stage-0 source: scaled PCM (SSB) or the IQ pair (INTERP), history first
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
     }
     else if (g < n)
     {
-      if (KIND == HRFD_MOD_INTERP)
+      if (kPairs)
       {
         a = in[2 * g];
         b = in[2 * g + 1];
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
         a = tin[o];
         b = tin[kModTail + o];
       }
-      else if (KIND == HRFD_MOD_INTERP)
+      else if (kPairs)
       {
         a = in[2 * g];
         b = in[2 * g + 1];
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       iv = tin[2 * kModTail + kModTail + (t0 + j)];
       qv = tin[3 * kModTail + kModTail + (t0 + j)];
     }
-    else if (KIND == HRFD_MOD_INTERP)
+    else if (kPairs)
     {
       iv = s0[0];
       qv = src[1][kModTail + j];
@@ -324,10 +329,95 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 
 template __global__ void k_mod<HRFD_MOD_SSB>(const ModParams);
 template __global__ void k_mod<HRFD_MOD_INTERP>(const ModParams);
+template __global__ void k_mod<HRFD_MOD_RAILS>(const ModParams);
 
 } // namespace hrfd
 
 namespace hrfd {
+
+// ---- AM / FM modulator basebands ---------------------------------------
+// AmModulator::modulateSignal (AmModulator.cc:574-612): I = Q = (int16)(((pcm/32768)*m + 1)/2*128*250),
+// float operations in that order.  One thread per sample; rails [C][2n] int16 (I,Q pairs).
+struct BaseParams
+{
+  const int16_t *pcm;       // [C][n]
+  int16_t *rails;           // [C][2n]
+  const float *param;       // [C] modulation index (AM) / frequency deviation in Hz (FM)
+  float *acc;               // [C] FM: Nco phase accumulator (persists across calls)
+  float *phase;             // [C][n] FM scratch: phase of every sample
+  uint32_t n, n_channels;
+};
+
+__global__ void k_am_rails(const BaseParams B)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B.n * B.n_channels)
+  {
+    return;
+  }
+  const uint32_t c = (uint32_t)(t / B.n);
+  float signal = (float)B.pcm[t] / 32768.0f;
+  signal = signal * B.param[c];
+  signal = signal + 1.0f;
+  signal = signal / 2.0f;
+  signal = signal * 128.0f;
+  signal = signal * 250.0f;
+  int v = (int)signal;                                   // (int16_t) with x86 semantics: |signal| < 2^15 here
+  v = (int)(short)v;
+  reinterpret_cast<uint32_t *>(B.rails)[t] = ((uint32_t)v & 0xffffu) * 0x00010001u;
+}
+
+// FmModulator::modulateSignal (FmModulator.cc:586-627).  Pass 1, one thread per channel: the
+// Nco phase recurrence (PhaseAccumulator.cc:95-107,157-181: step = (float)((2*M_PI*f)/fs) with
+// fs = 8000, float accumulate, wrap with double compares and double subtraction) -- exact.
+__global__ void k_fm_phase(const BaseParams B)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B.n_channels)
+  {
+    return;
+  }
+  const double pi = 3.14159265358979323846, two_pi = 6.283185307179586476925286766559;
+  const float dev = B.param[c];
+  float acc = B.acc[c];
+  const int16_t *pcm = B.pcm + (size_t)c * B.n;
+  float *ph = B.phase + (size_t)c * B.n;
+  for (uint32_t k = 0; k < B.n; k++)
+  {
+    float f = dev * (float)pcm[k];
+    f = f / 32768.0f;
+    const float step = (float)((two_pi * (double)f) / (double)8000.0f);
+    ph[k] = acc;
+    acc = acc + step;
+    while ((double)acc > pi)
+    {
+      acc = (float)((double)acc - two_pi);
+    }
+    while ((double)acc < -pi)
+    {
+      acc = (float)((double)acc + two_pi);
+    }
+  }
+  B.acc[c] = acc;
+}
+
+// Pass 2, one thread per sample: Nco::run (Nco.cc:186-199) calls libm cosf/sinf; here the
+// double-precision cos/sin rounded to float (within 1 ulp of glibc's, so the int16 rails and the
+// int8 output are within 1 LSB: the float-trig tolerance of BASELINE.json), times 16000, (int16_t).
+__global__ void k_fm_rails(const BaseParams B)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B.n * B.n_channels)
+  {
+    return;
+  }
+  const float phase = B.phase[t];
+  float iv = (float)cos((double)phase), qv = (float)sin((double)phase);
+  iv = iv * 16000.0f;
+  qv = qv * 16000.0f;
+  const int i16 = (int)(short)(int)iv, q16 = (int)(short)(int)qv;
+  reinterpret_cast<uint32_t *>(B.rails)[t] = ((uint32_t)i16 & 0xffffu) | ((uint32_t)q16 << 16);
+}
 
 // =============================================================================
 //  Nco (Nco/Nco.cc, Nco/PhaseAccumulator.cc): one oscillator per thread

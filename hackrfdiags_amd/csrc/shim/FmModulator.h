@@ -1,0 +1,34 @@
+// FmModulator.h -- drop-in replacement header: same class name and public interface
+// as radioDiags/FmModulator/FmModulator.h:20-33 of the reference, implemented over
+// the C ABI of libhrfd.so (hrfd_mod_*, include/hrfd.h).
+#ifndef HRFD_SHIM_FMMODULATOR_H
+#define HRFD_SHIM_FMMODULATOR_H
+
+#include <stdint.h>
+
+#include "hrfd.h"
+
+class FmModulator
+{
+  public:
+
+  FmModulator(void);
+  ~FmModulator(void);
+
+  void resetModulator(void);
+  void setFrequencyDeviation(float deviaton);
+
+  void acceptData(int16_t *bufferPtr,
+                  uint32_t bufferLength,
+                  int8_t *outputBufferPtr,
+                  uint32_t *outputBufferLengthPtr);
+
+  void displayInternalInformation(void);
+
+  private:
+
+  float frequencyDeviation;
+  hrfd_mod *handle;
+};
+
+#endif

@@ -17,6 +17,8 @@
 #include "SsbDemodulator.h"
 #include "IqDataProcessor.h"
 #include "SsbModulator.h"
+#include "AmModulator.h"
+#include "FmModulator.h"
 #include "Nco.h"
 
 // symbols of the host application the reference code also expects
@@ -432,6 +434,122 @@ void SsbModulator::displayInternalInformation(void)
   nprintf(stderr, "SSB Modulator Internal Information (libhrfd, MI355X)\n");
   nprintf(stderr, "--------------------------------------------\n");
   nprintf(stderr, "Modulation Mode          : %s\n", lsbModulationMode ? "LSB" : "USB");
+}
+
+// ---------------------------------------------------------------- AmModulator
+AmModulator::AmModulator(void)
+{
+  modulationIndex = 0.8;                                 // AmModulator.cc:218
+  handle = NULL;
+}
+
+AmModulator::~AmModulator(void)
+{
+  if (handle != NULL)
+  {
+    hrfd_mod_destroy(handle);
+  }
+}
+
+void AmModulator::resetModulator(void)
+{
+  if (handle != NULL)
+  {
+    int rc = hrfd_mod_reset(handle, 0);
+    if (rc != HRFD_OK) fatal("hrfd_mod_reset", rc);
+  }
+}
+
+void AmModulator::setModulationIndex(float modulationIndex)
+{
+  if ((modulationIndex >= 0) && (modulationIndex <= 1))  // AmModulator.cc:332
+  {
+    this->modulationIndex = modulationIndex;
+  }
+  if (handle != NULL) hrfd_mod_set_modulation_index(handle, 0, this->modulationIndex);
+}
+
+void AmModulator::acceptData(int16_t *bufferPtr,
+                             uint32_t bufferLength,
+                             int8_t *outputBufferPtr,
+                             uint32_t *outputBufferLengthPtr)
+{
+  int rc;
+  if (handle == NULL)
+  {
+    rc = hrfd_mod_create(HRFD_MOD_AM, 1, -1, &handle);
+    if (rc != HRFD_OK) fatal("hrfd_mod_create", rc);
+    hrfd_mod_set_modulation_index(handle, 0, modulationIndex);
+  }
+  rc = hrfd_mod_process(handle, bufferPtr, bufferLength, outputBufferPtr, outputBufferLengthPtr);
+  if (rc != HRFD_OK) fatal("hrfd_mod_process", rc);
+}
+
+void AmModulator::displayInternalInformation(void)
+{
+  nprintf(stderr, "\n--------------------------------------------\n");
+  nprintf(stderr, "AM Modulator Internal Information (libhrfd, MI355X)\n");
+  nprintf(stderr, "--------------------------------------------\n");
+  nprintf(stderr, "Modulator Index          : %f\n", modulationIndex);
+}
+
+// ---------------------------------------------------------------- FmModulator
+FmModulator::FmModulator(void)
+{
+  frequencyDeviation = 3500;                             // FmModulator.cc:218
+  handle = NULL;
+}
+
+FmModulator::~FmModulator(void)
+{
+  if (handle != NULL)
+  {
+    hrfd_mod_destroy(handle);
+  }
+}
+
+void FmModulator::resetModulator(void)
+{
+  if (handle != NULL)
+  {
+    int rc = hrfd_mod_reset(handle, 0);
+    if (rc != HRFD_OK) fatal("hrfd_mod_reset", rc);
+  }
+}
+
+void FmModulator::setFrequencyDeviation(float deviaton)
+{
+  // FmModulator.cc:339 tests the member, not the argument: kept
+  if ((frequencyDeviation >= 0) && (frequencyDeviation <= 3500))
+  {
+    this->frequencyDeviation = deviaton;
+  }
+  if (handle != NULL) hrfd_mod_set_deviation(handle, 0, deviaton);
+}
+
+void FmModulator::acceptData(int16_t *bufferPtr,
+                             uint32_t bufferLength,
+                             int8_t *outputBufferPtr,
+                             uint32_t *outputBufferLengthPtr)
+{
+  int rc;
+  if (handle == NULL)
+  {
+    rc = hrfd_mod_create(HRFD_MOD_FM, 1, -1, &handle);
+    if (rc != HRFD_OK) fatal("hrfd_mod_create", rc);
+    // replay the setter history into the fresh handle: one call reproduces any reachable value
+    if (frequencyDeviation != 3500) hrfd_mod_set_deviation(handle, 0, frequencyDeviation);
+  }
+  rc = hrfd_mod_process(handle, bufferPtr, bufferLength, outputBufferPtr, outputBufferLengthPtr);
+  if (rc != HRFD_OK) fatal("hrfd_mod_process", rc);
+}
+
+void FmModulator::displayInternalInformation(void)
+{
+  nprintf(stderr, "\n--------------------------------------------\n");
+  nprintf(stderr, "FM Modulator Internal Information (libhrfd, MI355X)\n");
+  nprintf(stderr, "--------------------------------------------\n");
+  nprintf(stderr, "Frequency Deviation:      : %fHz\n", frequencyDeviation);
 }
 
 // ---------------------------------------------------------------- Nco

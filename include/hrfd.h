@@ -151,10 +151,20 @@ int hrfd_demod_process(hrfd_demod *h, const int8_t *iq256k, uint32_t bytes_per_c
  */
 #define HRFD_MOD_SSB    1
 #define HRFD_MOD_INTERP 2
+/* kinds HRFD_MOD_AM / HRFD_MOD_FM replace AmModulator::acceptData (AmModulator.cc:381-395,
+ * modulateSignal :574-612) and FmModulator::acceptData (FmModulator.cc:393-407, modulateSignal
+ * :586-627: an 8 kS/s Nco driven by deviation * pcm / 32768), same x256 cascade and tables;
+ * PCM in, as for SSB.  FM goes through cos/sin: int8 IQ within +-1 LSB of the reference. */
+#define HRFD_MOD_AM     3
+#define HRFD_MOD_FM     4
 int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out);
 int hrfd_mod_destroy(hrfd_mod *h);
 int hrfd_mod_reset(hrfd_mod *h, uint32_t channel);
 int hrfd_mod_set_sideband(hrfd_mod *h, uint32_t channel, int lsb);
+/* AmModulator::setModulationIndex (AmModulator.cc:329-336; default 0.8, accepted in [0, 1]) */
+int hrfd_mod_set_modulation_index(hrfd_mod *h, uint32_t channel, float index);
+/* FmModulator::setFrequencyDeviation (FmModulator.cc:336-346; default 3500 Hz) */
+int hrfd_mod_set_deviation(hrfd_mod *h, uint32_t channel, float deviation_hz);
 /* pcm [n_channels][n_per_channel] int16 (SSB) or [n_channels][2*n_per_channel]
  * int16 IQ pairs (INTERP); iq_out [n_channels][512*n_per_channel] int8;
  * *out_bytes = 512*n_per_channel (bytes per channel, as the reference returns). */

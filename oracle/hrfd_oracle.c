@@ -1016,6 +1016,141 @@ uint32_t orc_interp_process(orc_interp *h, const int16_t *iq, uint32_t n_pairs, 
   return n_pairs * 512u;
 }
 
+/* AmModulator (AmModulator.cc): modulateSignal :574-612, increaseSampleRate :406-483 (the same
+ * eight x2 stages and tables as the SSB modulator), modulationIndex 0.8 by default (:218),
+ * setModulationIndex accepts [0, 1] (:329-336). */
+struct orc_ammod
+{
+  float index;
+  q15i_t ip[2][8];
+};
+
+orc_ammod *orc_ammod_create(void)
+{
+  struct orc_ammod *h = (struct orc_ammod *)malloc(sizeof(*h));
+  memset(h, 0, sizeof(*h));
+  h->index = 0.8;
+  cascade_init(h->ip, AUDIO_D40);
+  return h;
+}
+
+void orc_ammod_destroy(orc_ammod *h)
+{
+  free(h);
+}
+
+void orc_ammod_reset(orc_ammod *h)
+{
+  for (int r = 0; r < 2; r++)
+  {
+    for (int s = 0; s < 8; s++)
+    {
+      q15i_reset(&h->ip[r][s]);
+    }
+  }
+}
+
+void orc_ammod_set_index(orc_ammod *h, float index)
+{
+  if ((index >= 0) && (index <= 1))
+  {
+    h->index = index;
+  }
+}
+
+uint32_t orc_ammod_process(orc_ammod *h, const int16_t *pcm, uint32_t n, int8_t *iq_out)
+{
+  int16_t *m = (int16_t *)calloc((size_t)n + 1, sizeof(int16_t));
+  for (uint32_t i = 0; i < n; i++)
+  {
+    float signal = (float)pcm[i] / 32768;                  /* :583 */
+    signal *= h->index;
+    signal = signal + 1;
+    signal /= 2;
+    m[i] = f2i16(signal * 128 * 250);                      /* :603-604: I and Q alike */
+  }
+  cascade_run(h->ip[0], m, n, iq_out, 0);
+  cascade_run(h->ip[1], m, n, iq_out, 1);
+  free(m);
+  return n << 9;
+}
+
+/* FmModulator (FmModulator.cc): modulateSignal :586-627 -- per 8 kS/s sample the Nco (8000 Hz
+ * sample rate, :221) gets frequency = deviation * pcm / 32768 and run() returns cos/sin of the
+ * phase BEFORE the step (Nco.cc:186-199: sinf/cosf under the C++ overloads), scaled by 16000;
+ * deviation 3500 Hz by default (:218); resetModulator (:277-300) leaves the Nco alone. */
+struct orc_fmmod
+{
+  float deviation;
+  float acc;
+  q15i_t ip[2][8];
+};
+
+orc_fmmod *orc_fmmod_create(void)
+{
+  struct orc_fmmod *h = (struct orc_fmmod *)malloc(sizeof(*h));
+  memset(h, 0, sizeof(*h));
+  h->deviation = 3500;
+  h->acc = 0;
+  cascade_init(h->ip, AUDIO_D40);
+  return h;
+}
+
+void orc_fmmod_destroy(orc_fmmod *h)
+{
+  free(h);
+}
+
+void orc_fmmod_reset(orc_fmmod *h)
+{
+  for (int r = 0; r < 2; r++)
+  {
+    for (int s = 0; s < 8; s++)
+    {
+      q15i_reset(&h->ip[r][s]);
+    }
+  }
+}
+
+void orc_fmmod_set_deviation(orc_fmmod *h, float deviation)
+{
+  /* FmModulator.cc:336-346 tests the CURRENT member, not the argument (kept as is) */
+  if ((h->deviation >= 0) && (h->deviation <= 3500))
+  {
+    h->deviation = deviation;
+  }
+}
+
+uint32_t orc_fmmod_process(orc_fmmod *h, const int16_t *pcm, uint32_t n, int8_t *iq_out)
+{
+  int16_t *mi = (int16_t *)calloc((size_t)n + 1, sizeof(int16_t));
+  int16_t *mq = (int16_t *)calloc((size_t)n + 1, sizeof(int16_t));
+  for (uint32_t i = 0; i < n; i++)
+  {
+    float f = h->deviation * (float)pcm[i] / 32768;        /* :597 */
+    float step = (float)((2 * M_PI * f) / 8000.0f);        /* PhaseAccumulator.cc:105 */
+    float phase = h->acc;                                  /* PhaseAccumulator.cc:157-181 */
+    h->acc += step;
+    while (h->acc > M_PI)
+    {
+      h->acc -= (2 * M_PI);
+    }
+    while (h->acc < (-M_PI))
+    {
+      h->acc += (2 * M_PI);
+    }
+    float iv = cosf(phase), qv = sinf(phase);
+    iv *= 16000;
+    qv *= 16000;
+    mi[i] = f2i16(iv);
+    mq[i] = f2i16(qv);
+  }
+  cascade_run(h->ip[0], mi, n, iq_out, 0);
+  cascade_run(h->ip[1], mq, n, iq_out, 1);
+  free(mi); free(mq);
+  return n << 9;
+}
+
 /* ------------------------------------------------------------------ Nco */
 struct orc_nco
 {

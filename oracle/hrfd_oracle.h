@@ -25,6 +25,8 @@ enum { ORC_NONE = 0, ORC_AM = 1, ORC_FM = 2, ORC_WBFM = 3, ORC_LSB = 4, ORC_USB 
 typedef struct orc_rx orc_rx;         /* IqDataProcessor + 4 demodulators + squelch */
 typedef struct orc_demod orc_demod;   /* one {Am,Fm,WbFm,Ssb}Demodulator            */
 typedef struct orc_ssbmod orc_ssbmod; /* SsbModulator                               */
+typedef struct orc_ammod orc_ammod;   /* AmModulator                                */
+typedef struct orc_fmmod orc_fmmod;   /* FmModulator                                */
 typedef struct orc_interp orc_interp; /* signals/interpolateSignal cascade          */
 typedef struct orc_nco orc_nco;       /* Nco + PhaseAccumulator                     */
 
@@ -58,6 +60,18 @@ void orc_ssbmod_set_sideband(orc_ssbmod *h, int lsb);
 uint32_t orc_ssbmod_process(orc_ssbmod *h, const int16_t *pcm, uint32_t n, int8_t *iq_out);
 
 /* ---- transmit: signals/interpolateSignal.cc:250-374 (int16 IQ pairs -> int8 IQ x256) */
+orc_ammod *orc_ammod_create(void);
+void orc_ammod_destroy(orc_ammod *h);
+void orc_ammod_reset(orc_ammod *h);
+void orc_ammod_set_index(orc_ammod *h, float index);
+uint32_t orc_ammod_process(orc_ammod *h, const int16_t *pcm, uint32_t n, int8_t *iq_out);
+
+orc_fmmod *orc_fmmod_create(void);
+void orc_fmmod_destroy(orc_fmmod *h);
+void orc_fmmod_reset(orc_fmmod *h);
+void orc_fmmod_set_deviation(orc_fmmod *h, float deviation);
+uint32_t orc_fmmod_process(orc_fmmod *h, const int16_t *pcm, uint32_t n, int8_t *iq_out);
+
 orc_interp *orc_interp_create(void);
 void orc_interp_destroy(orc_interp *h);
 /* n_pairs IQ pairs in (2*n_pairs int16), 512*n_pairs bytes out */

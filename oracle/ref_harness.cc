@@ -34,6 +34,8 @@
 #define private public
 #include "IqDataProcessor.h"
 #include "SsbModulator.h"
+#include "AmModulator.h"
+#include "FmModulator.h"
 #include "Nco.h"
 #include "Interpolator_int16.h"
 #include "FirFilter_int16.h"
@@ -314,6 +316,32 @@ uint32_t ref_ssbmod_process(void *hv,
   std::vector<int16_t> scratch(pcmPtr, pcmPtr + sampleCount);
   uint32_t outBytes = 0;
   m->acceptData(scratch.data(), sampleCount, iqOut, &outBytes);
+  return outBytes;
+}
+
+// AmModulator::acceptData (AmModulator.cc:381-395); sampleCount <= 512.
+void *ref_ammod_create(void) { return new AmModulator(); }
+void ref_ammod_destroy(void *hv) { delete (AmModulator *)hv; }
+void ref_ammod_reset(void *hv) { ((AmModulator *)hv)->resetModulator(); }
+void ref_ammod_set_index(void *hv, float index) { ((AmModulator *)hv)->setModulationIndex(index); }
+uint32_t ref_ammod_process(void *hv, const int16_t *pcmPtr, uint32_t sampleCount, int8_t *iqOut)
+{
+  std::vector<int16_t> scratch(pcmPtr, pcmPtr + sampleCount);
+  uint32_t outBytes = 0;
+  ((AmModulator *)hv)->acceptData(scratch.data(), sampleCount, iqOut, &outBytes);
+  return outBytes;
+}
+
+// FmModulator::acceptData (FmModulator.cc:393-407); sampleCount <= 512.
+void *ref_fmmod_create(void) { return new FmModulator(); }
+void ref_fmmod_destroy(void *hv) { delete (FmModulator *)hv; }
+void ref_fmmod_reset(void *hv) { ((FmModulator *)hv)->resetModulator(); }
+void ref_fmmod_set_deviation(void *hv, float deviation) { ((FmModulator *)hv)->setFrequencyDeviation(deviation); }
+uint32_t ref_fmmod_process(void *hv, const int16_t *pcmPtr, uint32_t sampleCount, int8_t *iqOut)
+{
+  std::vector<int16_t> scratch(pcmPtr, pcmPtr + sampleCount);
+  uint32_t outBytes = 0;
+  ((FmModulator *)hv)->acceptData(scratch.data(), sampleCount, iqOut, &outBytes);
   return outBytes;
 }
 

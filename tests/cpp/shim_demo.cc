@@ -13,6 +13,8 @@
 
 #include "IqDataProcessor.h"
 #include "SsbModulator.h"
+#include "AmModulator.h"
+#include "FmModulator.h"
 
 uint32_t radio_adjustableReceiveGainInDb = 0;          // Radio.cc:15
 void nprintf(FILE *s, const char *formatPtr, ...)      // diagUi.cc:2881
@@ -32,7 +34,7 @@ int main(int argc, char **argv)
 {
   if (argc < 4)
   {
-    fprintf(stderr, "usage: %s <mode> <outer|inner|ssbmod> <block_bytes>\n", argv[0]);
+    fprintf(stderr, "usage: %s <mode> <outer|inner|ssbmod|ammod|fmmod> <block_bytes>\n", argv[0]);
     return 2;
   }
   const int mode = atoi(argv[1]);
@@ -51,6 +53,30 @@ int main(int argc, char **argv)
     {
       uint32_t outBytes = 0;
       mod.acceptData(pcm.data(), 512, iq.data(), &outBytes);
+      fwrite(iq.data(), 1, outBytes, stdout);
+    }
+    return 0;
+  }
+
+  if (strcmp(argv[2], "ammod") == 0 || strcmp(argv[2], "fmmod") == 0)
+  {
+    // the other two modulators behind the same call (BasebandDataProcessor.cc:660-697); <mode> is
+    // the setter's argument in thousandths when non-zero (modulation index / deviation in Hz)
+    const bool am = strcmp(argv[2], "ammod") == 0;
+    AmModulator amMod;
+    FmModulator fmMod;
+    if (mode != 0)
+    {
+      if (am) amMod.setModulationIndex((float)mode / 1000);
+      else fmMod.setFrequencyDeviation((float)mode);
+    }
+    std::vector<int16_t> pcm(512);
+    std::vector<int8_t> iq(262144);
+    while (fread(pcm.data(), 2, 512, stdin) == 512)
+    {
+      uint32_t outBytes = 0;
+      if (am) amMod.acceptData(pcm.data(), 512, iq.data(), &outBytes);
+      else fmMod.acceptData(pcm.data(), 512, iq.data(), &outBytes);
       fwrite(iq.data(), 1, outBytes, stdout);
     }
     return 0;

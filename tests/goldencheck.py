@@ -98,3 +98,41 @@ def check_interp(engine, arrays, manifest):
     assert (out[:8192] == arrays["interp_head"]).all() and synth.digest(out) == a["iq_sha256"]
     out = engine.interp().process(synth.lcg_pcm(b["lcg_seed"], 2 * b["pairs"]))
     assert synth.digest(out) == b["iq_sha256"]
+
+
+def load_mod():
+    arrays = np.load(os.path.join(HERE, "golden_mod.npz"))
+    with open(os.path.join(HERE, "golden_mod.json")) as f:
+        manifest = json.load(f)
+    return arrays, manifest
+
+
+def check_am_mod(engine, arrays, case):
+    """AM modulator (integer cascade after a float scaling that is exact on both sides): bit-exact"""
+    pcm = synth.lcg_pcm(case["seed"], case["calls"] * 512)
+    m = engine.ammod()
+    if case["index"] is not None:
+        m.set_param(case["index"])
+    out = np.concatenate([m.process(pcm[b * 512:(b + 1) * 512]) for b in range(case["calls"])])
+    assert (out[:4096] == arrays[case["key"] + "_head"]).all()
+    assert (out[-4096:] == arrays[case["key"] + "_tail"]).all()
+    assert synth.digest(out) == case["iq_sha256"]
+
+
+def check_fm_mod(engine, arrays, case, tol):
+    """FM modulator: tol = 0 for the CPU oracle (same libm as the reference), 1 LSB on the device"""
+    pcm = synth.lcg_pcm(case["seed"], sum(case["calls"]))
+    m = engine.fmmod()
+    if case["deviation"] is not None:
+        m.set_param(case["deviation"])
+    parts, off = [], 0
+    for n in case["calls"]:
+        parts.append(m.process(pcm[off:off + n])); off += n
+    out = np.concatenate(parts)
+    d = np.abs(out.astype(np.int16) - arrays[case["key"]].astype(np.int16))
+    d = np.minimum(d, 256 - d)
+    assert d.max() <= tol, int(d.max())
+    if tol == 0:
+        assert synth.digest(out) == case["iq_sha256"]
+    else:
+        assert (d != 0).mean() < 0.01

@@ -64,6 +64,14 @@ class Oracle:
         L.orc_demod_set_sideband.argtypes = [C.c_void_p, C.c_int]
         L.orc_demod_process.restype = C.c_uint32
         L.orc_demod_process.argtypes = [C.c_void_p, _i8p, C.c_uint32, _i16p, C.c_uint32]
+        for kind, setter in (("ammod", "set_index"), ("fmmod", "set_deviation")):
+            getattr(L, f"orc_{kind}_create").restype = C.c_void_p
+            getattr(L, f"orc_{kind}_create").argtypes = []
+            getattr(L, f"orc_{kind}_destroy").argtypes = [C.c_void_p]
+            getattr(L, f"orc_{kind}_reset").argtypes = [C.c_void_p]
+            getattr(L, f"orc_{kind}_{setter}").argtypes = [C.c_void_p, C.c_float]
+            getattr(L, f"orc_{kind}_process").restype = C.c_uint32
+            getattr(L, f"orc_{kind}_process").argtypes = [C.c_void_p, _i16p, C.c_uint32, _i8p]
         L.orc_ssbmod_create.restype = C.c_void_p
         L.orc_ssbmod_create.argtypes = [C.c_int]
         L.orc_ssbmod_destroy.argtypes = [C.c_void_p]
@@ -152,6 +160,12 @@ class Oracle:
     def ssbmod(self, lsb=True):
         return _OrcSsbMod(self.lib, lsb)
 
+    def ammod(self):
+        return _Mod(self.lib, "orc", "ammod", "set_index")
+
+    def fmmod(self):
+        return _Mod(self.lib, "orc", "fmmod", "set_deviation")
+
     def interp(self):
         return _OrcInterp(self.lib)
 
@@ -220,6 +234,37 @@ class _OrcDemod:
         pcm = np.zeros(len(iq256) // 2 + 8, dtype=np.int16)
         n = self.lib.orc_demod_process(self.h, _p(iq256, _i8p), len(iq256), _p(pcm, _i16p), len(pcm))
         return pcm[:n].copy()
+
+
+class _Mod:
+    """AM / FM modulator of either library (`orc_` restatement or `ref_` compiled reference).
+    The reference's objects take at most 512 PCM samples per call (fixed member arrays)."""
+
+    def __init__(self, lib, prefix, kind, setter, max_call=None):
+        self.lib, self.pre, self.kind, self.setter, self.max_call = lib, prefix, kind, setter, max_call
+        self.h = C.c_void_p(getattr(lib, f"{prefix}_{kind}_create")())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.lib, f"{self.pre}_{self.kind}_destroy")(self.h)
+            self.h = None
+
+    def reset(self):
+        getattr(self.lib, f"{self.pre}_{self.kind}_reset")(self.h)
+
+    def set_param(self, value):
+        getattr(self.lib, f"{self.pre}_{self.kind}_{self.setter}")(self.h, float(value))
+
+    def process(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        step = self.max_call or max(len(pcm), 1)
+        outs = []
+        for o in range(0, len(pcm), step):
+            part = np.ascontiguousarray(pcm[o:o + step])
+            out = np.zeros(len(part) * 512, dtype=np.int8)
+            n = getattr(self.lib, f"{self.pre}_{self.kind}_process")(self.h, _p(part, _i16p), len(part), _p(out, _i8p))
+            outs.append(out[:n])
+        return np.concatenate(outs) if outs else np.zeros(0, dtype=np.int8)
 
 
 class _OrcSsbMod:
@@ -323,6 +368,14 @@ class Ref:
         L.ref_demod_set_sideband.argtypes = [C.c_void_p, C.c_int]
         L.ref_demod_process.restype = C.c_uint32
         L.ref_demod_process.argtypes = [C.c_void_p, _i8p, C.c_uint32, _i16p, C.c_uint32]
+        for kind, setter in (("ammod", "set_index"), ("fmmod", "set_deviation")):
+            getattr(L, f"ref_{kind}_create").restype = C.c_void_p
+            getattr(L, f"ref_{kind}_create").argtypes = []
+            getattr(L, f"ref_{kind}_destroy").argtypes = [C.c_void_p]
+            getattr(L, f"ref_{kind}_reset").argtypes = [C.c_void_p]
+            getattr(L, f"ref_{kind}_{setter}").argtypes = [C.c_void_p, C.c_float]
+            getattr(L, f"ref_{kind}_process").restype = C.c_uint32
+            getattr(L, f"ref_{kind}_process").argtypes = [C.c_void_p, _i16p, C.c_uint32, _i8p]
         L.ref_ssbmod_create.restype = C.c_void_p
         L.ref_ssbmod_create.argtypes = [C.c_int]
         L.ref_ssbmod_destroy.argtypes = [C.c_void_p]
@@ -385,6 +438,12 @@ class Ref:
 
     def ssbmod(self, lsb=True):
         return _RefSsbMod(self.lib, lsb)
+
+    def ammod(self):
+        return _Mod(self.lib, "ref", "ammod", "set_index", max_call=512)
+
+    def fmmod(self):
+        return _Mod(self.lib, "ref", "fmmod", "set_deviation", max_call=512)
 
     def nco(self, fs, f):
         return _Nco(self.lib, "ref", fs, f)

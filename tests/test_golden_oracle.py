@@ -59,3 +59,16 @@ def test_nco(oracle):
         assert (bits(np.stack([i0, q0])) == bits(ARR[case["key"] + "_run"])).all()
         assert (bits(np.stack([i1, q1])) == bits(ARR[case["key"] + "_fast"])).all()
     assert s[8192] != 0.0      # accumulated-phase quirk: Sin[8192] = -3.46e-4, not 0
+
+
+ARR_MOD, MAN_MOD = G.load_mod()
+
+
+@pytest.mark.parametrize("case", MAN_MOD["am"], ids=lambda c: c["key"])
+def test_am_modulator(oracle, case):
+    G.check_am_mod(oracle, ARR_MOD, case)
+
+
+@pytest.mark.parametrize("case", MAN_MOD["fm"], ids=lambda c: c["key"])
+def test_fm_modulator(oracle, case):
+    G.check_fm_mod(oracle, ARR_MOD, case, tol=0)

@@ -69,3 +69,21 @@ def test_shim_ssb_modulator_reproduces_oracle(oracle):
     o = oracle.ssbmod(False)
     want = np.concatenate([o.process(pcm[b * 512:(b + 1) * 512]) for b in range(3)])
     assert (got == want).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,arg,param,tol", [("ammod", "500", 0.5, 0), ("fmmod", "1200", 1200.0, 1)])
+def test_shim_am_fm_modulators_reproduce_oracle(oracle, kind, arg, param, tol):
+    """AmModulator / FmModulator shim classes (reference names and setters) against the oracle:
+    AM bit-exact, FM within the +-1 LSB of the trig path"""
+    _build_demo()
+    pcm = synth.lcg_pcm(9, 2 * 512)
+    out = subprocess.run([DEMO, arg, kind, "0"], input=pcm.tobytes(), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, check=True).stdout
+    got = np.frombuffer(out, dtype=np.int8)
+    o = getattr(oracle, kind)()
+    o.set_param(param)
+    want = np.concatenate([o.process(pcm[b * 512:(b + 1) * 512]) for b in range(2)])
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    d = np.minimum(d, 256 - d)
+    assert len(got) == len(want) and d.max() <= tol
