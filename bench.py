@@ -126,8 +126,8 @@ def bench_ssbmod(args, api, device, rank, world, dist):
     gen.manual_seed(7 + rank)
     pcm = torch.randint(-32768, 32768, (C, n), dtype=torch.int16, device=device, generator=gen)
     out = torch.empty((C, 512 * n), dtype=torch.int8, device=device)
-    kind = {"ssbmod": api.MOD_SSB, "ammod": api.MOD_AM, "fmmod": api.MOD_FM}[args.workload]
-    kname = {"ssbmod": "SSB", "ammod": "AM", "fmmod": "FM"}[args.workload]
+    kind = {"ssbmod": api.MOD_SSB, "ammod": api.MOD_AM, "fmmod": api.MOD_FM, "wbfmmod": api.MOD_WBFM}[args.workload]
+    kname = {"ssbmod": "SSB", "ammod": "AM", "fmmod": "FM", "wbfmmod": "WBFM"}[args.workload]
     m = api.Mod(kind, C, device=device.index)
     stream = torch.cuda.Stream(device=device)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -171,7 +171,8 @@ def bench_ssbmod(args, api, device, rank, world, dist):
                        "blocks_per_step": B},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "hrfd::k_mod<1>" if args.workload == "ssbmod" else "k_am_rails / k_fm_phase + k_fm_rails, then hrfd::k_mod<100>",
+                         "kernel": {"ssbmod": "hrfd::k_mod<1>", "wbfmmod": "hrfd::k_mod<101>, k_wb_step/phase/rails, hrfd::k_mod<102>"}.get(
+                             args.workload, "k_am_rails / k_fm_phase + k_fm_rails, then hrfd::k_mod<100>"),
                          "kernel_ms_mean": round(mean_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
         }), flush=True)
     if dist is not None:
@@ -203,7 +204,7 @@ def main():
     ap.add_argument("--channels", type=int, default=256, help="channels per GPU (BASELINE config 2)")
     ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
     ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")
-    ap.add_argument("--workload", choices=["wbfm", "mixed", "ssbmod", "ammod", "fmmod"], default="wbfm",
+    ap.add_argument("--workload", choices=["wbfm", "mixed", "ssbmod", "ammod", "fmmod", "wbfmmod"], default="wbfm",
                     help="wbfm = BASELINE config 2 (the headline); mixed = config 3 (AM+FM+WBFM+SSB bank, "
                          "per-mode dispatch); ssbmod = config 5 (SSB modulator, 8-stage x256 interpolator)")
     ap.add_argument("--scatter", action="store_true",
@@ -226,7 +227,7 @@ def main():
 
     from hackrfdiags_amd import api, shard
 
-    if args.workload in ("ssbmod", "ammod", "fmmod"):
+    if args.workload in ("ssbmod", "ammod", "fmmod", "wbfmmod"):
         return bench_ssbmod(args, api, device, rank, world, dist)
 
     C, B = args.channels, args.blocks

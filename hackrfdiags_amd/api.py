@@ -193,7 +193,7 @@ class Demod:
         return pcm if self.n > 1 else pcm[0]
 
 
-MOD_SSB, MOD_INTERP, MOD_AM, MOD_FM = 1, 2, 3, 4
+MOD_SSB, MOD_INTERP, MOD_AM, MOD_FM, MOD_WBFM = 1, 2, 3, 4, 5
 
 
 class Mod:
@@ -227,7 +227,7 @@ class Mod:
         check(self.L.hrfd_mod_set_deviation(self.h, channel, float(deviation_hz)), "hrfd_mod_set_deviation")
 
     def set_param(self, value, channel=ALL):
-        """the kind's parameter: AM modulation index / FM deviation (mirrors tests.reflib._Mod)"""
+        """the kind's parameter: AM modulation index / FM, WBFM deviation (mirrors tests.reflib._Mod)"""
         (self.set_modulation_index if self.kind == MOD_AM else self.set_deviation)(value, channel)
 
     def process(self, pcm):
@@ -295,6 +295,9 @@ class Engine:
 
     def fmmod(self):
         return Mod(MOD_FM, 1)
+
+    def wbfmmod(self):
+        return Mod(MOD_WBFM, 1)
 
     def rx(self):
         return SingleChannelRx()

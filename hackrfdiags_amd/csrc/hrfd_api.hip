@@ -1129,6 +1129,11 @@ struct hrfd_mod
   size_t cap_phase = 0, cap_rails = 0;
   std::vector<float> h_param;
   bool param_dirty = true;
+  // WBFM: the PCM at 256 kS/s, the step/phase/rails cells, Nco::runFast tables, rail history
+  int16_t *d_mid = nullptr;
+  uint32_t *d_wb = nullptr, *d_wbtail[2] = {nullptr, nullptr};
+  size_t cap_mid = 0, cap_wb = 0;
+  float *d_sin = nullptr, *d_cos = nullptr;
   // staging for the host entry
   int16_t *d_in = nullptr;
   int8_t *d_out = nullptr;
@@ -1143,7 +1148,8 @@ static int mod_free(hrfd_mod *h)
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->d_tail[0], h->d_tail[1], h->d_lsb, h->d_in, h->d_out, h->d_param, h->d_acc, h->d_phase, h->d_rails};
+  void *ptrs[] = {h->d_tail[0], h->d_tail[1], h->d_lsb, h->d_in, h->d_out, h->d_param, h->d_acc, h->d_phase, h->d_rails,
+                  h->d_mid, h->d_wb, h->d_wbtail[0], h->d_wbtail[1], h->d_sin, h->d_cos};
   for (void *p : ptrs)
   {
     if (p) (void)hipFree(p);
@@ -1156,9 +1162,10 @@ static int mod_free(hrfd_mod *h)
 extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out)
 {
   if (out == nullptr || n_channels == 0 ||
-      (kind != HRFD_MOD_SSB && kind != HRFD_MOD_INTERP && kind != HRFD_MOD_AM && kind != HRFD_MOD_FM))
+      (kind != HRFD_MOD_SSB && kind != HRFD_MOD_INTERP && kind != HRFD_MOD_AM && kind != HRFD_MOD_FM &&
+       kind != HRFD_MOD_WBFM))
   {
-    return fail(HRFD_EINVAL, "hrfd_mod_create: kind must be HRFD_MOD_SSB, _INTERP, _AM or _FM, n_channels > 0");
+    return fail(HRFD_EINVAL, "hrfd_mod_create: kind must be HRFD_MOD_SSB, _INTERP, _AM, _FM or _WBFM, n_channels > 0");
   }
   *out = nullptr;
   if (hrfd_device_count() <= 0)
@@ -1183,10 +1190,33 @@ extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_m
   if (e == hipSuccess) e = hipMemset(h->d_tail[0], 0, tail_bytes);   // zero pipelines == resetModulator()
   if (e == hipSuccess) e = hipMemset(h->d_tail[1], 0, tail_bytes);
   // AmModulator.cc:218 modulationIndex = 0.8; FmModulator.cc:218 frequencyDeviation = 3500, Nco phase 0
-  h->h_param.assign(n_channels, kind == HRFD_MOD_FM ? 3500.0f : (float)0.8);
+  // WbFmModulator.cc:204 frequencyDeviation = 70000
+  h->h_param.assign(n_channels, kind == HRFD_MOD_FM ? 3500.0f : kind == HRFD_MOD_WBFM ? 70000.0f : (float)0.8);
   if (e == hipSuccess) e = hipMalloc((void **)&h->d_param, sizeof(float) * n_channels);
   if (e == hipSuccess) e = hipMalloc((void **)&h->d_acc, sizeof(float) * n_channels);
   if (e == hipSuccess) e = hipMemset(h->d_acc, 0, sizeof(float) * n_channels);
+  if (kind == HRFD_MOD_WBFM)
+  {
+    // Nco.cc:50-61: tables from a float angle accumulated by float increments; sinf/cosf: host libm
+    std::vector<float> st(16384), ct(16384);
+    const float inc = (float)(2 * M_PI / 16384);
+    float ang = (float)(-M_PI);
+    for (int i = 0; i < 16384; i++)
+    {
+      st[i] = sinf(ang);
+      ct[i] = cosf(ang);
+      ang += inc;
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_sin, sizeof(float) * 16384);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_cos, sizeof(float) * 16384);
+    if (e == hipSuccess) e = hipMemcpy(h->d_sin, st.data(), sizeof(float) * 16384, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_cos, ct.data(), sizeof(float) * 16384, hipMemcpyHostToDevice);
+    for (int k = 0; k < 2; k++)
+    {
+      if (e == hipSuccess) e = hipMalloc((void **)&h->d_wbtail[k], sizeof(uint32_t) * 2 * n_channels);
+      if (e == hipSuccess) e = hipMemset(h->d_wbtail[k], 0, sizeof(uint32_t) * 2 * n_channels);
+    }
+  }
   if (e != hipSuccess)
   {
     const int rc = fail(HRFD_ENOMEM, "hrfd_mod_create: %s", hipGetErrorString(e));
@@ -1251,14 +1281,16 @@ extern "C" int hrfd_mod_set_modulation_index(hrfd_mod *h, uint32_t channel, floa
 // test looks at the CURRENT deviation, not at the new one (kept: it is the observable behaviour).
 extern "C" int hrfd_mod_set_deviation(hrfd_mod *h, uint32_t channel, float deviation)
 {
-  if (h == nullptr || h->kind != HRFD_MOD_FM || (channel != HRFD_ALL_CHANNELS && channel >= h->n_channels))
+  if (h == nullptr || (h->kind != HRFD_MOD_FM && h->kind != HRFD_MOD_WBFM) ||
+      (channel != HRFD_ALL_CHANNELS && channel >= h->n_channels))
   {
-    return fail(HRFD_EINVAL, "hrfd_mod_set_deviation: needs an FM modulator handle and a valid channel");
+    return fail(HRFD_EINVAL, "hrfd_mod_set_deviation: needs an FM or WBFM modulator handle and a valid channel");
   }
+  const float limit = (h->kind == HRFD_MOD_FM) ? 3500.0f : 112000.0f;   // WbFmModulator.cc:313
   std::lock_guard<std::mutex> g(h->mu);
   for (uint32_t c = 0; c < h->n_channels; c++)
   {
-    if ((channel == HRFD_ALL_CHANNELS || channel == c) && (h->h_param[c] >= 0) && (h->h_param[c] <= 3500))
+    if ((channel == HRFD_ALL_CHANNELS || channel == c) && (h->h_param[c] >= 0) && (h->h_param[c] <= limit))
     {
       h->h_param[c] = deviation;
     }
@@ -1297,10 +1329,12 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
       if (ch == HRFD_ALL_CHANNELS)
       {
         HIP_TRY(hipMemsetAsync(h->d_tail[h->cur], 0, per * h->n_channels, s));
+        if (h->kind == HRFD_MOD_WBFM) HIP_TRY(hipMemsetAsync(h->d_wbtail[h->cur], 0, 8 * (size_t)h->n_channels, s));
       }
       else
       {
         HIP_TRY(hipMemsetAsync(h->d_tail[h->cur] + (size_t)ch * 4 * kModTail, 0, per, s));
+        if (h->kind == HRFD_MOD_WBFM) HIP_TRY(hipMemsetAsync(h->d_wbtail[h->cur] + (size_t)ch * 2, 0, 8, s));
       }
     }
     h->resets.clear();
@@ -1311,11 +1345,52 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
   M.tail_in = h->d_tail[h->cur];
   M.tail_out = h->d_tail[h->cur ^ 1];
   M.lsb = h->d_lsb;
+  M.mid = nullptr;
+  M.wbtail = nullptr;
   M.n = n_per_channel;
   M.n_channels = h->n_channels;
   const uint32_t tiles = (n_per_channel + kModTile - 1) / kModTile;
   const uint32_t grid = h->n_channels * tiles;
-  if (h->kind == HRFD_MOD_AM || h->kind == HRFD_MOD_FM)
+  if (h->kind == HRFD_MOD_WBFM)
+  {
+    // WbFmModulator::acceptData (WbFmModulator.cc:341-356): x32 on the PCM, the 256 kS/s Nco, x8
+    const size_t samples = (size_t)n_per_channel * h->n_channels;
+    const size_t s32 = samples * 32;
+    int rc;
+    if (samples * 4 > h->cap_rails || s32 * 2 > h->cap_mid || s32 * 4 > h->cap_wb)
+    {
+      HIP_TRY(hipStreamSynchronize(s));
+      if ((rc = grow((void **)&h->d_rails, &h->cap_rails, samples * 4)) != HRFD_OK) return rc;
+      if ((rc = grow((void **)&h->d_mid, &h->cap_mid, s32 * 2)) != HRFD_OK) return rc;
+      if ((rc = grow((void **)&h->d_wb, &h->cap_wb, s32 * 4)) != HRFD_OK) return rc;
+    }
+    BaseParams B;
+    memset(&B, 0, sizeof(B));
+    B.pcm = d_pcm;
+    B.rails = h->d_rails;
+    B.param = h->d_param;
+    B.acc = h->d_acc;
+    B.mid = h->d_mid;
+    B.wb = h->d_wb;
+    B.cos_t = h->d_cos;
+    B.sin_t = h->d_sin;
+    B.wbtail_out = h->d_wbtail[h->cur ^ 1];
+    B.n = n_per_channel;
+    B.n_channels = h->n_channels;
+    hipLaunchKernelGGL(k_wb_pairs, dim3((uint32_t)((samples + 255) / 256)), dim3(256), 0, s, B);
+    M.in = h->d_rails;
+    M.mid = h->d_mid;
+    hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_HEAD>, dim3(grid), dim3(kModThreads), 0, s, M);
+    const uint32_t g32 = (uint32_t)((s32 + 255) / 256);
+    hipLaunchKernelGGL(k_wb_step, dim3(g32), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(k_phase_scan, dim3((h->n_channels + 63) / 64), dim3(64), 0, s, h->d_wb, (size_t)n_per_channel * 32,
+                       h->d_acc, h->n_channels);
+    hipLaunchKernelGGL(k_wb_rails, dim3(g32), dim3(256), 0, s, B);
+    M.in = reinterpret_cast<const int16_t *>(h->d_wb);
+    M.wbtail = h->d_wbtail[h->cur];
+    hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(grid), dim3(kModThreads), 0, s, M);
+  }
+  else if (h->kind == HRFD_MOD_AM || h->kind == HRFD_MOD_FM)
   {
     // baseband rails first (k_am_rails / k_fm_phase + k_fm_rails), then the shared x256 cascade
     const size_t samples = (size_t)n_per_channel * h->n_channels;
@@ -1327,6 +1402,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
       if (h->kind == HRFD_MOD_FM && (rc = grow((void **)&h->d_phase, &h->cap_phase, samples * 4)) != HRFD_OK) return rc;
     }
     BaseParams B;
+    memset(&B, 0, sizeof(B));
     B.pcm = d_pcm;
     B.rails = h->d_rails;
     B.param = h->d_param;
@@ -1341,7 +1417,9 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     }
     else
     {
-      hipLaunchKernelGGL(k_fm_phase, dim3((h->n_channels + 63) / 64), dim3(64), 0, s, B);
+      hipLaunchKernelGGL(k_fm_step, dim3(gs), dim3(256), 0, s, B);
+      hipLaunchKernelGGL(k_phase_scan, dim3((h->n_channels + 63) / 64), dim3(64), 0, s,
+                         reinterpret_cast<uint32_t *>(h->d_phase), (size_t)n_per_channel, h->d_acc, h->n_channels);
       hipLaunchKernelGGL(k_fm_rails, dim3(gs), dim3(256), 0, s, B);
     }
     M.in = h->d_rails;

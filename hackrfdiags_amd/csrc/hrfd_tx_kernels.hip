@@ -22,6 +22,8 @@
 namespace hrfd {
 
 constexpr int HRFD_MOD_RAILS = 100;     // internal kind: int16 (I,Q) rails in, modulator tables
+constexpr int HRFD_MOD_WB_HEAD = 101;   // WBFM modulator: (pcm, 0) pairs in, rail 0 after stage 5 out (x32)
+constexpr int HRFD_MOD_WB_TAIL = 102;   // WBFM modulator: 256 kS/s (I,Q) rails in, stages 6-8 (x8)
 constexpr int kModTile = 32;            // input samples per workgroup
 constexpr int kModThreads = 256;
 constexpr int kModTail = 64;            // carried input history per channel (>= 54)
@@ -34,6 +36,8 @@ struct ModParams
   int16_t *tail_out;        //   rows 2,3 the last kH0 samples of the I and Q rails as they were
                             //   produced (the Q rail carries the sideband sign of its time)
   const uint8_t *lsb;       // [C] sideband (SSB)
+  int16_t *mid;             // WB_HEAD: [C][32 n] the PCM at 256 kS/s
+  const uint32_t *wbtail;   // WB_TAIL: [C][2] the last two (I,Q) rail pairs of the previous call
   uint32_t n;               // input samples per channel
   uint32_t n_channels;
 };
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   // INTERP and RAILS take int16 (I,Q) pairs; RAILS (the AM / FM modulators' baseband, produced by
   // k_am_rails / k_fm_rails) runs them through the modulators' stage-1 table, INTERP through
   // interpolateSignal's own
-  constexpr bool kPairs = (KIND == HRFD_MOD_INTERP) || (KIND == HRFD_MOD_RAILS);
+  constexpr bool kPairs = (KIND == HRFD_MOD_INTERP) || (KIND == HRFD_MOD_RAILS) || (KIND == HRFD_MOD_WB_HEAD);
   const uint32_t tiles = (M.n + kModTile - 1) / kModTile;
   const uint32_t c = blockIdx.x / tiles;
   const uint32_t tile = blockIdx.x - c * tiles;
@@ -109,183 +113,223 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   const int tid = threadIdx.x;
   const int t0 = (int)tile * kModTile;                    // first input sample of the tile
   const int n = (int)M.n;
-  const int16_t *in = M.in + (size_t)c * M.n * (kPairs ? 2 : 1);
-  const int16_t *tin = M.tail_in + (size_t)c * 4 * kModTail;
-
-  // ---- stage-0 source: scaled PCM (SSB) or the IQ pair (INTERP), history first
-  for (int t = tid; t < kModTail + kModTile; t += kModThreads)
+  if constexpr (KIND == HRFD_MOD_WB_TAIL)
   {
-    const int g = t0 - kModTail + t;                      // global input index
-    int a = 0, b = 0;
-    if (g < 0)
+    // the rails arrive at 256 kS/s (k_wb_rails): they are stage 5's place in LDS; the two
+    // samples in front of the tile come from the input or, at the start of a call, from the
+    // previous call's last two pairs
+    const uint32_t *rin = reinterpret_cast<const uint32_t *>(M.in) + (size_t)c * M.n * 32;
+    const int n32 = (int)M.n * 32;
+    for (int t = tid; t < kH5 + 32 * kModTile; t += kModThreads)
     {
-      a = tin[kModTail + g];
-      b = tin[kModTail + kModTail + g];
-    }
-    else if (g < n)
-    {
-      if (kPairs)
+      const int g = 32 * t0 + t - kH5;
+      uint32_t w = 0u;
+      if (g < 0)
       {
-        a = in[2 * g];
-        b = in[2 * g + 1];
+        w = M.wbtail[(size_t)c * 2 + (2 + g)];
       }
-      else
+      else if (g < n32)
       {
-        // scaledSample = (float)pcm / 2; (int16_t) truncates toward zero (:679-686)
-        float f = (float)in[g];
-        f = f / 2.0f;
-        a = (int)f;
+        w = rin[g];
       }
+      r[0][kO5 + t] = (int16_t)(w & 0xffffu);
+      r[1][kO5 + t] = (int16_t)(w >> 16);
     }
-    src[0][t] = (int16_t)a;
-    src[1][t] = (int16_t)b;
+    __syncthreads();
   }
-  // the last tile of the call also leaves the new tail (the other buffer of the ping-pong)
-  if (tile + 1 == tiles)
+  else
   {
-    int16_t *tout = M.tail_out + (size_t)c * 4 * kModTail;
-    for (int t = tid; t < kModTail; t += kModThreads)
+    const int16_t *in = M.in + (size_t)c * M.n * (kPairs ? 2 : 1);
+    const int16_t *tin = M.tail_in + (size_t)c * 4 * kModTail;
+
+    // ---- stage-0 source: scaled PCM (SSB) or the IQ pair (INTERP), history first
+    for (int t = tid; t < kModTail + kModTile; t += kModThreads)
     {
-      const int g = n - kModTail + t;
+      const int g = t0 - kModTail + t;                      // global input index
       int a = 0, b = 0;
       if (g < 0)
       {
-        const int o = kModTail + g;                       // still inside the old tail
-        a = tin[o];
-        b = tin[kModTail + o];
+        a = tin[kModTail + g];
+        b = tin[kModTail + kModTail + g];
+      }
+      else if (g < n)
+      {
+        if (kPairs)
+        {
+          a = in[2 * g];
+          b = in[2 * g + 1];
+        }
+        else
+        {
+          // scaledSample = (float)pcm / 2; (int16_t) truncates toward zero (:679-686)
+          float f = (float)in[g];
+          f = f / 2.0f;
+          a = (int)f;
+        }
+      }
+      src[0][t] = (int16_t)a;
+      src[1][t] = (int16_t)b;
+    }
+    // the last tile of the call also leaves the new tail (the other buffer of the ping-pong)
+    if (tile + 1 == tiles)
+    {
+      int16_t *tout = M.tail_out + (size_t)c * 4 * kModTail;
+      for (int t = tid; t < kModTail; t += kModThreads)
+      {
+        const int g = n - kModTail + t;
+        int a = 0, b = 0;
+        if (g < 0)
+        {
+          const int o = kModTail + g;                       // still inside the old tail
+          a = tin[o];
+          b = tin[kModTail + o];
+        }
+        else if (kPairs)
+        {
+          a = in[2 * g];
+          b = in[2 * g + 1];
+        }
+        else
+        {
+          float f = (float)in[g];
+          f = f / 2.0f;
+          a = (int)f;
+        }
+        tout[t] = (int16_t)a;
+        tout[kModTail + t] = (int16_t)b;
+      }
+    }
+    __syncthreads();
+
+    // ---- stage 0: the two rails at the input rate, x0[j] for j in [-kH0, kModTile)
+    for (int t = tid; t < kH0 + kModTile; t += kModThreads)
+    {
+      const int j = t - kH0;
+      const int16_t *s0 = &src[0][kModTail + j];            // s[n], s0[-k] = s[n-k]
+      int iv, qv;
+      if (t0 + j < 0)
+      {
+        // before the call: the rails as the previous call produced them (a sideband
+        // switch between calls must not re-sign samples already in the pipelines)
+        iv = tin[2 * kModTail + kModTail + (t0 + j)];
+        qv = tin[3 * kModTail + kModTail + (t0 + j)];
       }
       else if (kPairs)
       {
-        a = in[2 * g];
-        b = in[2 * g + 1];
+        iv = s0[0];
+        qv = src[1][kModTail + j];
       }
       else
       {
-        float f = (float)in[g];
-        f = f / 2.0f;
-        a = (int)f;
+        // delay line: Q15 tap -32768 at k = 15 (FirFilter_int16.cc:151-224)
+        iv = q15((1 << 14) + (-32768) * (int)s0[-15]);
+        int acc = 1 << 14;
+  #pragma unroll
+        for (int k = 0; k < N_SSB_HILBERT; k++)
+        {
+          acc += (int)kHilbert[k] * (int)s0[-k];
+        }
+        qv = q15(acc);
+        if (!M.lsb[c])
+        {
+          qv = (int)(short)(-qv);                           // USB: qPhaseShifted = -qPhaseShifted (:696-699)
+        }
       }
-      tout[t] = (int16_t)a;
-      tout[kModTail + t] = (int16_t)b;
+      r[0][kO0 + t] = (int16_t)iv;
+      r[1][kO0 + t] = (int16_t)qv;
     }
-  }
-  __syncthreads();
-
-  // ---- stage 0: the two rails at the input rate, x0[j] for j in [-kH0, kModTile)
-  for (int t = tid; t < kH0 + kModTile; t += kModThreads)
-  {
-    const int j = t - kH0;
-    const int16_t *s0 = &src[0][kModTail + j];            // s[n], s0[-k] = s[n-k]
-    int iv, qv;
-    if (t0 + j < 0)
+    __syncthreads();
+    if (tile + 1 == tiles)
     {
-      // before the call: the rails as the previous call produced them (a sideband
-      // switch between calls must not re-sign samples already in the pipelines)
-      iv = tin[2 * kModTail + kModTail + (t0 + j)];
-      qv = tin[3 * kModTail + kModTail + (t0 + j)];
-    }
-    else if (kPairs)
-    {
-      iv = s0[0];
-      qv = src[1][kModTail + j];
-    }
-    else
-    {
-      // delay line: Q15 tap -32768 at k = 15 (FirFilter_int16.cc:151-224)
-      iv = q15((1 << 14) + (-32768) * (int)s0[-15]);
-      int acc = 1 << 14;
-#pragma unroll
-      for (int k = 0; k < N_SSB_HILBERT; k++)
+      // new rail tails: x0[g] for g in [n - kModTail, n); only the last kH0 are ever read
+      int16_t *tout = M.tail_out + (size_t)c * 4 * kModTail;
+      for (int t = tid; t < 2 * kModTail; t += kModThreads)
       {
-        acc += (int)kHilbert[k] * (int)s0[-k];
-      }
-      qv = q15(acc);
-      if (!M.lsb[c])
-      {
-        qv = (int)(short)(-qv);                           // USB: qPhaseShifted = -qPhaseShifted (:696-699)
+        const int rail = t / kModTail, u = t - rail * kModTail;
+        const int j = (n - t0) - kModTail + u;              // tile-relative index
+        tout[(2 + rail) * kModTail + u] = (j >= -kH0) ? r[rail][kO0 + kH0 + j] : (int16_t)0;
       }
     }
-    r[0][kO0 + t] = (int16_t)iv;
-    r[1][kO0 + t] = (int16_t)qv;
-  }
-  __syncthreads();
-  if (tile + 1 == tiles)
-  {
-    // new rail tails: x0[g] for g in [n - kModTail, n); only the last kH0 are ever read
-    int16_t *tout = M.tail_out + (size_t)c * 4 * kModTail;
-    for (int t = tid; t < 2 * kModTail; t += kModThreads)
-    {
-      const int rail = t / kModTail, u = t - rail * kModTail;
-      const int j = (n - t0) - kModTail + u;              // tile-relative index
-      tout[(2 + rail) * kModTail + u] = (j >= -kH0) ? r[rail][kO0 + kH0 + j] : (int16_t)0;
-    }
-  }
 
-  // ---- stage 1: 40-tap prototype, x2; outputs m in [-kH1, 2*tile)
-  {
-    const int16_t *h = (KIND == HRFD_MOD_INTERP) ? kS1Interp : kS1Ssb;
-    for (int t = tid; t < 2 * (kH1 + 2 * kModTile); t += kModThreads)
+    // ---- stage 1: 40-tap prototype, x2; outputs m in [-kH1, 2*tile)
+    {
+      const int16_t *h = (KIND == HRFD_MOD_INTERP) ? kS1Interp : kS1Ssb;
+      for (int t = tid; t < 2 * (kH1 + 2 * kModTile); t += kModThreads)
+      {
+        const int rail = t & 1, u = t >> 1;
+        const int m = u - kH1;                              // output index at 16 kS/s
+        const int nn = m >> 1, ph = m & 1;                  // floor division (m may be negative)
+        const int16_t *x = &r[rail][kO0 + kH0 + nn];
+        int acc = 1 << 14;
+  #pragma unroll
+        for (int j = 0; j < 20; j++)
+        {
+          acc += (int)h[ph + 2 * j] * (int)x[-j];
+        }
+        r[rail][kO1 + u] = (int16_t)q15(acc);
+      }
+    }
+    __syncthreads();
+    // ---- stage 2: HB8, outputs m in [-kH2, 4*tile)
+    // (from here on a thread produces both phases of one input sample of one rail)
+    for (int t = tid; t < 2 * ((kH2 + 4 * kModTile) / 2); t += kModThreads)
+    {
+      const int rail = t & 1, u = t >> 1;                   // u: input sample slot
+      const int nn = u - kH2 / 2;                           // input index (16 kS/s)
+      int y0, y1;
+      hb8(&r[rail][kO1 + kH1], nn, y0, y1);
+      r[rail][kO2 + 2 * u] = (int16_t)y0;
+      r[rail][kO2 + 2 * u + 1] = (int16_t)y1;
+    }
+    __syncthreads();
+    // ---- stage 3: 4-tap HB3, outputs m in [-kH3, 8*tile)
+    for (int t = tid; t < 2 * ((kH3 + 8 * kModTile) / 2); t += kModThreads)
     {
       const int rail = t & 1, u = t >> 1;
-      const int m = u - kH1;                              // output index at 16 kS/s
-      const int nn = m >> 1, ph = m & 1;                  // floor division (m may be negative)
-      const int16_t *x = &r[rail][kO0 + kH0 + nn];
-      int acc = 1 << 14;
-#pragma unroll
-      for (int j = 0; j < 20; j++)
+      const int nn = u - kH3 / 2;
+      const int16_t *x = &r[rail][kO2 + kH2];
+      int y0, y1;
+      hb4(Q_INTERP_HB3, x[nn], x[nn - 1], y0, y1);
+      r[rail][kO3 + 2 * u] = (int16_t)y0;
+      r[rail][kO3 + 2 * u + 1] = (int16_t)y1;
+    }
+    __syncthreads();
+    // ---- stage 4: HB8, outputs m in [-kH4, 16*tile)
+    for (int t = tid; t < 2 * ((kH4 + 16 * kModTile) / 2); t += kModThreads)
+    {
+      const int rail = t & 1, u = t >> 1;
+      const int nn = u - kH4 / 2;
+      int y0, y1;
+      hb8(&r[rail][kO3 + kH3], nn, y0, y1);
+      r[rail][kO4 + 2 * u] = (int16_t)y0;
+      r[rail][kO4 + 2 * u + 1] = (int16_t)y1;
+    }
+    __syncthreads();
+    // ---- stage 5: HB8, outputs m in [-kH5, 32*tile)
+    for (int t = tid; t < 2 * ((kH5 + 32 * kModTile) / 2); t += kModThreads)
+    {
+      const int rail = t & 1, u = t >> 1;
+      const int nn = u - kH5 / 2;
+      int y0, y1;
+      hb8(&r[rail][kO4 + kH4], nn, y0, y1);
+      r[rail][kO5 + 2 * u] = (int16_t)y0;
+      r[rail][kO5 + 2 * u + 1] = (int16_t)y1;
+    }
+    __syncthreads();
+
+    if constexpr (KIND == HRFD_MOD_WB_HEAD)
+    {
+      // WbFmModulator::increasePcmSampleRate ends here (WbFmModulator.cc:389-425): rail 0 at
+      // 256 kS/s goes to the Nco kernels
+      const int valid32 = 32 * min(kModTile, n - t0);
+      int16_t *mid = M.mid + ((size_t)c * M.n + t0) * 32;
+      for (int j = tid; j < valid32; j += kModThreads)
       {
-        acc += (int)h[ph + 2 * j] * (int)x[-j];
+        mid[j] = r[0][kO5 + kH5 + j];
       }
-      r[rail][kO1 + u] = (int16_t)q15(acc);
+      return;
     }
   }
-  __syncthreads();
-  // ---- stage 2: HB8, outputs m in [-kH2, 4*tile)
-  // (from here on a thread produces both phases of one input sample of one rail)
-  for (int t = tid; t < 2 * ((kH2 + 4 * kModTile) / 2); t += kModThreads)
-  {
-    const int rail = t & 1, u = t >> 1;                   // u: input sample slot
-    const int nn = u - kH2 / 2;                           // input index (16 kS/s)
-    int y0, y1;
-    hb8(&r[rail][kO1 + kH1], nn, y0, y1);
-    r[rail][kO2 + 2 * u] = (int16_t)y0;
-    r[rail][kO2 + 2 * u + 1] = (int16_t)y1;
-  }
-  __syncthreads();
-  // ---- stage 3: 4-tap HB3, outputs m in [-kH3, 8*tile)
-  for (int t = tid; t < 2 * ((kH3 + 8 * kModTile) / 2); t += kModThreads)
-  {
-    const int rail = t & 1, u = t >> 1;
-    const int nn = u - kH3 / 2;
-    const int16_t *x = &r[rail][kO2 + kH2];
-    int y0, y1;
-    hb4(Q_INTERP_HB3, x[nn], x[nn - 1], y0, y1);
-    r[rail][kO3 + 2 * u] = (int16_t)y0;
-    r[rail][kO3 + 2 * u + 1] = (int16_t)y1;
-  }
-  __syncthreads();
-  // ---- stage 4: HB8, outputs m in [-kH4, 16*tile)
-  for (int t = tid; t < 2 * ((kH4 + 16 * kModTile) / 2); t += kModThreads)
-  {
-    const int rail = t & 1, u = t >> 1;
-    const int nn = u - kH4 / 2;
-    int y0, y1;
-    hb8(&r[rail][kO3 + kH3], nn, y0, y1);
-    r[rail][kO4 + 2 * u] = (int16_t)y0;
-    r[rail][kO4 + 2 * u + 1] = (int16_t)y1;
-  }
-  __syncthreads();
-  // ---- stage 5: HB8, outputs m in [-kH5, 32*tile)
-  for (int t = tid; t < 2 * ((kH5 + 32 * kModTile) / 2); t += kModThreads)
-  {
-    const int rail = t & 1, u = t >> 1;
-    const int nn = u - kH5 / 2;
-    int y0, y1;
-    hb8(&r[rail][kO4 + kH4], nn, y0, y1);
-    r[rail][kO5 + 2 * u] = (int16_t)y0;
-    r[rail][kO5 + 2 * u + 1] = (int16_t)y1;
-  }
-  __syncthreads();
 
   // ---- stages 6, 7, 8 in registers: one 256 kS/s sample j -> 8 output IQ pairs
   const int valid = min(kModTile, n - t0);                // input samples really in this tile
@@ -330,6 +374,8 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 template __global__ void k_mod<HRFD_MOD_SSB>(const ModParams);
 template __global__ void k_mod<HRFD_MOD_INTERP>(const ModParams);
 template __global__ void k_mod<HRFD_MOD_RAILS>(const ModParams);
+template __global__ void k_mod<HRFD_MOD_WB_HEAD>(const ModParams);
+template __global__ void k_mod<HRFD_MOD_WB_TAIL>(const ModParams);
 
 } // namespace hrfd
 
@@ -345,6 +391,10 @@ struct BaseParams
   const float *param;       // [C] modulation index (AM) / frequency deviation in Hz (FM)
   float *acc;               // [C] FM: Nco phase accumulator (persists across calls)
   float *phase;             // [C][n] FM scratch: phase of every sample
+  const int16_t *mid;       // WBFM: [C][32 n] the PCM at 256 kS/s (k_mod<WB_HEAD>)
+  uint32_t *wb;             // WBFM: [C][32 n] 4-byte cells: step -> phase -> (I,Q) rails, in place
+  const float *cos_t, *sin_t; // WBFM: Nco::runFast tables (host libm, Nco.cc:50-61)
+  uint32_t *wbtail_out;     // WBFM: [C][2] the call's last two rail pairs (next call's history)
   uint32_t n, n_channels;
 };
 
@@ -367,28 +417,62 @@ __global__ void k_am_rails(const BaseParams B)
   reinterpret_cast<uint32_t *>(B.rails)[t] = ((uint32_t)v & 0xffffu) * 0x00010001u;
 }
 
-// FmModulator::modulateSignal (FmModulator.cc:586-627).  Pass 1, one thread per channel: the
-// Nco phase recurrence (PhaseAccumulator.cc:95-107,157-181: step = (float)((2*M_PI*f)/fs) with
-// fs = 8000, float accumulate, wrap with double compares and double subtraction) -- exact.
-__global__ void k_fm_phase(const BaseParams B)
+// FmModulator::modulateSignal (FmModulator.cc:586-627).  Pass 1, one thread per sample: the Nco
+// step, f = deviation * pcm / 32768 (float), step = (float)((2*M_PI*f)/8000) (double expression,
+// PhaseAccumulator.cc:95-107).  Pass 2 is k_phase_scan (the recurrence), pass 3 k_fm_rails.
+__global__ void k_fm_step(const BaseParams B)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B.n * B.n_channels)
+  {
+    return;
+  }
+  const uint32_t c = (uint32_t)(t / B.n);
+  const double two_pi = 6.283185307179586476925286766559;
+  float f = B.param[c] * (float)B.pcm[t];
+  f = f / 32768.0f;
+  B.phase[t] = (float)((two_pi * (double)f) / (double)8000.0f);
+}
+
+// The Nco phase recurrence of both FM modulators (PhaseAccumulator.cc:157-181), one thread per
+// channel, step -> phase in place over `steps` 4-byte cells per channel: return the current
+// phase, add the step in float, wrap with double compares and a double subtraction.  Nothing but
+// the float add and the wrap test is in the dependent chain; cells are moved 16 at a time (one
+// 64-byte line per lane) with the next group in flight, because one global access per step costs
+// a memory round trip per step.
+__global__ void k_phase_scan(uint32_t *cells, size_t steps, float *acc_io, uint32_t n_channels)
 {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= B.n_channels)
+  if (c >= n_channels)
   {
     return;
   }
   const double pi = 3.14159265358979323846, two_pi = 6.283185307179586476925286766559;
-  const float dev = B.param[c];
-  float acc = B.acc[c];
-  const int16_t *pcm = B.pcm + (size_t)c * B.n;
-  float *ph = B.phase + (size_t)c * B.n;
-  for (uint32_t k = 0; k < B.n; k++)
-  {
-    float f = dev * (float)pcm[k];
-    f = f / 32768.0f;
-    const float step = (float)((two_pi * (double)f) / (double)8000.0f);
-    ph[k] = acc;
-    acc = acc + step;
+  const float pi_up = 3.14159274101257324e+00f;          // (double)acc > M_PI  <=>  acc >= pi_up
+  float acc = acc_io[c];
+  uint32_t *cell = cells + (size_t)c * steps;
+  // The wrap: for pi < |acc| <= 8 one subtraction of 2*M_PI suffices, and the reference's double
+  // subtraction equals two float ones, (acc -+ C_HI) -+ C_LO -- checked for every one of the
+  // 2.4e7 floats in that range by tools/proofs/wrap_float_acc.c.  That keeps the dependent chain
+  // at add, subtract, subtract, select, with no scalar instruction in it: whether some |acc|
+  // exceeded 8 (absurd deviations) is only looked at once per group of 16 cells, and such a group
+  // is redone from its first cell with the double loops.
+  const uint32_t c_hi = 0x40c90fdbu, c_lo = 0xb43bbd2eu;
+  float maxmag = 0.0f;
+  auto advance_fast = [&](uint32_t step_bits) -> uint32_t {
+    const uint32_t phase_bits = __builtin_bit_cast(uint32_t, acc);
+    acc = acc + __builtin_bit_cast(float, step_bits);
+    const float mag = __builtin_fabsf(acc);
+    maxmag = __builtin_fmaxf(maxmag, mag);
+    const uint32_t sg = __builtin_bit_cast(uint32_t, acc) & 0x80000000u;
+    const float u = acc - __builtin_bit_cast(float, c_hi | sg);
+    const float w = u - __builtin_bit_cast(float, c_lo ^ sg);
+    acc = (mag >= pi_up) ? w : acc;
+    return phase_bits;
+  };
+  auto advance = [&](uint32_t step_bits) -> uint32_t {
+    const uint32_t phase_bits = __builtin_bit_cast(uint32_t, acc);
+    acc = acc + __builtin_bit_cast(float, step_bits);
     while ((double)acc > pi)
     {
       acc = (float)((double)acc - two_pi);
@@ -397,11 +481,84 @@ __global__ void k_fm_phase(const BaseParams B)
     {
       acc = (float)((double)acc + two_pi);
     }
+    return phase_bits;
+  };
+  size_t k = 0;
+  if ((steps & 15) == 0 && steps >= 16)
+  {
+    // groups of 16 cells (four 16-byte pieces: one 64-byte line per lane), kGroups groups in
+    // flight in a register ring: the group just finished is refilled from 16*kGroups cells ahead
+    constexpr int kGroups = 4;
+    uint4 *v = reinterpret_cast<uint4 *>(cell);         // 16-byte aligned: steps is a multiple of 16
+    const size_t ngroups = steps >> 4;
+    uint4 g[kGroups][4];
+#pragma unroll
+    for (int d = 0; d < kGroups; d++)
+    {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        g[d][j] = ((size_t)d < ngroups) ? v[(size_t)d * 4 + j] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    for (size_t gi = 0; gi < ngroups; gi += kGroups)
+    {
+#pragma unroll
+      for (int d = 0; d < kGroups; d++)
+      {
+        const size_t cur = gi + d;
+        if (cur < ngroups)
+        {
+          const float acc0 = acc;
+          uint4 o[4];
+          maxmag = 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+          {
+            o[j].x = advance_fast(g[d][j].x);
+            o[j].y = advance_fast(g[d][j].y);
+            o[j].z = advance_fast(g[d][j].z);
+            o[j].w = advance_fast(g[d][j].w);
+          }
+          if (__builtin_amdgcn_ballot_w64(maxmag > 8.0f) != 0ull)
+          {
+            acc = acc0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+              o[j].x = advance(g[d][j].x);
+              o[j].y = advance(g[d][j].y);
+              o[j].z = advance(g[d][j].z);
+              o[j].w = advance(g[d][j].w);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+          {
+            v[cur * 4 + j] = o[j];
+          }
+          const size_t nxt = cur + kGroups;
+          if (nxt < ngroups)
+          {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+              g[d][j] = v[nxt * 4 + j];
+            }
+          }
+        }
+      }
+    }
+    k = steps;
   }
-  B.acc[c] = acc;
+  for (; k < steps; k++)
+  {
+    cell[k] = advance(cell[k]);
+  }
+  acc_io[c] = acc;
 }
 
-// Pass 2, one thread per sample: Nco::run (Nco.cc:186-199) calls libm cosf/sinf; here the
+// Pass 3, one thread per sample: Nco::run (Nco.cc:186-199) calls libm cosf/sinf; here the
 // double-precision cos/sin rounded to float (within 1 ulp of glibc's, so the int16 rails and the
 // int8 output are within 1 LSB: the float-trig tolerance of BASELINE.json), times 16000, (int16_t).
 __global__ void k_fm_rails(const BaseParams B)
@@ -417,6 +574,65 @@ __global__ void k_fm_rails(const BaseParams B)
   qv = qv * 16000.0f;
   const int i16 = (int)(short)(int)iv, q16 = (int)(short)(int)qv;
   reinterpret_cast<uint32_t *>(B.rails)[t] = ((uint32_t)i16 & 0xffffu) | ((uint32_t)q16 << 16);
+}
+
+// ---- WBFM modulator (WbFmModulator.cc:341-356) between the two halves of the cascade --------
+// (pcm, 0) pairs for k_mod<WB_HEAD>
+__global__ void k_wb_pairs(const BaseParams B)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (size_t)B.n * B.n_channels)
+  {
+    reinterpret_cast<uint32_t *>(B.rails)[t] = (uint32_t)(uint16_t)B.pcm[t];
+  }
+}
+
+// per 256 kS/s sample, in parallel: the Nco step of modulateSignal (:601-604) --
+// f = deviation * x / 1024 (float), step = (float)((2*M_PI*f)/256000) (double expression,
+// PhaseAccumulator.cc:105)
+__global__ void k_wb_step(const BaseParams B)
+{
+  const size_t n32 = (size_t)B.n * 32;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n32 * B.n_channels)
+  {
+    return;
+  }
+  const uint32_t c = (uint32_t)(t / n32);
+  const double two_pi = 6.283185307179586476925286766559;
+  float f = B.param[c] * (float)B.mid[t];
+  f = f / 1024.0f;
+  const float step = (float)((two_pi * (double)f) / (double)256000.0f);
+  B.wb[t] = __builtin_bit_cast(uint32_t, step);
+}
+
+// per sample, in parallel: Nco::runFast (Nco.cc:222-257) on the stored phase, x900, (int16_t):
+// phase -> (I,Q) rail pair in place; the call's last two pairs are kept for the next call
+__global__ void k_wb_rails(const BaseParams B)
+{
+  const size_t n32 = (size_t)B.n * 32;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n32 * B.n_channels)
+  {
+    return;
+  }
+  const double two_pi = 6.283185307179586476925286766559;
+  const float phase = __builtin_bit_cast(float, B.wb[t]);
+  const float scaled = phase * 16384.0f;
+  int idx = (int)(short)(int)((double)scaled / two_pi);
+  idx += 8192;
+  idx = max(0, min(16383, idx));
+  float iv = B.cos_t[idx], qv = B.sin_t[idx];
+  iv = iv * 900.0f;
+  qv = qv * 900.0f;
+  const int i16 = (int)(short)(int)iv, q16 = (int)(short)(int)qv;
+  const uint32_t w = ((uint32_t)i16 & 0xffffu) | ((uint32_t)q16 << 16);
+  B.wb[t] = w;
+  const size_t k = t % n32;
+  if (k + 2 >= n32)
+  {
+    B.wbtail_out[(size_t)(t / n32) * 2 + (k + 2 - n32)] = w;
+  }
 }
 
 // =============================================================================

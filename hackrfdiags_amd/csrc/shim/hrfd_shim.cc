@@ -19,6 +19,7 @@
 #include "SsbModulator.h"
 #include "AmModulator.h"
 #include "FmModulator.h"
+#include "WbFmModulator.h"
 #include "Nco.h"
 
 // symbols of the host application the reference code also expects
@@ -548,6 +549,65 @@ void FmModulator::displayInternalInformation(void)
 {
   nprintf(stderr, "\n--------------------------------------------\n");
   nprintf(stderr, "FM Modulator Internal Information (libhrfd, MI355X)\n");
+  nprintf(stderr, "--------------------------------------------\n");
+  nprintf(stderr, "Frequency Deviation:      : %fHz\n", frequencyDeviation);
+}
+
+// ---------------------------------------------------------------- WbFmModulator (wideband)
+WbFmModulator::WbFmModulator(void)
+{
+  frequencyDeviation = 70000;                            // WbFmModulator.cc:204
+  handle = NULL;
+}
+
+WbFmModulator::~WbFmModulator(void)
+{
+  if (handle != NULL)
+  {
+    hrfd_mod_destroy(handle);
+  }
+}
+
+void WbFmModulator::resetModulator(void)
+{
+  if (handle != NULL)
+  {
+    int rc = hrfd_mod_reset(handle, 0);
+    if (rc != HRFD_OK) fatal("hrfd_mod_reset", rc);
+  }
+}
+
+void WbFmModulator::setFrequencyDeviation(float deviaton)
+{
+  // WbFmModulator.cc:313 tests the member, not the argument: kept
+  if ((frequencyDeviation >= 0) && (frequencyDeviation <= 112000))
+  {
+    this->frequencyDeviation = deviaton;
+  }
+  if (handle != NULL) hrfd_mod_set_deviation(handle, 0, deviaton);
+}
+
+void WbFmModulator::acceptData(int16_t *bufferPtr,
+                             uint32_t bufferLength,
+                             int8_t *outputBufferPtr,
+                             uint32_t *outputBufferLengthPtr)
+{
+  int rc;
+  if (handle == NULL)
+  {
+    rc = hrfd_mod_create(HRFD_MOD_WBFM, 1, -1, &handle);
+    if (rc != HRFD_OK) fatal("hrfd_mod_create", rc);
+    // replay the setter history into the fresh handle: one call reproduces any reachable value
+    if (frequencyDeviation != 70000) hrfd_mod_set_deviation(handle, 0, frequencyDeviation);
+  }
+  rc = hrfd_mod_process(handle, bufferPtr, bufferLength, outputBufferPtr, outputBufferLengthPtr);
+  if (rc != HRFD_OK) fatal("hrfd_mod_process", rc);
+}
+
+void WbFmModulator::displayInternalInformation(void)
+{
+  nprintf(stderr, "\n--------------------------------------------\n");
+  nprintf(stderr, "WBFM Modulator Internal Information (libhrfd, MI355X)\n");
   nprintf(stderr, "--------------------------------------------\n");
   nprintf(stderr, "Frequency Deviation:      : %fHz\n", frequencyDeviation);
 }

@@ -157,13 +157,18 @@ int hrfd_demod_process(hrfd_demod *h, const int8_t *iq256k, uint32_t bytes_per_c
  * PCM in, as for SSB.  FM goes through cos/sin: int8 IQ within +-1 LSB of the reference. */
 #define HRFD_MOD_AM     3
 #define HRFD_MOD_FM     4
+/* kind HRFD_MOD_WBFM replaces WbFmModulator::acceptData (WbFmModulator.cc:341-356: PCM x32,
+ * a 256 kS/s Nco with runFast's table driven by deviation * x / 1024, x900, then x8): bit-exact
+ * (the tables are built with the host's libm like the reference's). */
+#define HRFD_MOD_WBFM   5
 int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out);
 int hrfd_mod_destroy(hrfd_mod *h);
 int hrfd_mod_reset(hrfd_mod *h, uint32_t channel);
 int hrfd_mod_set_sideband(hrfd_mod *h, uint32_t channel, int lsb);
 /* AmModulator::setModulationIndex (AmModulator.cc:329-336; default 0.8, accepted in [0, 1]) */
 int hrfd_mod_set_modulation_index(hrfd_mod *h, uint32_t channel, float index);
-/* FmModulator::setFrequencyDeviation (FmModulator.cc:336-346; default 3500 Hz) */
+/* FmModulator::setFrequencyDeviation (FmModulator.cc:336-346; default 3500 Hz) and
+ * WbFmModulator::setFrequencyDeviation (WbFmModulator.cc:307-318; default 70000 Hz) */
 int hrfd_mod_set_deviation(hrfd_mod *h, uint32_t channel, float deviation_hz);
 /* pcm [n_channels][n_per_channel] int16 (SSB) or [n_channels][2*n_per_channel]
  * int16 IQ pairs (INTERP); iq_out [n_channels][512*n_per_channel] int8;

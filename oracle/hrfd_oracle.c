@@ -1151,6 +1151,134 @@ uint32_t orc_fmmod_process(orc_fmmod *h, const int16_t *pcm, uint32_t n, int8_t 
   return n << 9;
 }
 
+/* WbFmModulator (WbFmModulator.cc): acceptData :341-356 = increasePcmSampleRate (:389-425: the
+ * PCM through stages 1-5, x32) -> modulateSignal (:586-625: a 256 kS/s Nco, frequency =
+ * deviation * x / 1024, runFast's table lookup, x900) -> increaseModulatedSampleRate (:447-492:
+ * stages 6-8 on I and Q, x8, (int8_t)).  Deviation 70000 Hz by default (:182), setter range test
+ * on the current member (:300-310, <= 112000); resetModulator leaves the Nco alone. */
+struct orc_wbfmmod
+{
+  float deviation;
+  float acc;
+  q15i_t head[5];
+  q15i_t tail[2][3];
+  float sin_t[16384], cos_t[16384];
+};
+
+orc_wbfmmod *orc_wbfmmod_create(void)
+{
+  struct orc_wbfmmod *h = (struct orc_wbfmmod *)malloc(sizeof(*h));
+  memset(h, 0, sizeof(*h));
+  h->deviation = 70000;
+  q15i_init(&h->head[0], AUDIO_D40, 40, 2);
+  q15i_init(&h->head[1], INTERP_HB8, 8, 2);
+  q15i_init(&h->head[2], INTERP_HB3, 4, 2);
+  q15i_init(&h->head[3], INTERP_HB8, 8, 2);
+  q15i_init(&h->head[4], INTERP_HB8, 8, 2);
+  for (int r = 0; r < 2; r++)
+  {
+    q15i_init(&h->tail[r][0], INTERP_HB3, 4, 2);
+    q15i_init(&h->tail[r][1], INTERP_HB2, 4, 2);
+    q15i_init(&h->tail[r][2], INTERP_HB1, 4, 2);
+  }
+  /* Nco.cc:50-61 (same tables as orc_nco_create) */
+  float inc = (float)(2 * M_PI / 16384);
+  float ang = (float)(-M_PI);
+  for (int i = 0; i < 16384; i++)
+  {
+    h->sin_t[i] = sinf(ang);
+    h->cos_t[i] = cosf(ang);
+    ang += inc;
+  }
+  return h;
+}
+
+void orc_wbfmmod_destroy(orc_wbfmmod *h)
+{
+  free(h);
+}
+
+void orc_wbfmmod_reset(orc_wbfmmod *h)
+{
+  for (int s = 0; s < 5; s++)
+  {
+    q15i_reset(&h->head[s]);
+  }
+  for (int r = 0; r < 2; r++)
+  {
+    for (int s = 0; s < 3; s++)
+    {
+      q15i_reset(&h->tail[r][s]);
+    }
+  }
+}
+
+void orc_wbfmmod_set_deviation(orc_wbfmmod *h, float deviation)
+{
+  if ((h->deviation >= 0) && (h->deviation <= 112000))
+  {
+    h->deviation = deviation;
+  }
+}
+
+uint32_t orc_wbfmmod_process(orc_wbfmmod *h, const int16_t *pcm, uint32_t n, int8_t *iq_out)
+{
+  const size_t n32 = (size_t)n * 32;
+  int16_t *a = (int16_t *)malloc((n32 * 8 + 2) * sizeof(int16_t));
+  int16_t *b = (int16_t *)malloc((n32 * 8 + 2) * sizeof(int16_t));
+  int16_t *mi = (int16_t *)malloc((n32 + 1) * sizeof(int16_t));
+  int16_t *mq = (int16_t *)malloc((n32 + 1) * sizeof(int16_t));
+  uint32_t cnt = n;
+  memcpy(a, pcm, (size_t)n * sizeof(int16_t));
+  for (int s = 0; s < 5; s++)
+  {
+    q15i_run(&h->head[s], a, cnt, b);
+    cnt *= 2;
+    int16_t *t = a; a = b; b = t;
+  }
+  for (size_t i = 0; i < n32; i++)
+  {
+    float f = h->deviation * (float)a[i] / 1024;           /* :601 */
+    float step = (float)((2 * M_PI * f) / 256000.0f);      /* PhaseAccumulator.cc:105 */
+    float phase = h->acc;
+    h->acc += step;
+    while (h->acc > M_PI)
+    {
+      h->acc -= (2 * M_PI);
+    }
+    while (h->acc < (-M_PI))
+    {
+      h->acc += (2 * M_PI);
+    }
+    int idx = d2i16(phase * 16384 / (2 * M_PI));          /* Nco.cc:231 */
+    idx += 8192;
+    if (idx < 0) idx = 0;
+    else if (idx > 16383) idx = 16383;
+    float iv = h->cos_t[idx], qv = h->sin_t[idx];
+    iv *= 900;
+    qv *= 900;
+    mi[i] = f2i16(iv);
+    mq[i] = f2i16(qv);
+  }
+  for (int r = 0; r < 2; r++)
+  {
+    cnt = (uint32_t)n32;
+    memcpy(a, r ? mq : mi, n32 * sizeof(int16_t));
+    for (int s = 0; s < 3; s++)
+    {
+      q15i_run(&h->tail[r][s], a, cnt, b);
+      cnt *= 2;
+      int16_t *t = a; a = b; b = t;
+    }
+    for (uint32_t i = 0; i < cnt; i++)
+    {
+      iq_out[2 * (size_t)i + r] = (int8_t)(uint8_t)((uint16_t)a[i] & 0xffu);
+    }
+  }
+  free(a); free(b); free(mi); free(mq);
+  return n << 9;                                           /* :354: (32 n) << 4 */
+}
+
 /* ------------------------------------------------------------------ Nco */
 struct orc_nco
 {

@@ -27,6 +27,7 @@ typedef struct orc_demod orc_demod;   /* one {Am,Fm,WbFm,Ssb}Demodulator        
 typedef struct orc_ssbmod orc_ssbmod; /* SsbModulator                               */
 typedef struct orc_ammod orc_ammod;   /* AmModulator                                */
 typedef struct orc_fmmod orc_fmmod;   /* FmModulator                                */
+typedef struct orc_wbfmmod orc_wbfmmod; /* WbFmModulator                            */
 typedef struct orc_interp orc_interp; /* signals/interpolateSignal cascade          */
 typedef struct orc_nco orc_nco;       /* Nco + PhaseAccumulator                     */
 
@@ -71,6 +72,12 @@ void orc_fmmod_destroy(orc_fmmod *h);
 void orc_fmmod_reset(orc_fmmod *h);
 void orc_fmmod_set_deviation(orc_fmmod *h, float deviation);
 uint32_t orc_fmmod_process(orc_fmmod *h, const int16_t *pcm, uint32_t n, int8_t *iq_out);
+
+orc_wbfmmod *orc_wbfmmod_create(void);
+void orc_wbfmmod_destroy(orc_wbfmmod *h);
+void orc_wbfmmod_reset(orc_wbfmmod *h);
+void orc_wbfmmod_set_deviation(orc_wbfmmod *h, float deviation);
+uint32_t orc_wbfmmod_process(orc_wbfmmod *h, const int16_t *pcm, uint32_t n, int8_t *iq_out);
 
 orc_interp *orc_interp_create(void);
 void orc_interp_destroy(orc_interp *h);

@@ -36,6 +36,7 @@
 #include "SsbModulator.h"
 #include "AmModulator.h"
 #include "FmModulator.h"
+#include "WbFmModulator.h"
 #include "Nco.h"
 #include "Interpolator_int16.h"
 #include "FirFilter_int16.h"
@@ -342,6 +343,19 @@ uint32_t ref_fmmod_process(void *hv, const int16_t *pcmPtr, uint32_t sampleCount
   std::vector<int16_t> scratch(pcmPtr, pcmPtr + sampleCount);
   uint32_t outBytes = 0;
   ((FmModulator *)hv)->acceptData(scratch.data(), sampleCount, iqOut, &outBytes);
+  return outBytes;
+}
+
+// WbFmModulator::acceptData (WbFmModulator.cc:341-356); sampleCount <= 512.
+void *ref_wbfmmod_create(void) { return new WbFmModulator(); }
+void ref_wbfmmod_destroy(void *hv) { delete (WbFmModulator *)hv; }
+void ref_wbfmmod_reset(void *hv) { ((WbFmModulator *)hv)->resetModulator(); }
+void ref_wbfmmod_set_deviation(void *hv, float deviation) { ((WbFmModulator *)hv)->setFrequencyDeviation(deviation); }
+uint32_t ref_wbfmmod_process(void *hv, const int16_t *pcmPtr, uint32_t sampleCount, int8_t *iqOut)
+{
+  std::vector<int16_t> scratch(pcmPtr, pcmPtr + sampleCount);
+  uint32_t outBytes = 0;
+  ((WbFmModulator *)hv)->acceptData(scratch.data(), sampleCount, iqOut, &outBytes);
   return outBytes;
 }
 

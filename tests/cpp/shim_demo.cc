@@ -15,6 +15,7 @@
 #include "SsbModulator.h"
 #include "AmModulator.h"
 #include "FmModulator.h"
+#include "WbFmModulator.h"
 
 uint32_t radio_adjustableReceiveGainInDb = 0;          // Radio.cc:15
 void nprintf(FILE *s, const char *formatPtr, ...)      // diagUi.cc:2881
@@ -34,7 +35,7 @@ int main(int argc, char **argv)
 {
   if (argc < 4)
   {
-    fprintf(stderr, "usage: %s <mode> <outer|inner|ssbmod|ammod|fmmod> <block_bytes>\n", argv[0]);
+    fprintf(stderr, "usage: %s <mode> <outer|inner|ssbmod|ammod|fmmod|wbfmmod> <block_bytes>\n", argv[0]);
     return 2;
   }
   const int mode = atoi(argv[1]);
@@ -58,16 +59,19 @@ int main(int argc, char **argv)
     return 0;
   }
 
-  if (strcmp(argv[2], "ammod") == 0 || strcmp(argv[2], "fmmod") == 0)
+  if (strcmp(argv[2], "ammod") == 0 || strcmp(argv[2], "fmmod") == 0 || strcmp(argv[2], "wbfmmod") == 0)
   {
     // the other two modulators behind the same call (BasebandDataProcessor.cc:660-697); <mode> is
     // the setter's argument in thousandths when non-zero (modulation index / deviation in Hz)
     const bool am = strcmp(argv[2], "ammod") == 0;
+    const bool wb = strcmp(argv[2], "wbfmmod") == 0;
     AmModulator amMod;
     FmModulator fmMod;
+    WbFmModulator wbMod;
     if (mode != 0)
     {
       if (am) amMod.setModulationIndex((float)mode / 1000);
+      else if (wb) wbMod.setFrequencyDeviation((float)mode);
       else fmMod.setFrequencyDeviation((float)mode);
     }
     std::vector<int16_t> pcm(512);
@@ -76,6 +80,7 @@ int main(int argc, char **argv)
     {
       uint32_t outBytes = 0;
       if (am) amMod.acceptData(pcm.data(), 512, iq.data(), &outBytes);
+      else if (wb) wbMod.acceptData(pcm.data(), 512, iq.data(), &outBytes);
       else fmMod.acceptData(pcm.data(), 512, iq.data(), &outBytes);
       fwrite(iq.data(), 1, outBytes, stdout);
     }

@@ -64,7 +64,7 @@ class Oracle:
         L.orc_demod_set_sideband.argtypes = [C.c_void_p, C.c_int]
         L.orc_demod_process.restype = C.c_uint32
         L.orc_demod_process.argtypes = [C.c_void_p, _i8p, C.c_uint32, _i16p, C.c_uint32]
-        for kind, setter in (("ammod", "set_index"), ("fmmod", "set_deviation")):
+        for kind, setter in (("ammod", "set_index"), ("fmmod", "set_deviation"), ("wbfmmod", "set_deviation")):
             getattr(L, f"orc_{kind}_create").restype = C.c_void_p
             getattr(L, f"orc_{kind}_create").argtypes = []
             getattr(L, f"orc_{kind}_destroy").argtypes = [C.c_void_p]
@@ -165,6 +165,9 @@ class Oracle:
 
     def fmmod(self):
         return _Mod(self.lib, "orc", "fmmod", "set_deviation")
+
+    def wbfmmod(self):
+        return _Mod(self.lib, "orc", "wbfmmod", "set_deviation")
 
     def interp(self):
         return _OrcInterp(self.lib)
@@ -368,7 +371,7 @@ class Ref:
         L.ref_demod_set_sideband.argtypes = [C.c_void_p, C.c_int]
         L.ref_demod_process.restype = C.c_uint32
         L.ref_demod_process.argtypes = [C.c_void_p, _i8p, C.c_uint32, _i16p, C.c_uint32]
-        for kind, setter in (("ammod", "set_index"), ("fmmod", "set_deviation")):
+        for kind, setter in (("ammod", "set_index"), ("fmmod", "set_deviation"), ("wbfmmod", "set_deviation")):
             getattr(L, f"ref_{kind}_create").restype = C.c_void_p
             getattr(L, f"ref_{kind}_create").argtypes = []
             getattr(L, f"ref_{kind}_destroy").argtypes = [C.c_void_p]
@@ -444,6 +447,9 @@ class Ref:
 
     def fmmod(self):
         return _Mod(self.lib, "ref", "fmmod", "set_deviation", max_call=512)
+
+    def wbfmmod(self):
+        return _Mod(self.lib, "ref", "wbfmmod", "set_deviation", max_call=512)
 
     def nco(self, fs, f):
         return _Nco(self.lib, "ref", fs, f)

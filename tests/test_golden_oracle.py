@@ -72,3 +72,8 @@ def test_am_modulator(oracle, case):
 @pytest.mark.parametrize("case", MAN_MOD["fm"], ids=lambda c: c["key"])
 def test_fm_modulator(oracle, case):
     G.check_fm_mod(oracle, ARR_MOD, case, tol=0)
+
+
+@pytest.mark.parametrize("case", MAN_MOD["wbfm"], ids=lambda c: c["key"])
+def test_wbfm_modulator(oracle, case):
+    G.check_wbfm_mod(oracle, ARR_MOD, case)

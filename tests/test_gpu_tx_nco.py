@@ -129,7 +129,7 @@ def _mod_case(oracle, kind, api_kind, tol):
     off, diff, total = 0, 0, 0
     for k, n in enumerate([512, 512, 100, 33, 1, 700, 512]):
         if k == 2:
-            v = 0.4 if kind == "ammod" else 1500.0
+            v = {"ammod": 0.4, "fmmod": 1500.0, "wbfmmod": 30000.0}[kind]
             m.set_param(v, channel=1)
             os_[1].set_param(v)
         if k == 5:
@@ -152,6 +152,12 @@ def test_am_modulator_bit_exact(oracle):
     assert _mod_case(oracle, "ammod", api.MOD_AM, 0) == 0.0
 
 
+def test_wbfm_modulator_bit_exact(oracle):
+    """WbFmModulator: integer cascades around a table-lookup Nco whose phase recurrence is
+    reproduced operation for operation -- no tolerance"""
+    assert _mod_case(oracle, "wbfmmod", api.MOD_WBFM, 0) == 0.0
+
+
 def test_fm_modulator_within_one_lsb(oracle):
     """FmModulator's Nco calls libm cosf/sinf (Nco.cc:186-199); the device evaluates cos/sin in
     double and rounds to float.  The phase recurrence is exact, so the only difference is an
@@ -172,3 +178,8 @@ def test_golden_am_modulator(engine, case):
 @pytest.mark.parametrize("case", MAN_MOD["fm"], ids=lambda c: c["key"])
 def test_golden_fm_modulator(engine, case):
     G.check_fm_mod(engine, ARR_MOD, case, tol=1)
+
+
+@pytest.mark.parametrize("case", MAN_MOD["wbfm"], ids=lambda c: c["key"])
+def test_golden_wbfm_modulator(engine, case):
+    G.check_wbfm_mod(engine, ARR_MOD, case)

@@ -204,7 +204,7 @@ def test_nco(oracle, ref):
 
 
 # ---------------------------------------------------------------- AM / FM modulators
-@pytest.mark.parametrize("kind", ["ammod", "fmmod"])
+@pytest.mark.parametrize("kind", ["ammod", "fmmod", "wbfmmod"])
 @pytest.mark.parametrize("src", ["lcg", "tone", "fullscale"])
 def test_modulators_am_fm(oracle, ref, kind, src):
     """the restated AM / FM modulators against the compiled reference, bit for bit (the FM one
@@ -219,7 +219,7 @@ def test_modulators_am_fm(oracle, ref, kind, src):
         pcm = np.where(np.arange(n) % 7 < 3, 32767, -32768).astype(np.int16)
     o, r = getattr(oracle, kind)(), getattr(ref, kind)()
     assert (o.process(pcm[:512]) == r.process(pcm[:512])).all()
-    param = 0.35 if kind == "ammod" else 1200.0
+    param = {"ammod": 0.35, "fmmod": 1200.0, "wbfmmod": 25000.0}[kind]
     o.set_param(param); r.set_param(param)
     assert (o.process(pcm[512:1024]) == r.process(pcm[512:1024])).all()
     o.reset(); r.reset()

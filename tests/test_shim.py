@@ -72,10 +72,11 @@ def test_shim_ssb_modulator_reproduces_oracle(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,arg,param,tol", [("ammod", "500", 0.5, 0), ("fmmod", "1200", 1200.0, 1)])
+@pytest.mark.parametrize("kind,arg,param,tol", [("ammod", "500", 0.5, 0), ("fmmod", "1200", 1200.0, 1),
+                                                ("wbfmmod", "30000", 30000.0, 0)])
 def test_shim_am_fm_modulators_reproduce_oracle(oracle, kind, arg, param, tol):
-    """AmModulator / FmModulator shim classes (reference names and setters) against the oracle:
-    AM bit-exact, FM within the +-1 LSB of the trig path"""
+    """AmModulator / FmModulator / WbFmModulator shim classes (reference names and setters) against
+    the oracle: AM and WBFM bit-exact, FM within the +-1 LSB of the trig path"""
     _build_demo()
     pcm = synth.lcg_pcm(9, 2 * 512)
     out = subprocess.run([DEMO, arg, kind, "0"], input=pcm.tobytes(), stdout=subprocess.PIPE,
