@@ -93,6 +93,10 @@ class Rx:
         check(self.L.hrfd_rx_debug_atan_eval(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "hrfd_rx_debug_atan_eval")
         return out
 
+    def debug_set_run_len(self, blocks: int):
+        """consecutive blocks of a channel per WBFM workgroup (0 = automatic)"""
+        check(self.L.hrfd_rx_debug_set_run_len(self.h, int(blocks)), "hrfd_rx_debug_set_run_len")
+
     def debug_set_warm(self, warm: int):
         check(self.L.hrfd_rx_debug_set_warm(self.h, warm), "hrfd_rx_debug_set_warm")
 

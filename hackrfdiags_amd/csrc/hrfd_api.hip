@@ -190,6 +190,7 @@ struct hrfd_rx
   size_t dbg_cap = 0;
   int warm = kWarm;
   int stagger = 4;
+  int run_len = 0;                     // test hook: blocks per workgroup run of k_rx_wbfm (0 = automatic)
   uint32_t last_counters[kNumCounters] = {0};
 };
 
@@ -514,6 +515,17 @@ extern "C" int hrfd_rx_debug_stamps(hrfd_rx *h, uint32_t cap_groups, unsigned lo
   return HRFD_OK;
 }
 
+// test hook: consecutive blocks of a channel that one k_rx_wbfm workgroup walks (0 = automatic)
+extern "C" int hrfd_rx_debug_set_run_len(hrfd_rx *h, int blocks)
+{
+  if (h == nullptr || blocks < 0 || blocks > 64)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_set_run_len: 0..64");
+  }
+  h->run_len = blocks;
+  return HRFD_OK;
+}
+
 extern "C" int hrfd_rx_debug_set_stagger(hrfd_rx *h, int units)
 {
   if (h == nullptr || units < 0)
@@ -723,6 +735,8 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.serial = opt.serial;
   P.src256 = opt.src256;
   P.stagger = h->stagger & 63;
+  P.run_len = 1;
+  P.n_runs = n_blocks;
   P.dbg_flags = h->stagger >> 8;
   P.out_blocks = opt.out_blocks;
   P.out_b0 = opt.out_b0;
@@ -759,7 +773,23 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     }
     P.chan_list = h->d_lists + (size_t)m * h->n_channels;
     P.n_list = n;
-    const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+    // runs of consecutive blocks per workgroup (only a run's first block re-produces the history
+    // in front of it): as long as possible while the launch still fills both workgroup slots of
+    // every CU
+    const uint32_t groups = 8u * ((n + 7u) / 8u);
+    uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : 8u;
+    run_len = std::min(run_len, n_blocks);
+    while (h->run_len <= 0 && run_len > 1 && groups * ((n_blocks + run_len - 1) / run_len) < 512u)
+    {
+      run_len--;
+    }
+    if (opt.serial || opt.src256)
+    {
+      run_len = 1;
+    }
+    P.run_len = run_len;
+    P.n_runs = (n_blocks + run_len - 1) / run_len;
+    const uint32_t grid = groups * P.n_runs;
     P.dbg = (h->d_dbg != nullptr && (size_t)grid * 8 <= h->dbg_cap && m == HRFD_MODE_WBFM) ? h->d_dbg : nullptr;
     if (m == HRFD_MODE_NONE)
     {

@@ -93,6 +93,7 @@ struct RxParams
                                //    2 bytes per sample, no front end, no squelch
   int32_t dbg_flags;           // timing experiments only (results are wrong when non-zero)
   int32_t stagger;             // start-up delay of odd dispatch layers, in units of s_sleep(127) (~8k cycles)
+  uint32_t run_len, n_runs;    // k_rx_wbfm: consecutive blocks of a channel per workgroup; runs per channel
   uint32_t out_blocks;         // outputs are laid out [C][out_blocks][...]; this launch fills
   uint32_t out_b0;             //   blocks out_b0 .. out_b0 + n_blocks - 1 of that layout
   const uint32_t *chan_list;   // channels of this launch (all in the same mode)

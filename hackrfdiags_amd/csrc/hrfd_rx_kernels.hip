@@ -547,6 +547,7 @@ struct StreamCtx
   const uint8_t *atc;            // arithmetic atan2: LDS copies of the correction bytes and of 1/a
   const float *ati;
   uint4 tab;                     // this thread's 16 bytes of them, loaded at kernel entry (in flight)
+  bool publish;                  // ... and still to be published to LDS by this produce_stream call
   bool first;
 };
 
@@ -665,7 +666,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   const int cbeg = REPAIR ? c0 - 1 : c0;
   if (cbeg >= c1)
   {
-    if (ARITH && !REPAIR)
+    if (ARITH && !REPAIR && X.publish)
     {
       publish_atan_tables(X);
     }
@@ -811,7 +812,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
     q[k] = load_chunk<S256>(X, cbeg + k);
     th[k] = 0.0f;
   }
-  if (ARITH && !REPAIR)
+  if (ARITH && !REPAIR && X.publish)
   {
     publish_atan_tables(X);
   }
@@ -989,23 +990,58 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   // arithmetic atan2 tables (zero-sized in the gather build of the kernel)
   __shared__ __attribute__((aligned(16))) uint8_t atcorr[ARITH ? kCorrBytes : 16];
   __shared__ __attribute__((aligned(16))) float atinv[ARITH ? kInvEntries : 4];
-  static_assert(sizeof(uint32_t) * kMaxNV + kCorrBytes + sizeof(float) * kInvEntries + 512 <= 81920,
+  static_assert(sizeof(uint32_t) * kMaxNV + kCorrBytes + sizeof(float) * kInvEntries + 640 <= 81920,
                 "two workgroups per CU need <= 80 KiB of LDS each");
   __shared__ uint32_t red[kWaves];
+  __shared__ int8_t dbfs8[128];         // the reachable part of the dBFS table (0..48), so that the
+                                        // squelch decision after phase A does not wait for a global load
   __shared__ float tailcarry[2];        // theta, b0*x of the block's last sample
   __shared__ uint32_t edges[kWaves][4]; // per run: theta of its first two and last two samples
 
-  uint32_t ci, b;
-  if (!map_unit(blockIdx.x, P.n_list, P.n_blocks, ci, b))
+  // A workgroup owns a RUN of up to P.run_len consecutive blocks of one channel and walks them in
+  // order.  Only the run's first block produces the history in front of it; for the others the
+  // tail of v that the previous block produced is carried over in two registers per thread
+  // (it has to survive phase B, which overwrites v with y in place) and put back in front of
+  // the new block.  Everything else -- tiles, speculation, checks -- is per block, as before.
+  uint32_t ci, run;
+  if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
   {
     return;
   }
   const uint32_t c = P.chan_list[ci];
-  const int tid = threadIdx.x;
+  const int n256 = (int)P.n256;
+  const uint32_t b_first = run * P.run_len;
+  const uint32_t b_end = min(P.n_blocks, b_first + P.run_len);
+  if (P.run_len > 1 && ((blockIdx.x >> 8) & 1u) != 0u)
+  {
+    // the two workgroups that share a CU (ids w and w + 256) would otherwise walk their runs in
+    // lockstep and sit in the single-wave phase B at the same time
+    for (int i = 0; i < P.stagger; i++)
+    {
+      __builtin_amdgcn_s_sleep(127);
+    }
+  }
+  uint32_t keep0 = 0u, keep1 = 0u;                       // v[n256 - hal + tid], v[n256 - hal + 1024 + tid]
+  for (uint32_t b = b_first; b < b_end; b++)
+  {
+  // Everything derived from the thread index is re-derived per block behind an opaque copy:
+  // otherwise the compiler hoists dozens of per-lane constants out of this loop, keeps them
+  // alive across all phases and spills them.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: keep it scalar
-  const int n256 = (int)P.n256;
   const bool first = (b == 0);
+  const bool cont = (b > b_first);                       // the previous block of the run is ours
+  if (cont)
+  {
+    __syncthreads();                                     // the previous block's phase C is done with the buffer
+    lds[tid] = keep0;
+    if (tid + kThreads < P.hal)
+    {
+      lds[tid + kThreads] = keep1;
+    }
+  }
   const int hal = P.hal;
   const ChanState *st = P.state + c;
   const ChanCfg cfg = P.cfg[c];
@@ -1026,17 +1062,19 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   X.kgain = cfg.gain_wbfm / 75000.0f;
   X.kgain = X.kgain * 32767.0f;
   X.hal = hal;
-  X.vstart = first ? 0 : -hal;                           // first position of v we produce
+  X.vstart = (first || cont || ablate(P, 256)) ? 0 : -hal;   // first position of v we produce (256: TIMING EXPERIMENT ONLY, no history)
   X.n256 = n256;
   X.lane = lane;
   X.first = first;
   X.atc = atcorr;
   X.ati = atinv;
-  // the dBFS table (128 entries are reachable) rides in two registers per lane, so that the
-  // squelch decision after phase A does not wait for a global load
-  const int dbfs_lo = P.dbfs[lane], dbfs_hi = P.dbfs[64 + lane];
+  if (!cont && tid < 128)
+  {
+    dbfs8[tid] = (int8_t)P.dbfs[tid];                    // read after the barrier that ends phase A
+  }
   X.tab = make_uint4(0u, 0u, 0u, 0u);
-  if (ARITH)
+  X.publish = ARITH && !cont;                            // the atan2 tables go to LDS once per workgroup
+  if (ARITH && !cont)
   {
     // request this thread's piece of the atan2 tables now; produce_stream publishes them to LDS
     if (tid < kCorrBytes / 16)
@@ -1104,8 +1142,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   }
   const uint32_t mean_mag = total / (uint32_t)n256;      // SignalDetector.cc:255
   // DbfsCalculator::convertMagnitudeToDbFs (:111-147) with a 7-bit full scale
-  const int ms = __builtin_amdgcn_readfirstlane((int)min(mean_mag, 127u));
-  int32_t dbfs = ((ms < 64) ? __builtin_amdgcn_readlane(dbfs_lo, ms) : __builtin_amdgcn_readlane(dbfs_hi, ms - 64)) - 42;
+  int32_t dbfs = (int32_t)dbfs8[min(mean_mag, 127u)] - 42;
   dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
   const bool present = dbfs >= cfg.threshold;
   // Squelch::run + SignalTracker::run: allowed = present || tracking.  For b > 0
@@ -1127,9 +1164,16 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
     reinterpret_cast<uint32_t *>(so->fe_tail)[tid] =
         reinterpret_cast<const uint32_t *>(blk + P.block_bytes - 16)[tid];
   }
-  if (MODE != 3 || !allowed)
+  if (MODE != 3)
   {
-    return;                                              // demodulator untouched (state frozen)
+    continue;                                            // front end + squelch only: next block of the run
+  }
+  if (!allowed)
+  {
+    // demodulator untouched (state frozen).  Only a call's very first block can get here; in a
+    // multi-block call that is a gate violation, the launch is not committed and the host replays
+    // block by block, so the rest of this run is not worth producing.
+    break;
   }
 
   // ----------------------------------------------------------------- phase B
@@ -1147,14 +1191,22 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   HRFD_STAMP(2)
   if (wave == 0)
   {
-    // the recurrence is a long dependent chain that needs few issue slots: let it
-    // win arbitration against the streaming waves of the neighbouring workgroup
-    __builtin_amdgcn_s_setprio(3);
     // Patch the two provisional samples at the start of every run but the first
     // (produce_stream): they need theta of the two samples before the run, which
-    // the neighbouring wave produced.  One lane per run boundary.
+    // the neighbouring wave produced.  One lane per run boundary.  In a continuation block
+    // the first run starts provisionally too: its two samples need the previous block's last
+    // theta and b0*x, still in tailcarry[].
     {
       const int nruns = min(nch, kWaves);
+      if (cont && lane == 0)
+      {
+        const float tm1 = tailcarry[0], pm1 = tailcarry[1];
+        const float t0 = u2f(edges[0][0]), t1 = u2f(edges[0][1]);
+        const float p0 = numerator_p(t0, tm1, X.kgain);
+        const float p1 = numerator_p(t1, t0, X.kgain);
+        lds[0 + hal] = f2u(p0 + pm1);
+        lds[1 + hal] = f2u(p1 + p0);
+      }
       if (lane >= 1 && lane < nruns)
       {
         const int w = lane;
@@ -1174,6 +1226,21 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
         tailcarry[1] = numerator_p(tl1, tl2, X.kgain);
       }
     }
+  }
+  if (b + 1 < b_end)
+  {
+    // the next block of the run continues from this one: keep the tail of v (phase B is about
+    // to overwrite it with y)
+    __syncthreads();
+    keep0 = lds[n256 + tid];                             // position n256 - hal + tid
+    keep1 = (tid + kThreads < hal) ? lds[n256 + kThreads + tid] : 0u;
+    __syncthreads();
+  }
+  if (wave == 0)
+  {
+    // the recurrence is a long dependent chain that needs few issue slots: let it
+    // win arbitration against the streaming waves of the neighbouring workgroup
+    __builtin_amdgcn_s_setprio(3);
     const float a1 = DEEMPH_A1;
     if (P.serial)
     {
@@ -1273,7 +1340,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 
   if (ablate(P, 4))                                     // TIMING EXPERIMENT ONLY: skip phase C
   {
-    return;
+    continue;
   }
   // ----------------------------------------------------------------- phase C
   // C1: s[n] = (int16_t)y[n] (WbFmDemodulator.cc:476), repacked in place as
@@ -1380,6 +1447,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
       so->wb_v[tid] = (int16_t)V16[kVHist + (n256 >> 4) - kWbV + tid];
     }
   }
+  }  // blocks of the run
 }
 
 // =============================================================================

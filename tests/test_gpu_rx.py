@@ -374,3 +374,44 @@ def test_atan2_kernels_agree(oracle, kind):
         want = _oracle_stream(oracle, WBFM, xs[c], B)
         for b in range(B):
             assert (out[1][c, b] == want[b][0]).all(), (c, b)
+
+
+# ---------------------------------------------------------------- runs of blocks per workgroup
+@pytest.mark.parametrize("run_len", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("kind", ["lcg", "fmtone"])
+def test_wbfm_block_runs_match_oracle(oracle, run_len, kind):
+    """a WBFM workgroup walks `run_len` consecutive blocks of its channel, carrying the tail of
+    the phase-difference stream from block to block instead of re-producing it: any run length
+    (incl. ones that do not divide the block count) must give the sequential result, over two
+    calls so that the carried state is exercised too"""
+    C, B = 3, 7
+    xs = np.stack([synth.make_input(kind, 50 + c, 2 * B) for c in range(C)]).reshape(C, 2 * B, BLK)
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    rx.debug_set_run_len(run_len)
+    r1 = rx.process_block(xs[:, :B], B)
+    r2 = rx.process_block(xs[:, B:], B)
+    pcm = np.concatenate([r1[0], r2[0]], axis=1)
+    for c in range(C):
+        want = _oracle_stream(oracle, WBFM, xs[c], 2 * B)
+        for b in range(2 * B):
+            assert (pcm[c, b] == want[b][0]).all(), (run_len, c, b)
+    assert rx.debug_counters()[5] == 0           # every launch verified clean and was committed
+
+
+@pytest.mark.parametrize("run_len", [2, 4])
+def test_wbfm_block_runs_with_repairs(oracle, run_len):
+    """short warm-up forces tile repairs, also in continuation blocks (whose history comes from
+    the carried tail) -- still bit-exact"""
+    C, B = 2, 4
+    xs = np.stack([synth.make_input("fmtone" if c else "lcg", 80 + c, B) for c in range(C)]).reshape(C, B, BLK)
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    rx.debug_set_run_len(run_len)
+    rx.debug_set_warm(256)
+    pcm = rx.process_block(xs, B)[0]
+    for c in range(C):
+        want = _oracle_stream(oracle, WBFM, xs[c], B)
+        for b in range(B):
+            assert (pcm[c, b] == want[b][0]).all(), (run_len, c, b)
+    assert rx.debug_counters()[4] > 0

@@ -25,6 +25,10 @@ x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev, generato
 pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
 rx = api.Rx(C); rx.set_mode(api.WBFM)
 rx.debug_enable_timing(8)
+if os.environ.get("HRFD_RUNLEN"):
+    rx.debug_set_run_len(int(os.environ["HRFD_RUNLEN"]))
+if os.environ.get("HRFD_STAGGER"):
+    rx.debug_set_stagger(int(os.environ["HRFD_STAGGER"]))
 if os.environ.get("HRFD_ATAN"):
     rx.debug_set_atan(int(os.environ["HRFD_ATAN"]))
 if os.environ.get("HRFD_FLAGS"):

@@ -13,6 +13,8 @@ dev = torch.device("cuda:0")
 x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev)
 pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
 rx = api.Rx(C); rx.set_mode(api.WBFM); rx.debug_set_stagger(stag)
+if os.environ.get('HRFD_RUNLEN'):
+    rx.debug_set_run_len(int(os.environ['HRFD_RUNLEN']))
 if os.environ.get('HRFD_WARM'):
     rx.debug_set_warm(int(os.environ['HRFD_WARM']))
 grid = 8 * ((C + 7) // 8) * B
