@@ -179,6 +179,55 @@ def bench_ssbmod(args, api, device, rank, world, dist):
         dist.destroy_process_group()
 
 
+def bench_ingest(args, api, device, rank, world, dist):
+    """PCIe-inclusive rate: host batches of [channels][blocks][262144] int8 in pinned memory through
+    hrfd_ingest_* (H2D, WBFM demodulation, D2H of the PCM on three streams, two batches in
+    flight).  Not the headline metric: the boundary hands over host buffers here."""
+    from hackrfdiags_amd import shard
+    C, B = args.channels, min(args.blocks, 4)
+    rx = api.Rx(C, device=device.index)
+    rx.set_mode(api.WBFM)
+    ing = api.Ingest(rx, BLOCK, B, 2)
+    x = make_fm_batch(C, B, device, first_channel=rank * C).cpu().numpy()
+    for _ in range(2):                                   # both pinned slots hold valid IQ
+        ing.acquire()[...] = x
+        ing.submit(0)
+    for _ in range(2):
+        ing.collect()
+    for _ in range(args.warmup):
+        ing.acquire(); ing.submit(0); ing.collect()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ing.acquire(); ing.submit(0)
+    for i in range(args.steps):
+        if i + 1 < args.steps:
+            ing.acquire(); ing.submit(0)                 # batch i+1 travels while batch i is demodulated
+        ing.collect()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device)
+    samples = C * B * (BLOCK // 2)
+    value = world * samples * args.steps / elapsed / 1e6
+    if rank == 0:
+        print(json.dumps({
+            "metric": "IQ MSamples/s demodulated, host to host (pinned batches over PCIe, WBFM) per GPU",
+            "value": round(value, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int8 IQ -> int16 PCM", "data": "synthetic",
+            "config": {"workload": f"{C} WBFM channels, batches of {B} blocks from pinned host memory, 2 in flight "
+                                   f"(hrfd_ingest_*: H2D + kernels + D2H overlapped)", "channels_per_gpu": C,
+                       "blocks_per_step": B},
+            "pcie_GBps": round(C * B * BLOCK * args.steps / elapsed / 1e9, 2),
+            "replayed_batches": ing.replayed(),
+        }), flush=True)
+    ing.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def pmc_traffic_bytes(args, C, B):
     """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_round.sh
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs of this same command; the summary
@@ -204,7 +253,7 @@ def main():
     ap.add_argument("--channels", type=int, default=256, help="channels per GPU (BASELINE config 2)")
     ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
     ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")
-    ap.add_argument("--workload", choices=["wbfm", "mixed", "ssbmod", "ammod", "fmmod", "wbfmmod"], default="wbfm",
+    ap.add_argument("--workload", choices=["wbfm", "mixed", "ssbmod", "ammod", "fmmod", "wbfmmod", "ingest"], default="wbfm",
                     help="wbfm = BASELINE config 2 (the headline); mixed = config 3 (AM+FM+WBFM+SSB bank, "
                          "per-mode dispatch); ssbmod = config 5 (SSB modulator, 8-stage x256 interpolator)")
     ap.add_argument("--scatter", action="store_true",
@@ -229,6 +278,8 @@ def main():
 
     if args.workload in ("ssbmod", "ammod", "fmmod", "wbfmmod"):
         return bench_ssbmod(args, api, device, rank, world, dist)
+    if args.workload == "ingest":
+        return bench_ingest(args, api, device, rank, world, dist)
 
     C, B = args.channels, args.blocks
     gen = make_fm_batch if args.signal == "fmtone" else make_random_batch

@@ -97,6 +97,12 @@ def load() -> C.CDLL:
     L.hrfd_demod_set_gain.argtypes = [_vp, C.c_uint32, C.c_float]
     L.hrfd_demod_set_sideband.argtypes = [_vp, C.c_uint32, C.c_int]
     L.hrfd_demod_process.argtypes = [_vp, _vp, C.c_uint32, _vp, _vp]
+    L.hrfd_ingest_create.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_vp)]
+    L.hrfd_ingest_destroy.argtypes = [_vp]
+    L.hrfd_ingest_acquire.argtypes = [_vp, C.POINTER(_vp)]
+    L.hrfd_ingest_submit.argtypes = [_vp, C.c_uint32]
+    L.hrfd_ingest_collect.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]
+    L.hrfd_ingest_replayed.argtypes = [_vp, C.POINTER(C.c_uint64)]
     L.hrfd_mod_create.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(_vp)]
     L.hrfd_mod_destroy.argtypes = [_vp]
     L.hrfd_mod_reset.argtypes = [_vp, C.c_uint32]

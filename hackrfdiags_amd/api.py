@@ -200,6 +200,58 @@ class Demod:
 MOD_SSB, MOD_INTERP, MOD_AM, MOD_FM, MOD_WBFM = 1, 2, 3, 4, 5
 
 
+class Ingest:
+    """Pinned-memory, double-buffered block transport in front of an Rx (hrfd_ingest_*)."""
+
+    def __init__(self, rx: "Rx", block_bytes: int, n_blocks: int, n_slots: int = 2):
+        self.L = _lib.load()
+        self.rx = rx
+        self.block_bytes, self.n_blocks, self.C = int(block_bytes), int(n_blocks), rx.n
+        h = C.c_void_p()
+        check(self.L.hrfd_ingest_create(rx.h, self.block_bytes, self.n_blocks, int(n_slots), C.byref(h)),
+              "hrfd_ingest_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hrfd_ingest_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def acquire(self) -> np.ndarray:
+        """the next free slot's pinned input buffer as int8 [C, n_blocks, block_bytes] (a view)"""
+        p = C.c_void_p()
+        check(self.L.hrfd_ingest_acquire(self.h, C.byref(p)), "hrfd_ingest_acquire")
+        n = self.C * self.n_blocks * self.block_bytes
+        buf = (C.c_int8 * n).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.int8).reshape(self.C, self.n_blocks, self.block_bytes)
+
+    def submit(self, gain_db: int = 0):
+        check(self.L.hrfd_ingest_submit(self.h, int(gain_db)), "hrfd_ingest_submit")
+
+    def collect(self):
+        """(pcm [C, B, bytes/512], n_pcm [C, B], magnitude [C, B], allowed [C, B]) -- copies"""
+        ps = [C.c_void_p() for _ in range(4)]
+        check(self.L.hrfd_ingest_collect(self.h, *[C.byref(p) for p in ps]), "hrfd_ingest_collect")
+        units = self.C * self.n_blocks
+        npcm = self.block_bytes // 512
+
+        def view(p, ctype, dtype, count):
+            return np.frombuffer((ctype * count).from_address(p.value), dtype=dtype).copy()
+
+        pcm = view(ps[0], C.c_int16, np.int16, units * npcm).reshape(self.C, self.n_blocks, npcm)
+        n_pcm = view(ps[1], C.c_uint32, np.uint32, units).reshape(self.C, self.n_blocks)
+        mag = view(ps[2], C.c_uint32, np.uint32, units).reshape(self.C, self.n_blocks)
+        allowed = view(ps[3], C.c_uint8, np.uint8, units).reshape(self.C, self.n_blocks)
+        return pcm, n_pcm, mag, allowed
+
+    def replayed(self) -> int:
+        n = C.c_uint64(0)
+        check(self.L.hrfd_ingest_replayed(self.h, C.byref(n)), "hrfd_ingest_replayed")
+        return int(n.value)
+
+
 class Mod:
     """n_channels SSB modulators / interpolateSignal cascades (hrfd_mod_*)."""
 

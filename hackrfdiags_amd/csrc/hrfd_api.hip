@@ -270,7 +270,7 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && alloc((void **)&h->d_atcorr, kCorrBytes);
   ok = ok && alloc((void **)&h->d_atinv, sizeof(float) * kInvEntries);
   ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
-  ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * kNumCounters);
+  ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * kNumDevCounters);
   ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 6 * n_channels);
   if (!ok)
   {
@@ -298,7 +298,7 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   if (e == hipSuccess) e = hipMemcpy(h->d_state_out, init.data(), sizeof(ChanState) * n_channels, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_lut, lut.data(), sizeof(float) * 65536, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_dbfs, dbfs, sizeof(dbfs), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(h->d_counters, 0, sizeof(uint32_t) * kNumCounters);
+  if (e == hipSuccess) e = hipMemset(h->d_counters, 0, sizeof(uint32_t) * kNumDevCounters);
   // arithmetic atan2: reciprocals from the host (correctly rounded), correction bytes derived on
   // the device from the table just uploaded, with the kernel's own arithmetic (k_build_atan_corr)
   float inv[kInvEntries];
@@ -316,6 +316,7 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(&bad, h->d_counters + kCntScratch, sizeof(bad), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemset(h->d_counters + kCntScratch, 0, sizeof(uint32_t));
   if (e != hipSuccess)
   {
     rc = fail(HRFD_ENODEV, "hrfd_rx_create: initial upload failed: %s", hipGetErrorString(e));
@@ -919,9 +920,19 @@ extern "C" int hrfd_rx_sync(hrfd_rx *h, uint32_t *n_violations)
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipMemcpy(h->last_counters, h->d_counters, sizeof(h->last_counters), hipMemcpyDeviceToHost));
   h->total_repairs = h->last_counters[kCntTotRepair];
+  uint32_t viol = h->last_counters[kCntGate] + h->last_counters[kCntSpec];
+  if (viol == 0 && h->last_counters[kCntTotLaunch] != 0 && h->last_counters[kCntCommit] == 0)
+  {
+    viol = 1;                                            // clean by itself, but behind an unrepaired failed launch
+  }
+  if (viol != 0)
+  {
+    // the caller repairs from here (resubmits block by block): later launches may commit again
+    HIP_TRY(hipMemset(h->d_counters + kCntPoison, 0, sizeof(uint32_t)));
+  }
   if (n_violations != nullptr)
   {
-    *n_violations = h->last_counters[kCntGate] + h->last_counters[kCntSpec];
+    *n_violations = viol;
   }
   return HRFD_OK;
 }

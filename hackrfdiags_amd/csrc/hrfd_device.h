@@ -143,7 +143,10 @@ constexpr int kCntTotRepair = 4;
 constexpr int kCntTotViol = 5; // launches whose state was NOT committed
 constexpr int kCntTotLaunch = 6;
 constexpr int kCntScratch = 7;  // k_build_atan_corr's violation count (hrfd_rx_create only)
-constexpr int kNumCounters = 8;
+constexpr int kNumCounters = 8;   // counters visible through hrfd_rx_debug_counters
+constexpr int kCntPoison = 8;     // sticky: a launch was not committed and the host has not repaired it yet --
+                                  // later launches must not commit either (pipelined submission, hrfd_ingest_*)
+constexpr int kNumDevCounters = 10;
 
 } // namespace hrfd
 

@@ -6,3 +6,4 @@
 #include "../../include/hrfd.h"
 #include "hrfd_tx_kernels.hip"
 #include "hrfd_api.hip"
+#include "hrfd_ingest.hip"

@@ -1518,9 +1518,14 @@ __global__ __launch_bounds__(64) void k_rx_commit(const EpilogueParams E)
 {
   const uint32_t c = blockIdx.x;
   const int lane = threadIdx.x;
-  const bool clean = (E.counters[kCntGate] | E.counters[kCntSpec]) == 0u;
+  // a launch behind an unrepaired failed one started from a stale state: it must not commit
+  const bool clean = (E.counters[kCntGate] | E.counters[kCntSpec] | E.counters[kCntPoison]) == 0u;
   if (c == 0 && lane == 0)
   {
+    if (!clean)
+    {
+      E.counters[kCntPoison] = 1u;
+    }
     E.counters[kCntCommit] = clean ? 1u : 0u;
     E.counters[kCntTotRepair] += E.counters[kCntRepair];
     E.counters[kCntTotViol] += clean ? 0u : 1u;

@@ -143,6 +143,31 @@ int hrfd_demod_process(hrfd_demod *h, const int8_t *iq256k, uint32_t bytes_per_c
                        int16_t *pcm, uint32_t *n_pcm);
 
 /* ------------------------------------------------------------------------------
+ * Block transport in front of hrfd_rx.  Replaces the role of
+ * DataConsumer (src_diags/DataConsumer.cc:219-262 acceptData: copy into a ring of messages and
+ * queue; :319-351 the consumer thread calling IqDataProcessor::acceptIqData) for many channels:
+ * a ring of n_slots pinned host batches [n_channels][n_blocks][block_bytes]; a submitted batch
+ * is copied to the device, demodulated and its results copied back on separate streams, so the
+ * transfer of one batch runs under the kernels of the previous one.  Results are the sequential
+ * ones (a batch whose speculation fails is replayed exactly, with the batches in flight behind it).
+ *   producer:  hrfd_ingest_acquire (pinned input buffer of the next free slot; HRFD_ESTATE when
+ *              none is free) -> fill -> hrfd_ingest_submit (returns at once)
+ *   consumer:  hrfd_ingest_collect (oldest submitted batch; blocks; pcm [C][B][block_bytes/512],
+ *              n_pcm / magnitude / signal_allowed [C][B]; pointers valid until that slot is
+ *              acquired again)
+ * The rx handle must not be used by other calls while batches are in flight.
+ */
+typedef struct hrfd_ingest hrfd_ingest;
+int hrfd_ingest_create(hrfd_rx *rx, uint32_t block_bytes, uint32_t n_blocks, uint32_t n_slots,
+                       hrfd_ingest **out);
+int hrfd_ingest_destroy(hrfd_ingest *g);
+int hrfd_ingest_acquire(hrfd_ingest *g, int8_t **iq_slot);
+int hrfd_ingest_submit(hrfd_ingest *g, uint32_t gain_db);
+int hrfd_ingest_collect(hrfd_ingest *g, const int16_t **pcm, const uint32_t **n_pcm,
+                        const uint32_t **magnitude, const uint8_t **signal_allowed);
+int hrfd_ingest_replayed(hrfd_ingest *g, uint64_t *n_batches);
+
+/* ------------------------------------------------------------------------------
  * Transmit: PCM -> int8 IQ through the 8-stage x256 half-band interpolator.
  * kind HRFD_MOD_SSB replaces SsbModulator::acceptData (SsbModulator.cc:455-470)
  * incl. set{Lsb,Usb}ModulationMode / resetModulator (SsbModulator.h:23-35);
