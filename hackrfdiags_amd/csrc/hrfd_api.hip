@@ -21,7 +21,7 @@ namespace hrfd {
 template <int MODE, bool S256, bool ARITH> __global__ void k_rx_wbfm(const RxParams);
 __global__ void k_build_atan_corr(const float *, const float *, uint8_t *, uint32_t *);
 __global__ void k_atan_eval(const uint8_t *, const float *, float *);
-template <int MODE, bool S256> __global__ void k_rx_fir(const RxParams);
+template <int MODE, bool S256, bool ARITH> __global__ void k_rx_fir(const RxParams);
 template <int MODE> __global__ void k_rx_post(const RxParams);
 __global__ void k_rx_epilogue(const EpilogueParams);
 __global__ void k_rx_commit(const EpilogueParams);
@@ -830,22 +830,26 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     {
       if (opt.src256)
       {
-        hipLaunchKernelGGL((k_rx_fir<2, true>), dim3(grid), dim3(kThreads), 0, s, P);
+        hipLaunchKernelGGL((k_rx_fir<2, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else if (h->arith_ok && h->atan_mode != 0)
+      {
+        hipLaunchKernelGGL((k_rx_fir<2, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       else
       {
-        hipLaunchKernelGGL((k_rx_fir<2, false>), dim3(grid), dim3(kThreads), 0, s, P);
+        hipLaunchKernelGGL((k_rx_fir<2, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
       }
     }
     else if (m == HRFD_MODE_AM)
     {
       if (opt.src256)
       {
-        hipLaunchKernelGGL((k_rx_fir<1, true>), dim3(grid), dim3(kThreads), 0, s, P);
+        hipLaunchKernelGGL((k_rx_fir<1, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       else
       {
-        hipLaunchKernelGGL((k_rx_fir<1, false>), dim3(grid), dim3(kThreads), 0, s, P);
+        hipLaunchKernelGGL((k_rx_fir<1, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       hipLaunchKernelGGL(k_rx_post<1>, dim3(n), dim3(256), 0, s, P);
     }
@@ -853,11 +857,11 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     {
       if (opt.src256)
       {
-        hipLaunchKernelGGL((k_rx_fir<4, true>), dim3(grid), dim3(kThreads), 0, s, P);
+        hipLaunchKernelGGL((k_rx_fir<4, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       else
       {
-        hipLaunchKernelGGL((k_rx_fir<4, false>), dim3(grid), dim3(kThreads), 0, s, P);
+        hipLaunchKernelGGL((k_rx_fir<4, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       hipLaunchKernelGGL(k_rx_post<4>, dim3(n), dim3(256), 0, s, P);
     }

@@ -45,11 +45,16 @@ __device__ __forceinline__ int fir_dot(const uint32_t *x, const RevTaps<N> &t, i
   return acc;
 }
 
-template <int MODE, bool S256>
+template <int MODE, bool S256, bool ARITH>
 __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
 {
   __shared__ __attribute__((aligned(16))) uint32_t lds[kFirDwords];
   __shared__ uint32_t red[kWaves];
+  // FM with the arithmetic atan2 (theta_arith, hrfd_rx_kernels.hip): correction bytes and 1/a
+  __shared__ __attribute__((aligned(16))) uint8_t atcorr[(ARITH && MODE == 2) ? kCorrBytes : 16];
+  __shared__ __attribute__((aligned(16))) float atinv[(ARITH && MODE == 2) ? kInvEntries : 4];
+  static_assert(sizeof(uint32_t) * kFirDwords + kCorrBytes + sizeof(float) * kInvEntries + 512 <= 81920,
+                "two workgroups per CU need <= 80 KiB of LDS each");
 
   constexpr int H = (MODE == 2) ? kFmTail : kAmTail;     // 256 kS/s history in front of the block
   uint32_t ci, b;
@@ -59,6 +64,19 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
   }
   const uint32_t c = P.chan_list[ci];
   const int tid = threadIdx.x;
+  uint4 attab = make_uint4(0u, 0u, 0u, 0u);
+  if (ARITH && MODE == 2)
+  {
+    // this thread's 16 bytes of the atan2 tables, requested now, published to LDS before F1
+    if (tid < kCorrBytes / 16)
+    {
+      attab = reinterpret_cast<const uint4 *>(P.at_corr)[tid];
+    }
+    else if (tid < kCorrBytes / 16 + kInvEntries / 4)
+    {
+      attab = reinterpret_cast<const uint4 *>(P.at_inv)[tid - kCorrBytes / 16];
+    }
+  }
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n256 = (int)P.n256;
@@ -108,11 +126,11 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
     uint32_t e[4];
     if (P.iq256 != nullptr)
     {
-      produce_stream<MODE, false, true, S256>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<MODE, false, true, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
     }
     else
     {
-      produce_stream<MODE, false, false, S256>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<MODE, false, false, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
     }
   }
   for (int off = 32; off > 0; off >>= 1)
@@ -173,6 +191,18 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
     constexpr int kK0 = -164;                             // first 64 kS/s sample needed
     constexpr int kPairs = ((kMaxN256 / 4 + 164) / 2 + kThreads - 1) / kThreads;
     const int npairs = (n64 - kK0) >> 1;
+    if (ARITH)
+    {
+      if (tid < kCorrBytes / 16)
+      {
+        reinterpret_cast<uint4 *>(atcorr)[tid] = attab;
+      }
+      else if (tid < kCorrBytes / 16 + kInvEntries / 4)
+      {
+        reinterpret_cast<uint4 *>(atinv)[tid - kCorrBytes / 16] = attab;
+      }
+      __syncthreads();
+    }
     float th[kPairs][2];
 #pragma unroll
     for (int r = 0; r < kPairs; r++)
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
           // low byte of the int16 sample, biased by 128 (FmDemodulator.cc:495-496)
           const uint32_t ii = ((uint32_t)ti & 0xffu) ^ 0x80u;
           const uint32_t qi = ((uint32_t)tq & 0xffu) ^ 0x80u;
-          th[r][o] = P.atan2_lut[(qi << 8) | ii];
+          th[r][o] = ARITH ? theta_arith((qi << 16) | ii, atcorr, atinv) : P.atan2_lut[(qi << 8) | ii];
         }
       }
     }
@@ -586,12 +616,13 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
   }
 }
 
-template __global__ void k_rx_fir<1, false>(const RxParams);
-template __global__ void k_rx_fir<1, true>(const RxParams);
-template __global__ void k_rx_fir<2, false>(const RxParams);
-template __global__ void k_rx_fir<2, true>(const RxParams);
-template __global__ void k_rx_fir<4, false>(const RxParams);
-template __global__ void k_rx_fir<4, true>(const RxParams);
+template __global__ void k_rx_fir<1, false, false>(const RxParams);
+template __global__ void k_rx_fir<1, true, false>(const RxParams);
+template __global__ void k_rx_fir<2, false, false>(const RxParams);
+template __global__ void k_rx_fir<2, false, true>(const RxParams);
+template __global__ void k_rx_fir<2, true, false>(const RxParams);
+template __global__ void k_rx_fir<4, false, false>(const RxParams);
+template __global__ void k_rx_fir<4, true, false>(const RxParams);
 template __global__ void k_rx_post<1>(const RxParams);
 template __global__ void k_rx_post<4>(const RxParams);
 

@@ -415,3 +415,27 @@ def test_wbfm_block_runs_with_repairs(oracle, run_len):
         for b in range(B):
             assert (pcm[c, b] == want[b][0]).all(), (run_len, c, b)
     assert rx.debug_counters()[4] > 0
+
+
+@pytest.mark.parametrize("kind", ["lcg", "fmtone", "fullscale"])
+def test_fm_atan2_kernels_agree(oracle, kind):
+    """the FM kernel too exists with the table gather and with the arithmetic atan2 (its index is
+    the low byte of the int16 tuner outputs): both against the oracle, bit for bit"""
+    C, B = 2, 3
+    if kind == "fullscale":
+        rng = np.random.default_rng(6)
+        xs = rng.choice(np.array([-128, -127, 127], dtype=np.int8), size=(C, B, BLK))
+        xs = np.repeat(xs[:, :, ::256], 256, axis=2).copy()
+    else:
+        xs = np.stack([synth.make_input(kind, 95 + c, B) for c in range(C)]).reshape(C, B, BLK)
+    out = []
+    for mode in (0, 1):
+        rx = api.Rx(C)
+        rx.set_mode(api.FM)
+        rx.debug_set_atan(mode)
+        out.append(rx.process_block(xs, B)[0])
+    assert (out[0] == out[1]).all()
+    for c in range(C):
+        want = _oracle_stream(oracle, FM, xs[c], B)
+        for b in range(B):
+            assert (out[1][c, b] == want[b][0]).all(), (c, b)
