@@ -126,6 +126,7 @@ def bench_ssbmod(args, api, device, rank, world, dist):
     gen.manual_seed(7 + rank)
     pcm = torch.randint(-32768, 32768, (C, n), dtype=torch.int16, device=device, generator=gen)
     out = torch.empty((C, 512 * n), dtype=torch.int8, device=device)
+    torch.cuda.synchronize()                             # the PCM was generated on torch's stream
     kind = {"ssbmod": api.MOD_SSB, "ammod": api.MOD_AM, "fmmod": api.MOD_FM, "wbfmmod": api.MOD_WBFM}[args.workload]
     kname = {"ssbmod": "SSB", "ammod": "AM", "fmmod": "FM", "wbfmmod": "WBFM"}[args.workload]
     m = api.Mod(kind, C, device=device.index)
@@ -286,6 +287,7 @@ def main():
     iq = gen(C, B, device, first_channel=rank * C)
     pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=device)
     n_pcm = torch.zeros((C, B), dtype=torch.int32, device=device)
+    torch.cuda.synchronize()                             # inputs and outputs were written on torch's stream
     rx = api.Rx(C, device=local_rank)
     rx.set_mode(api.WBFM)
     if args.workload == "mixed":

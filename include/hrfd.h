@@ -109,6 +109,9 @@ int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t block_bytes,
  * concurrently: the call speculates that every squelch gate in the batch is
  * open and that the WBFM de-emphasis tiles re-synchronise; both
  * assumptions are verified on the device and hrfd_rx_sync() reports them.
+ * Stream ordering is the caller's: the handle's own stream is non-blocking, so buffers that
+ * were filled or cleared on another stream (e.g. a framework's default stream) must be
+ * complete -- or `stream` must be that stream -- before this call.
  */
 int hrfd_rx_process_device(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride,
                            uint32_t block_bytes, uint32_t n_blocks, uint32_t gain_db,

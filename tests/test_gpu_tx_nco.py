@@ -71,6 +71,7 @@ def test_modulator_full_scale_and_device_entry(oracle):
     dev = torch.device("cuda:0")
     d_in = torch.from_numpy(pcm).to(dev)
     d_out = torch.zeros((C, 512 * n), dtype=torch.int8, device=dev)
+    torch.cuda.synchronize()                             # torch filled these on its own stream
     m = api.Mod(api.MOD_SSB, C)
     m.process_device(d_in.data_ptr(), n, d_out.data_ptr())
     m.sync()

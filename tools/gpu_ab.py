@@ -23,6 +23,7 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev, generator=g)
 pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+torch.cuda.synchronize()
 rx = api.Rx(C); rx.set_mode(api.WBFM)
 rx.debug_enable_timing(8)
 if os.environ.get("HRFD_RUNLEN"):

@@ -12,6 +12,7 @@ stag = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda:0")
 x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev)
 pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+torch.cuda.synchronize()
 rx = api.Rx(C); rx.set_mode(api.WBFM); rx.debug_set_stagger(stag)
 if os.environ.get('HRFD_RUNLEN'):
     rx.debug_set_run_len(int(os.environ['HRFD_RUNLEN']))

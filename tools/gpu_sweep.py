@@ -10,6 +10,7 @@ C, B = 256, 16
 dev = torch.device("cuda:0")
 x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev)
 pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+torch.cuda.synchronize()
 rx = api.Rx(C); rx.set_mode(api.WBFM)
 rx.debug_enable_timing(8)
 for stag in [4] + [4 + 256 * f for f in (1, 2, 4, 6, 16, 16 + 8, 16 + 8 + 6)]:
