@@ -77,23 +77,17 @@ __device__ __forceinline__ uint32_t lane63(uint32_t v)
 // (Decimator_int16.cc:176-249 with the 3-tap tables of IqDataProcessor.cc:8-27).
 // With a' = a+128 etc. and T = a'+c':  4*(y+128) + rem = T + 2b' + k(T), where
 //   k(T) = floor((d*(T-256) + 16384) / 8192)
-//        = 1 + (T >> 8)                     h0 = 8206 (d = 14)
+//        = 1 + (T >> 8)                     h0 = 8206 (d = 14)   [stage 1: on bytes, hb1_bytes below]
 //        = (57 T + 1792) >> 13              h0 = 8249 (d = 57)
 //        = ((29 T + 2816) >> 10) - 8        h0 = 8424 (d = 232)
 // I sits in bits 0..15 and Q in bits 16..31 of one register.  Every field stays
 // in 0..2053, so plain 32-bit adds and (shift, mask) pairs act on both fields at
 // once; those are 32-bit-encoded VOP2 instructions, which gfx950 issues at about
 // twice the rate of the 64-bit-encoded packed-math ones (tools/ubench/valu_rate.hip).
-// Only the two multiplies remain v_pk_mad_u16.  The last stage adds 4*256 so that
+// Stages 2 and 3 run that way (only their multiplies are v_pk_mad_u16).  The last stage adds 4*256 so that
 // no field goes negative; the (int8_t) narrowing of IqDataProcessor.cc:458,489
 // keeps the low byte only, which that does not touch.
 // Checked exhaustively against the direct form in tests/test_abi_and_tables.py.
-__device__ __forceinline__ uint32_t hb1_sum(uint32_t a, uint32_t b, uint32_t c)
-{
-  const uint32_t t = a + c;
-  const uint32_t h = (t >> 8) & 0x00010001u;
-  return t + ((b << 1) | 0x00010001u) + h;
-}
 // b2 = 2 b' (form_b2 of the previous stage)
 __device__ __forceinline__ uint32_t hb2_sum(uint32_t a, uint32_t b2, uint32_t c)
 {
@@ -111,11 +105,24 @@ __device__ __forceinline__ uint32_t hb3_sum(uint32_t a, uint32_t b2, uint32_t c)
 __device__ __forceinline__ uint32_t form_ac(uint32_t s) { return (s >> 2) & 0x00ff00ffu; }
 __device__ __forceinline__ uint32_t form_b2(uint32_t s) { return (s >> 1) & 0x01fe01feu; }
 
+// Stage 1 (h0 = 8206) works on BYTES, four at a time, with the pixel-average instruction
+// v_lerp_u8 (per byte (x + y + r) >> 1, r = bit 0 of the matching byte of the third operand).
+// With m = (a' + c') >> 1 and e = (a' + c') & 1 the sum above is 2(m + b') + e + 1 + [m >= 128],
+// so  y' = (m + b' + (e | m>>7)) >> 1 = lerp(lerp(a', c', 0), b', (a' ^ c') | (m >> 7)):
+// five instructions for two (I,Q) outputs, straight from the interleaved input bytes -- no
+// unpacking to 16-bit fields before the first stage (tests: all 2^24 byte triples).
+__device__ __forceinline__ uint32_t hb1_bytes(uint32_t a, uint32_t b, uint32_t c)
+{
+  const uint32_t m = __builtin_amdgcn_lerp(a, c, 0u);
+  const uint32_t r = (a ^ c) | (m >> 7);                 // only bit 0 of each byte is looked at
+  return __builtin_amdgcn_lerp(m, b, r);
+}
+
 // Carry between consecutive 1 KiB chunks of one wave: lane 0 of each register
 // holds the value of the previous chunk's last lane.
 struct FeCarry
 {
-  uint32_t x7;    // last input pair
+  uint32_t x7;    // last input dword (offset binary): its upper two bytes are the last (I,Q) pair
   uint32_t y13;   // last stage-1 output pair
   uint32_t y21;   // last stage-2 output pair
 };
@@ -124,29 +131,31 @@ struct FeCarry
 // of each half = value + 128).  IqDataProcessor::reduceSampleRate, :429-500.
 __device__ __forceinline__ uint32_t frontend(const uint4 raw, FeCarry &c)
 {
+  // dword k holds samples x[2k], x[2k+1] as bytes (I, Q, I, Q)
   const uint32_t r0 = raw.x ^ 0x80808080u, r1 = raw.y ^ 0x80808080u;
   const uint32_t r2 = raw.z ^ 0x80808080u, r3 = raw.w ^ 0x80808080u;
-  // zero-extend bytes (I0,Q0,I1,Q1) into two (I,Q) pairs
-  const uint32_t x0 = __builtin_amdgcn_perm(0u, r0, 0x0c010c00u);
-  const uint32_t x1 = __builtin_amdgcn_perm(0u, r0, 0x0c030c02u);
-  const uint32_t x2 = __builtin_amdgcn_perm(0u, r1, 0x0c010c00u);
-  const uint32_t x3 = __builtin_amdgcn_perm(0u, r1, 0x0c030c02u);
-  const uint32_t x4 = __builtin_amdgcn_perm(0u, r2, 0x0c010c00u);
-  const uint32_t x5 = __builtin_amdgcn_perm(0u, r2, 0x0c030c02u);
-  const uint32_t x6 = __builtin_amdgcn_perm(0u, r3, 0x0c010c00u);
-  const uint32_t x7 = __builtin_amdgcn_perm(0u, r3, 0x0c030c02u);
-
-  const uint32_t xm1 = shr1(x7, c.x7);
-  c.x7 = ror1(x7);
-  const uint32_t y10b = form_b2(hb1_sum(xm1, x0, x1));
-  const uint32_t y11 = form_ac(hb1_sum(x1, x2, x3));
-  const uint32_t y12b = form_b2(hb1_sum(x3, x4, x5));
-  const uint32_t y13 = form_ac(hb1_sum(x5, x6, x7));
+  const uint32_t rm1 = shr1(r3, c.x7);                   // the dword in front of this lane's 16 bytes
+  c.x7 = ror1(r3);
+  // stage 1, outputs (y1[0], y1[1]) and (y1[2], y1[3]) as byte quadruples:
+  // outer taps x[2m-1], x[2m+1] (odd samples), centre x[2m] (even samples)
+  const uint32_t a01 = __builtin_amdgcn_perm(r0, rm1, 0x07060302u);   // x[-1], x[1]
+  const uint32_t b01 = __builtin_amdgcn_perm(r1, r0, 0x05040100u);    // x[0],  x[2]
+  const uint32_t c01 = __builtin_amdgcn_perm(r1, r0, 0x07060302u);    // x[1],  x[3]
+  const uint32_t a23 = __builtin_amdgcn_perm(r2, r1, 0x07060302u);    // x[3],  x[5]
+  const uint32_t b23 = __builtin_amdgcn_perm(r3, r2, 0x05040100u);    // x[4],  x[6]
+  const uint32_t c23 = __builtin_amdgcn_perm(r3, r2, 0x07060302u);    // x[5],  x[7]
+  const uint32_t y01 = hb1_bytes(a01, b01, c01);
+  const uint32_t y23 = hb1_bytes(a23, b23, c23);
+  // to 16-bit (I,Q) fields for the other two stages
+  const uint32_t y10 = __builtin_amdgcn_perm(0u, y01, 0x0c010c00u);
+  const uint32_t y11 = __builtin_amdgcn_perm(0u, y01, 0x0c030c02u);
+  const uint32_t y12 = __builtin_amdgcn_perm(0u, y23, 0x0c010c00u);
+  const uint32_t y13 = __builtin_amdgcn_perm(0u, y23, 0x0c030c02u);
 
   const uint32_t y1m1 = shr1(y13, c.y13);
   c.y13 = ror1(y13);
-  const uint32_t y20b = form_b2(hb2_sum(y1m1, y10b, y11));
-  const uint32_t y21 = form_ac(hb2_sum(y11, y12b, y13));
+  const uint32_t y20b = form_b2(hb2_sum(y1m1, y10 << 1, y11));
+  const uint32_t y21 = form_ac(hb2_sum(y11, y12 << 1, y13));
 
   const uint32_t y2m1 = shr1(y21, c.y21);
   c.y21 = ror1(y21);
@@ -159,20 +168,22 @@ __device__ __forceinline__ FeCarry carry_from_16(const uint4 raw)
 {
   const uint32_t r0 = raw.x ^ 0x80808080u, r1 = raw.y ^ 0x80808080u;
   const uint32_t r2 = raw.z ^ 0x80808080u, r3 = raw.w ^ 0x80808080u;
-  const uint32_t x1 = __builtin_amdgcn_perm(0u, r0, 0x0c030c02u);
-  const uint32_t x2 = __builtin_amdgcn_perm(0u, r1, 0x0c010c00u);
-  const uint32_t x3 = __builtin_amdgcn_perm(0u, r1, 0x0c030c02u);
-  const uint32_t x4 = __builtin_amdgcn_perm(0u, r2, 0x0c010c00u);
-  const uint32_t x5 = __builtin_amdgcn_perm(0u, r2, 0x0c030c02u);
-  const uint32_t x6 = __builtin_amdgcn_perm(0u, r3, 0x0c010c00u);
-  const uint32_t x7 = __builtin_amdgcn_perm(0u, r3, 0x0c030c02u);
-  const uint32_t y11 = form_ac(hb1_sum(x1, x2, x3));
-  const uint32_t y12b = form_b2(hb1_sum(x3, x4, x5));
-  const uint32_t y13 = form_ac(hb1_sum(x5, x6, x7));
+  const uint32_t b01 = __builtin_amdgcn_perm(r1, r0, 0x05040100u);
+  const uint32_t c01 = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
+  const uint32_t a23 = __builtin_amdgcn_perm(r2, r1, 0x07060302u);
+  const uint32_t b23 = __builtin_amdgcn_perm(r3, r2, 0x05040100u);
+  const uint32_t c23 = __builtin_amdgcn_perm(r3, r2, 0x07060302u);
+  // y1[1] needs x[1..3] only; y1[0] is not needed (its outer tap x[-1] lies before the 16 bytes)
+  const uint32_t a01 = __builtin_amdgcn_perm(r0, r0, 0x07060302u);    // (x[1], x[1]): pair 1 is what counts
+  const uint32_t y01 = hb1_bytes(a01, b01, c01);
+  const uint32_t y23 = hb1_bytes(a23, b23, c23);
+  const uint32_t y11 = __builtin_amdgcn_perm(0u, y01, 0x0c030c02u);
+  const uint32_t y12 = __builtin_amdgcn_perm(0u, y23, 0x0c010c00u);
+  const uint32_t y13 = __builtin_amdgcn_perm(0u, y23, 0x0c030c02u);
   FeCarry c;
-  c.x7 = x7;
+  c.x7 = r3;
   c.y13 = y13;
-  c.y21 = form_ac(hb2_sum(y11, y12b, y13));
+  c.y21 = form_ac(hb2_sum(y11, y12 << 1, y13));
   return c;
 }
 
@@ -672,7 +683,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
     }
     return;
   }
-  FeCarry fc = {0x00800080u, 0x00800080u, 0x00800080u};
+  FeCarry fc = {0x80808080u, 0x00800080u, 0x00800080u};   // zero input, zero stage outputs (offset binary)
   uint32_t c_theta = 0, c_p = 0;                         // lane 0: theta, b0*x of the sample before
   if (X.first && cbeg == 0)
   {

@@ -61,9 +61,9 @@ def test_host_built_tables_match_oracle(lib, oracle):
 
 
 def test_halfband_offset_domain_formula():
-    """The 32-bit SWAR form the kernel uses for the three half-band stages
-    (hrfd_rx_kernels.hip, hb1_sum / hb2_sum / hb3_sum with I in bits 0..15 and Q in
-    bits 16..31 of one register) equals the reference's Q15 form for every input
+    """The forms the kernel uses for the three half-band stages (hrfd_rx_kernels.hip: hb1_bytes on
+    bytes with v_lerp_u8; hb2_sum / hb3_sum as 32-bit SWAR with I in bits 0..15 and Q in
+    bits 16..31 of one register) equal the reference's Q15 form for every input
     triple, on both fields at once, and no field ever borrows from or carries into
     its neighbour."""
     A = np.arange(-128, 128, dtype=np.int64)
@@ -84,14 +84,23 @@ def test_halfband_offset_domain_formula():
 
     pa, pb, pc = pack(a, qa), pack(b, qb), pack(c, qc)
     M = np.uint32
-    # stage 1
+    # stage 1 runs on bytes with v_lerp_u8 (per byte (x + y + (r & 1)) >> 1), four bytes per
+    # register: hb1_bytes = lerp(lerp(a, c, 0), b, (a ^ c) | (m >> 7)); here on two bytes (I, Q)
+    def lerp(x, y, r):
+        out = np.zeros_like(x)
+        for k in range(4):
+            sh = M(8 * k)
+            xb, yb, rb = (x >> sh) & M(0xFF), (y >> sh) & M(0xFF), (r >> sh) & M(1)
+            out |= (((xb + yb + rb) >> M(1)) & M(0xFF)) << sh
+        return out
+
+    ba, bb, bc = (pa & M(0xFF)) | ((pa >> M(8)) & M(0xFF00)), (pb & M(0xFF)) | ((pb >> M(8)) & M(0xFF00)), \
+        (pc & M(0xFF)) | ((pc >> M(8)) & M(0xFF00))
+    m = lerp(ba, bc, M(0))
+    y1 = lerp(m, bb, (ba ^ bc) | (m >> M(7)))
+    assert ((y1 & M(0xFF)).astype(np.int64) - 128 == direct(8206, a, b, c)).all()
+    assert (((y1 >> M(8)) & M(0xFF)).astype(np.int64) - 128 == direct(8206, qa, qb, qc)).all()
     t = pa + pc
-    s1 = t + ((pb << M(1)) | M(0x00010001)) + ((t >> M(8)) & M(0x00010001))
-    ac = (s1 >> M(2)) & M(0x00FF00FF)
-    b2 = (s1 >> M(1)) & M(0x01FE01FE)
-    assert ((ac & M(0xFFFF)).astype(np.int64) - 128 == direct(8206, a, b, c)).all()
-    assert ((ac >> M(16)).astype(np.int64) - 128 == direct(8206, qa, qb, qc)).all()
-    assert (b2 == M(2) * ac).all()
     # stage 2 (its inputs are stage-1 outputs: -128..127 again)
     s2 = t + (pb << M(1)) + ((pk_mad(t, 57, 1792) >> M(13)) & M(0x00070007))
     ac = (s2 >> M(2)) & M(0x00FF00FF)
