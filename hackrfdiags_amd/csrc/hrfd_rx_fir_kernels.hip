@@ -421,11 +421,79 @@ __device__ __forceinline__ float dcrem_step(float x, float &xp, float y)
   return v - r;
 }
 
+// `count` steps of it for one lane, out of LDS: x[k] for k in [0, count), x[-1] in front; only
+// steps lo <= k < hi exist for this lane (the others leave y alone).  The inputs are read in
+// groups of eight with the next group in flight and v = x[k] - x[k-1] is formed off the chain,
+// so that the dependent chain per step is the multiply and the subtract only (a plain
+// `for` over LDS pays the LDS latency on every step: 5x slower).
+template <bool STORE>
+__device__ __forceinline__ float dcrem_run(const float *x, float *out, const int dummy, const int count, const int lo,
+                                           const int hi, float y)
+{
+  constexpr int U = 8;
+  // "lo <= k < hi" as ONE unsigned compare into VCC, and stores of the other lanes go to a dummy
+  // slot: no scalar instruction and no exec-mask change between the steps (a VALU -> SALU -> VALU
+  // hand-over per step made this loop 4x slower)
+  const uint32_t span = (hi > lo) ? (uint32_t)(hi - lo) : 0u;
+  float ga[U + 1], gb[U + 1];                            // [0] = the sample before the group
+  auto load = [&](float (&g)[U + 1], int at) {
+#pragma unroll
+    for (int j = 0; j <= U; j++)
+    {
+      g[j] = x[at - 1 + j];
+    }
+  };
+  auto one = [&](float xm1, float x0, int k) {
+    const float v = x0 - xm1;
+    const float r = DCREM_A1 * y;
+    const float yn = v - r;
+    const bool live = (uint32_t)(k - lo) < span;
+    y = live ? yn : y;
+    if (STORE)
+    {
+      out[live ? k : dummy] = y;
+    }
+  };
+  auto run = [&](const float (&g)[U + 1], int at) {
+#pragma unroll
+    for (int j = 0; j < U; j++)
+    {
+      one(g[j], g[j + 1], at + j);
+    }
+  };
+  int k = 0;
+  if (count >= U)
+  {
+    load(ga, 0);
+  }
+  for (; k + 3 * U <= count; k += 2 * U)
+  {
+    load(gb, k + U);
+    run(ga, k);
+    load(ga, k + 2 * U);
+    run(gb, k + U);
+  }
+  if (k + U <= count)
+  {
+    run(ga, k);
+    k += U;
+  }
+  for (; k < count; k++)
+  {
+    one(x[k - 1], x[k], k);
+  }
+  return y;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
 {
-  __shared__ float xs[kPostSeg + 1];                      // xs[0] = x[-1] of the segment
-  __shared__ float ys[kPostSeg];
+  // xs[1 + n] = x[n] of the segment, xs[0] = x[-1]; the kPostWarm floats in
+  // front are never used as data (tiles near the segment start skip those steps) but keep every
+  // lane's warm-up window inside the array
+  __shared__ float xs_pad[kPostWarm + kPostSeg + 8];
+  float *const xs = xs_pad + kPostWarm;                   // xs[0] = x[-1] of the segment
+  __shared__ float ys[kPostSeg + 1];                      // + one dummy slot for masked-off stores
   __shared__ int16_t iq[2][kPostSeg + kSsbHist];          // SSB: i, q with 32 samples of history
 
   const uint32_t ci = blockIdx.x;
@@ -463,31 +531,63 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
     // ---- step 1: x[n] of the segment
     if (MODE == 1)
     {
-      for (int n = tid; n < len; n += kPostThreads)
+      // the envelope k_rx_fir<AM> left in the PCM buffer: all of a thread's loads first (one
+      // memory round trip per segment instead of one per element)
+      constexpr int kPer = kPostSeg / kPostThreads;
+      int16_t ev[kPer];
+#pragma unroll
+      for (int r = 0; r < kPer; r++)
       {
-        xs[1 + n] = (float)pcm[s0 + n];                   // the envelope k_rx_fir<AM> left there
+        const int n = tid + r * kPostThreads;
+        ev[r] = (n < len) ? pcm[s0 + n] : (int16_t)0;
+      }
+#pragma unroll
+      for (int r = 0; r < kPer; r++)
+      {
+        const int n = tid + r * kPostThreads;
+        if (n < len)
+        {
+          xs[1 + n] = (float)ev[r];
+        }
       }
     }
     else
     {
       // stage i, q with history: sample index g = s0 + n - kSsbHist .. ; g < 0 comes from state
-      for (int t = tid; t < len + kSsbHist; t += kPostThreads)
+      // (all of a thread's loads first: one memory round trip per segment)
+      constexpr int kPerS = (kPostSeg + kSsbHist + kPostThreads - 1) / kPostThreads;
+      int16_t iv[kPerS], qv[kPerS];
+#pragma unroll
+      for (int r = 0; r < kPerS; r++)
       {
+        const int t = tid + r * kPostThreads;
         const int g = s0 + t - kSsbHist;
-        int16_t iv, qv;
-        if (g < 0)
+        iv[r] = 0;
+        qv[r] = 0;
+        if (t < len + kSsbHist)
         {
-          iv = st->ssb_i[kSsbHist + g];
-          qv = st->ssb_q[kSsbHist + g];
+          if (g < 0)
+          {
+            iv[r] = st->ssb_i[kSsbHist + g];
+            qv[r] = st->ssb_q[kSsbHist + g];
+          }
+          else
+          {
+            const int bb = g / npcm, pp = g - bb * npcm;
+            iv[r] = siq[(size_t)bb * (2 * npcm) + pp];
+            qv[r] = siq[(size_t)bb * (2 * npcm) + npcm + pp];
+          }
         }
-        else
+      }
+#pragma unroll
+      for (int r = 0; r < kPerS; r++)
+      {
+        const int t = tid + r * kPostThreads;
+        if (t < len + kSsbHist)
         {
-          const int bb = g / npcm, pp = g - bb * npcm;
-          iv = siq[(size_t)bb * (2 * npcm) + pp];
-          qv = siq[(size_t)bb * (2 * npcm) + npcm + pp];
+          iq[0][t] = iv[r];
+          iq[1][t] = qv[r];
         }
-        iq[0][t] = iv;
-        iq[1][t] = qv;
       }
       __syncthreads();
       for (int n = tid; n < len; n += kPostThreads)
@@ -512,7 +612,11 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
     __syncthreads();
 
     // ---- step 2: the recurrence, 64 tiles, verified and repaired
+#ifdef HRFD_POST_ABLATE
+    if (false)
+#else
     if (wave == 0)
+#endif
     {
       int T = (len + 63) / 64;
       T |= 1;                                             // odd lane stride: no LDS bank conflicts
@@ -520,17 +624,12 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
       const int e = min(len, s + T);
       const int w0 = max(0, s - kPostWarm);               // warm-up start
       float y = (w0 == 0) ? y1 : 0.0f;
-      float xp = xs[w0];                                  // x[w0 - 1]
-      for (int n = w0; n < min(s, len); n++)
-      {
-        y = dcrem_step(xs[1 + n], xp, y);
-      }
+      // warm-up: the kPostWarm samples in front of the tile (those before the segment start do
+      // not exist: skipped), then the tile itself
+      y = dcrem_run<false>(xs + 1 + (s - kPostWarm), nullptr, 0, kPostWarm, kPostWarm - (s - w0),
+                           min(s, len) - (s - kPostWarm), y);
       const float y_spec = y;                             // speculated y[s-1]
-      for (int n = s; n < e; n++)
-      {
-        y = dcrem_step(xs[1 + n], xp, y);
-        ys[n] = y;
-      }
+      y = dcrem_run<true>(xs + 1 + s, ys + s, kPostSeg - s, T, 0, e - s, y);   // dummy slot: ys[kPostSeg]
       const bool active = s < len;
       const bool anchored = (w0 == 0);
       const float y_left = u2f(shr1(f2u(y), f2u(y_spec)));
