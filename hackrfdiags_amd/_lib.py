@@ -103,6 +103,12 @@ def load() -> C.CDLL:
     L.hrfd_ingest_submit.argtypes = [_vp, C.c_uint32]
     L.hrfd_ingest_collect.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]
     L.hrfd_ingest_replayed.argtypes = [_vp, C.POINTER(C.c_uint64)]
+    L.hrfd_txring_create.argtypes = [C.c_uint32, C.POINTER(_vp)]
+    L.hrfd_txring_destroy.argtypes = [_vp]
+    L.hrfd_txring_set_running.argtypes = [_vp, C.c_uint32, C.c_int]
+    L.hrfd_txring_write.argtypes = [_vp, C.c_uint32, _vp]
+    L.hrfd_txring_read_batch.argtypes = [_vp, _vp]
+    L.hrfd_txring_stats.argtypes = [_vp, C.c_uint32, _u32p]
     L.hrfd_mod_create.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(_vp)]
     L.hrfd_mod_destroy.argtypes = [_vp]
     L.hrfd_mod_reset.argtypes = [_vp, C.c_uint32]

@@ -7,3 +7,4 @@
 #include "hrfd_tx_kernels.hip"
 #include "hrfd_api.hip"
 #include "hrfd_ingest.hip"
+#include "hrfd_txring.hip"

@@ -208,6 +208,23 @@ int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32_t n_per_ch
 int hrfd_mod_sync(hrfd_mod *h);
 
 /* ------------------------------------------------------------------------------
+ * The transmit side's PCM ring, one per channel (host code).  Same slots, table
+ * and pacing policy as BasebandDataProcessor (src_diags/BasebandDataProcessor.cc: ctor :41-84,
+ * getNextUnfilledBuffer :410-425, getNextFilledBuffer :476-606 -- more than 10 blocks of lag
+ * drops one, fewer than 6 sends the previous one again, not running reads zeros --, start/stop
+ * :306-356).  hrfd_txring_read_batch gathers one 512-sample block per channel into
+ * batch[n_channels][512], the input of hrfd_mod_process(h, batch, 512, ...).
+ * stats: {produced, consumed, dropped, added, writer index, reader index}.
+ */
+typedef struct hrfd_txring hrfd_txring;
+int hrfd_txring_create(uint32_t n_channels, hrfd_txring **out);
+int hrfd_txring_destroy(hrfd_txring *r);
+int hrfd_txring_set_running(hrfd_txring *r, uint32_t channel, int running);
+int hrfd_txring_write(hrfd_txring *r, uint32_t channel, const int16_t *pcm512);
+int hrfd_txring_read_batch(hrfd_txring *r, int16_t *batch);
+int hrfd_txring_stats(hrfd_txring *r, uint32_t channel, uint32_t *out6);
+
+/* ------------------------------------------------------------------------------
  * Nco (Nco/Nco.cc:186-257, Nco/PhaseAccumulator.cc:157-181): n_channels
  * oscillators advanced `count` samples each; fast != 0 selects runFast's table.
  * i_out/q_out are [n_channels][count] float host buffers.

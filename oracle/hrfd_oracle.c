@@ -1279,6 +1279,104 @@ uint32_t orc_wbfmmod_process(orc_wbfmmod *h, const int16_t *pcm, uint32_t n, int
   return n << 9;                                           /* :354: (32 n) << 4 */
 }
 
+/* ------------------------------------------------------------------ tx PCM ring
+ * BasebandDataProcessor's 16-slot ring of 512-sample PCM blocks between the PCM reader thread and
+ * the transmit callback (BasebandDataProcessor.cc): getNextUnfilledBuffer :410-425 (writer),
+ * getNextFilledBuffer :476-606 (reader with the pacing policy: lag > 10 drops a block, lag < 6
+ * repeats one; first read after start() jumps to pcmReaderStartIndexTable[writer]), ctor :41-84,
+ * start/stop :306-356 (Idle <-> Running; stop clears `synchronized`). */
+#define ORC_RING 16
+struct orc_txring
+{
+  uint32_t writer, reader;
+  int running, synchronized;
+  uint32_t produced, consumed, dropped, added;
+  int16_t buf[ORC_RING][512];
+};
+static const int k_reader_start[ORC_RING] = {8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7};
+
+orc_txring *orc_txring_create(void)
+{
+  struct orc_txring *h = (struct orc_txring *)calloc(1, sizeof(*h));
+  h->writer = ORC_RING - 1;
+  h->reader = (uint32_t)k_reader_start[h->writer];
+  return h;
+}
+
+void orc_txring_destroy(orc_txring *h)
+{
+  free(h);
+}
+
+void orc_txring_set_running(orc_txring *h, int running)
+{
+  if (running)
+  {
+    h->running = 1;                                        /* start(): Idle -> Running (:306-315) */
+  }
+  else if (h->running)
+  {
+    h->running = 0;                                        /* stop(): Running -> Idle, unsynchronised (:341-354) */
+    h->synchronized = 0;
+  }
+}
+
+void orc_txring_write(orc_txring *h, const int16_t *pcm512)
+{
+  h->writer++;
+  h->writer %= ORC_RING;
+  memcpy(h->buf[h->writer], pcm512, 512 * sizeof(int16_t));
+  h->produced++;
+}
+
+void orc_txring_read(orc_txring *h, int16_t *pcm512)
+{
+  int32_t u = (int32_t)h->writer, l = (int32_t)h->reader;
+  if (u < l)
+  {
+    u += ORC_RING - 1;                                     /* :511-514 (sic: SIZE - 1) */
+  }
+  const int32_t lag = u - l;
+  if (lag > 10)
+  {
+    h->reader++;
+    h->reader %= ORC_RING;
+    h->dropped++;
+  }
+  else if (lag < 6)
+  {
+    int32_t d = (int32_t)h->reader - 1;
+    if (d < 0)
+    {
+      d += ORC_RING;
+    }
+    h->reader = (uint32_t)d;
+    h->added++;
+  }
+  if (h->running)
+  {
+    if (!h->synchronized)
+    {
+      h->synchronized = 1;
+      h->reader = (uint32_t)k_reader_start[h->writer];
+    }
+    memcpy(pcm512, h->buf[h->reader], 512 * sizeof(int16_t));
+    h->reader++;
+    h->reader %= ORC_RING;
+    h->consumed++;
+  }
+  else
+  {
+    memset(pcm512, 0, 512 * sizeof(int16_t));              /* zeroPcmBuffer */
+  }
+}
+
+void orc_txring_stats(const orc_txring *h, uint32_t *out6)
+{
+  out6[0] = h->produced; out6[1] = h->consumed; out6[2] = h->dropped; out6[3] = h->added;
+  out6[4] = h->writer; out6[5] = h->reader;
+}
+
 /* ------------------------------------------------------------------ Nco */
 struct orc_nco
 {

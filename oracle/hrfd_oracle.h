@@ -28,6 +28,7 @@ typedef struct orc_ssbmod orc_ssbmod; /* SsbModulator                           
 typedef struct orc_ammod orc_ammod;   /* AmModulator                                */
 typedef struct orc_fmmod orc_fmmod;   /* FmModulator                                */
 typedef struct orc_wbfmmod orc_wbfmmod; /* WbFmModulator                            */
+typedef struct orc_txring orc_txring; /* BasebandDataProcessor's PCM ring             */
 typedef struct orc_interp orc_interp; /* signals/interpolateSignal cascade          */
 typedef struct orc_nco orc_nco;       /* Nco + PhaseAccumulator                     */
 
@@ -78,6 +79,13 @@ void orc_wbfmmod_destroy(orc_wbfmmod *h);
 void orc_wbfmmod_reset(orc_wbfmmod *h);
 void orc_wbfmmod_set_deviation(orc_wbfmmod *h, float deviation);
 uint32_t orc_wbfmmod_process(orc_wbfmmod *h, const int16_t *pcm, uint32_t n, int8_t *iq_out);
+
+orc_txring *orc_txring_create(void);
+void orc_txring_destroy(orc_txring *h);
+void orc_txring_set_running(orc_txring *h, int running);
+void orc_txring_write(orc_txring *h, const int16_t *pcm512);
+void orc_txring_read(orc_txring *h, int16_t *pcm512);
+void orc_txring_stats(const orc_txring *h, uint32_t *out6);
 
 orc_interp *orc_interp_create(void);
 void orc_interp_destroy(orc_interp *h);

@@ -37,6 +37,7 @@
 #include "AmModulator.h"
 #include "FmModulator.h"
 #include "WbFmModulator.h"
+#include "BasebandDataProcessor.h"
 #include "Nco.h"
 #include "Interpolator_int16.h"
 #include "FirFilter_int16.h"
@@ -357,6 +358,42 @@ uint32_t ref_wbfmmod_process(void *hv, const int16_t *pcmPtr, uint32_t sampleCou
   uint32_t outBytes = 0;
   ((WbFmModulator *)hv)->acceptData(scratch.data(), sampleCount, iqOut, &outBytes);
   return outBytes;
+}
+
+// BasebandDataProcessor's PCM ring (BasebandDataProcessor.cc:410-425,476-606), driven without its
+// reader thread: the state start()/stop() set is written directly (members reached through the
+// harness's `#define private public`).
+void *ref_txring_create(void) { return new BasebandDataProcessor(); }
+void ref_txring_destroy(void *hv) { delete (BasebandDataProcessor *)hv; }
+void ref_txring_set_running(void *hv, int running)
+{
+  BasebandDataProcessor *p = (BasebandDataProcessor *)hv;
+  if (running)
+  {
+    p->streamState = BasebandDataProcessor::Running;
+  }
+  else if (p->streamState == BasebandDataProcessor::Running)
+  {
+    p->streamState = BasebandDataProcessor::Idle;
+    p->synchronized = false;
+  }
+}
+void ref_txring_write(void *hv, const int16_t *pcm512)
+{
+  int16_t *dst = ((BasebandDataProcessor *)hv)->getNextUnfilledBuffer();
+  memcpy(dst, pcm512, 512 * sizeof(int16_t));
+}
+void ref_txring_read(void *hv, int16_t *pcm512)
+{
+  const int16_t *src = ((BasebandDataProcessor *)hv)->getNextFilledBuffer();
+  memcpy(pcm512, src, 512 * sizeof(int16_t));
+}
+void ref_txring_stats(void *hv, uint32_t *out6)
+{
+  BasebandDataProcessor *p = (BasebandDataProcessor *)hv;
+  out6[0] = p->buffersProduced; out6[1] = p->buffersConsumed;
+  out6[2] = p->pcmBlocksDropped; out6[3] = p->pcmBlocksAdded;
+  out6[4] = p->pcmWriterIndex; out6[5] = p->pcmReaderIndex;
 }
 
 //---------------------------------------------------------------- Nco

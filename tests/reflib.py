@@ -72,6 +72,13 @@ class Oracle:
             getattr(L, f"orc_{kind}_{setter}").argtypes = [C.c_void_p, C.c_float]
             getattr(L, f"orc_{kind}_process").restype = C.c_uint32
             getattr(L, f"orc_{kind}_process").argtypes = [C.c_void_p, _i16p, C.c_uint32, _i8p]
+        L.orc_txring_create.restype = C.c_void_p
+        L.orc_txring_create.argtypes = []
+        L.orc_txring_destroy.argtypes = [C.c_void_p]
+        L.orc_txring_set_running.argtypes = [C.c_void_p, C.c_int]
+        L.orc_txring_write.argtypes = [C.c_void_p, _i16p]
+        L.orc_txring_read.argtypes = [C.c_void_p, _i16p]
+        L.orc_txring_stats.argtypes = [C.c_void_p, _u32p]
         L.orc_ssbmod_create.restype = C.c_void_p
         L.orc_ssbmod_create.argtypes = [C.c_int]
         L.orc_ssbmod_destroy.argtypes = [C.c_void_p]
@@ -160,6 +167,9 @@ class Oracle:
     def ssbmod(self, lsb=True):
         return _OrcSsbMod(self.lib, lsb)
 
+    def txring(self):
+        return _TxRing(self.lib, "orc")
+
     def ammod(self):
         return _Mod(self.lib, "orc", "ammod", "set_index")
 
@@ -237,6 +247,36 @@ class _OrcDemod:
         pcm = np.zeros(len(iq256) // 2 + 8, dtype=np.int16)
         n = self.lib.orc_demod_process(self.h, _p(iq256, _i8p), len(iq256), _p(pcm, _i16p), len(pcm))
         return pcm[:n].copy()
+
+
+class _TxRing:
+    """BasebandDataProcessor's PCM ring in either library (one channel)."""
+
+    def __init__(self, lib, prefix):
+        self.lib, self.pre = lib, prefix
+        self.h = C.c_void_p(getattr(lib, f"{prefix}_txring_create")())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.lib, f"{self.pre}_txring_destroy")(self.h)
+            self.h = None
+
+    def set_running(self, running):
+        getattr(self.lib, f"{self.pre}_txring_set_running")(self.h, int(bool(running)))
+
+    def write(self, pcm512):
+        pcm512 = np.ascontiguousarray(pcm512, dtype=np.int16)
+        getattr(self.lib, f"{self.pre}_txring_write")(self.h, _p(pcm512, _i16p))
+
+    def read(self):
+        out = np.zeros(512, dtype=np.int16)
+        getattr(self.lib, f"{self.pre}_txring_read")(self.h, _p(out, _i16p))
+        return out
+
+    def stats(self):
+        out = np.zeros(6, dtype=np.uint32)
+        getattr(self.lib, f"{self.pre}_txring_stats")(self.h, _p(out, _u32p))
+        return out
 
 
 class _Mod:
@@ -379,6 +419,13 @@ class Ref:
             getattr(L, f"ref_{kind}_{setter}").argtypes = [C.c_void_p, C.c_float]
             getattr(L, f"ref_{kind}_process").restype = C.c_uint32
             getattr(L, f"ref_{kind}_process").argtypes = [C.c_void_p, _i16p, C.c_uint32, _i8p]
+        L.ref_txring_create.restype = C.c_void_p
+        L.ref_txring_create.argtypes = []
+        L.ref_txring_destroy.argtypes = [C.c_void_p]
+        L.ref_txring_set_running.argtypes = [C.c_void_p, C.c_int]
+        L.ref_txring_write.argtypes = [C.c_void_p, _i16p]
+        L.ref_txring_read.argtypes = [C.c_void_p, _i16p]
+        L.ref_txring_stats.argtypes = [C.c_void_p, _u32p]
         L.ref_ssbmod_create.restype = C.c_void_p
         L.ref_ssbmod_create.argtypes = [C.c_int]
         L.ref_ssbmod_destroy.argtypes = [C.c_void_p]
@@ -441,6 +488,9 @@ class Ref:
 
     def ssbmod(self, lsb=True):
         return _RefSsbMod(self.lib, lsb)
+
+    def txring(self):
+        return _TxRing(self.lib, "ref")
 
     def ammod(self):
         return _Mod(self.lib, "ref", "ammod", "set_index", max_call=512)
