@@ -364,7 +364,12 @@ uint32_t ref_wbfmmod_process(void *hv, const int16_t *pcmPtr, uint32_t sampleCou
 // reader thread: the state start()/stop() set is written directly (members reached through the
 // harness's `#define private public`).
 void *ref_txring_create(void) { return new BasebandDataProcessor(); }
-void ref_txring_destroy(void *hv) { delete (BasebandDataProcessor *)hv; }
+void ref_txring_destroy(void *hv)
+{
+  // the destructor calls stop(), which joins the reader thread when Running: there is none here
+  ((BasebandDataProcessor *)hv)->streamState = BasebandDataProcessor::Idle;
+  delete (BasebandDataProcessor *)hv;
+}
 void ref_txring_set_running(void *hv, int running)
 {
   BasebandDataProcessor *p = (BasebandDataProcessor *)hv;
