@@ -472,3 +472,27 @@ def test_full_size_bench_batch_matches_oracle(oracle):
         for c in range(k, C, 8):                          # every channel with this input
             assert (got[c] == got[k]).all(), (c, k)
     assert rx.debug_counters()[5] == 0
+
+
+def test_odd_shapes_mixed_modes_and_runs(oracle):
+    """37 channels (not a multiple of the 8 XCDs) in five modes, 5 blocks of 65536 bytes per call,
+    forced runs of 3 blocks, two calls: every channel against its own sequential oracle"""
+    C, B, bb = 37, 5, 65536
+    modes = [WBFM, AM, FM, LSB, USB, WBFM, NONE]
+    raw = [synth.make_input("fmtone" if c % 3 else "lcg", 300 + c, 3)[: 2 * B * bb].reshape(2 * B, bb) for c in range(C)]
+    xs = np.stack(raw)
+    rx = api.Rx(C)
+    for c in range(C):
+        rx.set_mode(modes[c % len(modes)], channel=c)
+    rx.debug_set_run_len(3)
+    r1 = rx.process_block(xs[:, :B], B)
+    r2 = rx.process_block(xs[:, B:], B)
+    pcm = np.concatenate([r1[0], r2[0]], axis=1)
+    n_pcm = np.concatenate([r1[1], r2[1]], axis=1)
+    for c in range(C):
+        m = modes[c % len(modes)]
+        o = oracle.rx(); o.set_mode(m)
+        for b in range(2 * B):
+            want = o.process(xs[c, b])[0]
+            assert n_pcm[c, b] == len(want), (c, m, b)
+            assert (pcm[c, b, :len(want)] == want).all(), (c, m, b)
