@@ -376,6 +376,7 @@ def main():
                            else "all demodulator kernels of a step"),
                 "kernel_ms_mean": round(mean_ms, 4),
                 "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                "kernel_ms_median": round(float(np.median(kernel_ms)), 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
             "verification": {"uncommitted_launches": counters[5], "tiles_repaired_in_place": counters[4],
@@ -383,6 +384,9 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, os.cpu_count() or 1)
+            # also the reference on ONE host thread (config 1's shape), a short sample
+            one = cpu_baseline(min(3.0, args.cpu_seconds), 1)
+            line["cpu_baseline"]["single_thread_value"] = one["value"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
