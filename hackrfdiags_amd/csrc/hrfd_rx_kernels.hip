@@ -706,7 +706,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
                        ? reinterpret_cast<uint16_t *>(P.iq256 + X.ounit * (size_t)(2 * X.n256))
                        : nullptr;
   const float *lut = P.atan2_lut;
-  const int nskip = X.first ? 0 : (X.hal >> 6);          // chunks of history: not in the squelch sum
+  const int nskip = (-X.vstart) >> 6;                    // chunks of history in front of the block: not in the squelch sum
 
   // stage 1: raw chunk -> 256 kS/s sample, side outputs, atan2 gather issued
   auto front = [&](const uint4 raw, const int ch) -> float {
