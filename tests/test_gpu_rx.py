@@ -390,15 +390,17 @@ def test_wbfm_block_runs_match_oracle(oracle, run_len, kind):
     rx = api.Rx(C)
     rx.set_mode(api.WBFM)
     rx.debug_set_run_len(run_len)
-    r1 = rx.process_block(xs[:, :B], B)
-    r2 = rx.process_block(xs[:, B:], B)
+    r1 = rx.process_block(xs[:, :B], B, want_iq256=True)
+    r2 = rx.process_block(xs[:, B:], B, want_iq256=True)
     pcm = np.concatenate([r1[0], r2[0]], axis=1)
     mag = np.concatenate([r1[2], r2[2]], axis=1)
+    iq256 = np.concatenate([r1[4], r2[4]], axis=1)
     for c in range(C):
         want = _oracle_stream(oracle, WBFM, xs[c], 2 * B)
         for b in range(2 * B):
             assert (pcm[c, b] == want[b][0]).all(), (run_len, c, b)
             assert int(mag[c, b]) == want[b][1], (run_len, c, b)   # the squelch magnitude of every block
+            assert (iq256[c, b] == want[b][3]).all(), (run_len, c, b)   # and the 256 kS/s dump stream
     assert rx.debug_counters()[5] == 0           # every launch verified clean and was committed
 
 
