@@ -439,8 +439,9 @@ extern "C" int hrfd_rx_reset_demod(hrfd_rx *h, uint32_t channel, int mode)
   return for_channels(h, channel, [&](uint32_t c) { h->pending_resets.push_back({c, mode}); });
 }
 
-// test hook (not in the public header): shrink the de-emphasis warm-up so that
-// the speculation-failure / replay path can be exercised.
+// test hook (not in the public header): shrink the de-emphasis warm-up (warm / 128 tiles, at
+// most kWarmTiles) and start the lanes from y = 0 instead of their seed, so that the
+// speculation-failure / repair / replay paths can be exercised.  kWarm restores the default.
 extern "C" int hrfd_rx_debug_set_warm(hrfd_rx *h, int warm)
 {
   if (h == nullptr || warm < 0 || warm > kWarm || (warm & 1))
@@ -639,19 +640,21 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
 
   const uint32_t n256 = opt.src256 ? block_bytes / 2 : block_bytes / 16;
   const uint32_t halo_unit = opt.src256 ? 2u : 16u;   // input bytes per 256 kS/s sample
-  // 64 de-emphasis tiles end at n256; tile 0 is sacrificial, tile 1 must start at
-  // or before the first history sample the integer stages read (-kNeedHist).
-  int tile = (int)((n256 + kNeedHist + 62) / 63);
-  while ((tile & 3) != 2)
+  // De-emphasis tiles of kTile samples end at n256.  A lane starts warm_tiles tiles early from a
+  // seed summed over seed_terms tiles, so in a block that has to re-derive its history (the first
+  // block of a workgroup's run when b > 0) the first `sac` tiles cannot be started properly: they
+  // are sacrificial, and tile `sac` must begin at or before the cross-block check position
+  // -(kNeedHist + 1), the first sample the integer stages' history is built from.
+  const int warm_tiles = (h->warm >= kWarm) ? kWarmTiles : std::min(kWarmTiles, h->warm / 128);
+  const int seed_terms = (h->warm >= kWarm) ? kSeedTerms : 0;
+  const int sac = warm_tiles + seed_terms;
+  const int ntiles = ((int)n256 + kNeedHist + 1 + kTile - 1) / kTile + sac;
+  const int origin = (int)n256 - ntiles * kTile;
+  const int hal = (-origin + 63) / 64 * 64;
+  if (ntiles > kMaxTiles)
   {
-    // tile = 2 (mod 4): every lane's range starts on an even dword (64-bit LDS accesses in the
-    // recurrence) and lanes 0..31 fall into 32 different 8-byte banks (tile / 2 is odd)
-    tile++;
+    return fail(HRFD_EINVAL, "internal: %d de-emphasis tiles exceed %d", ntiles, kMaxTiles);
   }
-  const int origin = (int)n256 - 64 * tile;
-  // history produced in front of the block: tile 1's warm-up is the earliest sample anybody
-  // reads (tile 0 is never materialised: its lane shadows tile 1)
-  const int hal = ((h->warm - (origin + tile)) + 63) / 64 * 64;
   if (hal > kMaxHal)
   {
     return fail(HRFD_EINVAL, "internal: history %d exceeds %d", hal, kMaxHal);
@@ -729,10 +732,12 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.block_bytes = block_bytes;
   P.n_blocks = n_blocks;
   P.n256 = n256;
-  P.tile = tile;
+  P.ntiles = ntiles;
   P.origin = origin;
   P.hal = hal;
-  P.warm = h->warm;
+  P.warm_tiles = warm_tiles;
+  P.seed_terms = seed_terms;
+  P.seed_ct = (float)pow(-(double)DEEMPH_A1, (double)kTile);
   P.serial = opt.serial;
   P.src256 = opt.src256;
   P.stagger = h->stagger & 63;

@@ -15,10 +15,22 @@ namespace hrfd {
 constexpr int kThreads = 1024;                // 16 wave64 per workgroup (2 workgroups = 32 waves per CU)
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxN256 = 16384;               // 262144-byte block
-constexpr int kWarm = 512;                    // de-emphasis warm-up (P(miss) ~1e-5 per tile)
+// de-emphasis recurrence (phase B of k_rx_wbfm): the block is cut into tiles of kTile samples,
+// one per lane of the first four waves.  A lane starts kWarmTiles tiles early from an
+// APPROXIMATE y (a truncated geometric sum over kSeedTerms tiles, "seed") and is verified
+// bit for bit against its left neighbour.
+constexpr int kTile = 70;                     // = 2 (mod 4): 64-bit LDS accesses, 32 lanes in 32 different 8-byte banks
+constexpr int kBWaves = 4;                    // waves that run the recurrence (one per SIMD)
+constexpr int kMaxTiles = 64 * kBWaves;
+constexpr int kWarmTiles = 3;                 // warm-up = 210 samples behind a seed that is good to a few ulp
+constexpr int kSeedTerms = 5;                 // 0.949^350 = 1.2e-8
+constexpr int kWarm = 512;                    // argument of the test hook hrfd_rx_debug_set_warm that means "default"
 constexpr int kHist = 704;                    // exact history kept in front of a block (>= 644)
-constexpr int kMaxHal = 1664;                 // >= kWarm - origin for every block size, multiple of 64
 constexpr int kNeedHist = 644;                // first history sample the integer stages read
+// history re-derived in front of a speculative block: tile (kWarmTiles + kSeedTerms) must start at or
+// before -(kNeedHist + 1), so -origin <= 645 + kTile - 1 + 8 * kTile = 1274
+constexpr int kMaxHal = 1280;
+constexpr int kKeepMax = (kWarmTiles + kSeedTerms + 1) * kTile;   // v history a continuation block restores (630)
 constexpr int kMaxNV = kMaxN256 + kMaxHal;    // floats of the v/y stream in LDS
 // arithmetic atan2 (theta_arith in hrfd_rx_kernels.hip)
 constexpr int kTriEntries = 129 * 130 / 2;    // (a, b) with 0 <= b <= a <= 128
@@ -84,10 +96,12 @@ struct RxParams
   uint32_t block_bytes;
   uint32_t n_blocks;
   uint32_t n256;               // block_bytes / 16
-  int32_t tile;                // de-emphasis tile length T (odd)
-  int32_t origin;              // tile 0 (sacrificial) starts here; tile 1 starts <= -kNeedHist; tiles end at n256
-  int32_t hal;                 // history samples re-derived for blocks b > 0
-  int32_t warm;                // de-emphasis warm-up length (kWarm; tests shrink it)
+  int32_t ntiles;              // de-emphasis tiles of kTile samples; tile i = [origin + i*kTile, +kTile), the last ends at n256
+  int32_t origin;              // start of tile 0 (<= 0, even)
+  int32_t hal;                 // history samples re-derived in front of a run's first block (b > 0); >= -origin, multiple of 64
+  int32_t warm_tiles;          // warm-up length in tiles (kWarmTiles; tests shrink it)
+  int32_t seed_terms;          // tiles summed for a lane's approximate start (kSeedTerms; 0 = start from y = 0: tests)
+  float seed_ct;               // (-a1)^kTile
   int32_t serial;              // 1: exact one-lane recurrence (replay path, n_blocks == 1)
   int32_t src256;              // 1: the input IS the 256 kS/s mixed stream (inner demodulator API):
                                //    2 bytes per sample, no front end, no squelch

@@ -34,7 +34,7 @@
 #include <utility>
 #include "hrfd_tables.h"
 #ifndef HRFD_IIR_U
-#define HRFD_IIR_U 8
+#define HRFD_IIR_U 10   /* divides kTile and the warm-up: no scalar tail */
 #endif
 #ifdef HRFD_ABLATE
 #define HRFD_ABLATE_EARLY HRFD_ABLATE
@@ -674,7 +674,10 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   const RxParams &P = *X.P;
   const int lane = X.lane;
   const MixConst mc = mix_const(lane & 3);               // position & 3 (chunks are 64-aligned)
-  const int cbeg = REPAIR ? c0 - 1 : c0;
+  // REPAIR: one discarded chunk in front re-creates the carries -- except at the very start of
+  // the stream (first block of the call, chunk 0), where the carried state does
+  const int cbeg = REPAIR ? ((X.first && c0 == 0) ? 0 : c0 - 1) : c0;
+  const bool lead = REPAIR && cbeg < c0;
   if (cbeg >= c1)
   {
     if (ARITH && !REPAIR && X.publish)
@@ -795,7 +798,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
       const float t = front(load_chunk<S256>(X, cbeg + j), cbeg + j);
       if (MODE == 3)
       {
-        finish(t, cbeg + j, j == 0 ? !REPAIR : true);
+        finish(t, cbeg + j, j == 0 ? !lead : true);
         if (!REPAIR && j == 0)
         {
           edge[0] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(t), 0);
@@ -839,7 +842,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   q[LOOK % kDepth] = load_chunk<S256>(X, cbeg + LOOK + kDepth);
   if (MODE == 3)
   {
-    finish(th[0], cbeg, !REPAIR);
+    finish(th[0], cbeg, !lead);
     if (!REPAIR)
     {
       edge[0] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th[0]), 0);
@@ -994,6 +997,12 @@ __global__ void k_atan_eval(const uint8_t *corr, const float *inv, float *out)
   }
 }
 
+// c^n for the de-emphasis pole c = -a1 (approximate: only seeds use it)
+__device__ __forceinline__ float deemph_pow(int n)
+{
+  return exp2f((float)n * -0.07517338f);                 // log2(0.9492274)
+}
+
 template <int MODE, bool S256, bool ARITH>
 __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 {
@@ -1001,19 +1010,28 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   // arithmetic atan2 tables (zero-sized in the gather build of the kernel)
   __shared__ __attribute__((aligned(16))) uint8_t atcorr[ARITH ? kCorrBytes : 16];
   __shared__ __attribute__((aligned(16))) float atinv[ARITH ? kInvEntries : 4];
-  static_assert(sizeof(uint32_t) * kMaxNV + kCorrBytes + sizeof(float) * kInvEntries + 640 <= 81920,
+  static_assert(sizeof(uint32_t) * kMaxNV + kCorrBytes + sizeof(float) * kInvEntries + 1936 <= 81920,
                 "two workgroups per CU need <= 80 KiB of LDS each");
   __shared__ uint32_t red[kWaves];
   __shared__ int8_t dbfs8[128];         // the reachable part of the dBFS table (0..48), so that the
                                         // squelch decision after phase A does not wait for a global load
   __shared__ float tailcarry[2];        // theta, b0*x of the block's last sample
   __shared__ uint32_t edges[kWaves][4]; // per run: theta of its first two and last two samples
+  // phase B
+  __shared__ float parr[kMaxTiles + 8]; // per-tile geometric partial sums; in the repair path the speculated starts
+  __shared__ float wfin[kBWaves];       // final y of each recurrence wave's last lane
+  __shared__ unsigned long long badmask[kBWaves];
+  __shared__ uint32_t anybad;
+  __shared__ float yanchor;             // true y in front of the warm-up of tile j0 of the run's NEXT block
+  __shared__ float chk_prev;            // this block's cross-block check value, for the next block of the run
+  __shared__ __attribute__((aligned(4))) int16_t ctail[kWbS + kWbU + kWbV + 2];   // integer-stage histories, ditto
 
   // A workgroup owns a RUN of up to P.run_len consecutive blocks of one channel and walks them in
-  // order.  Only the run's first block produces the history in front of it; for the others the
-  // tail of v that the previous block produced is carried over in two registers per thread
-  // (it has to survive phase B, which overwrites v with y in place) and put back in front of
-  // the new block.  Everything else -- tiles, speculation, checks -- is per block, as before.
+  // order.  Only the run's first block re-derives history in front of it (and is verified across
+  // blocks by k_rx_epilogue); a continuation block carries everything exactly: the tail of v (one
+  // register per thread, it has to survive phase B, which overwrites v with y in place), theta
+  // and b0*x of the last sample, one true y for its first tile's start, the integer stages'
+  // histories.
   uint32_t ci, run;
   if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
   {
@@ -1026,13 +1044,13 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   if (P.run_len > 1 && ((blockIdx.x >> 8) & 1u) != 0u)
   {
     // the two workgroups that share a CU (ids w and w + 256) would otherwise walk their runs in
-    // lockstep and sit in the single-wave phase B at the same time
+    // lockstep and sit in phase B at the same time
     for (int i = 0; i < P.stagger; i++)
     {
       __builtin_amdgcn_s_sleep(127);
     }
   }
-  uint32_t keep0 = 0u, keep1 = 0u;                       // v[n256 - hal + tid], v[n256 - hal + 1024 + tid]
+  uint32_t keep0 = 0u;                                   // v[n256 - nkeep + tid]
   for (uint32_t b = b_first; b < b_end; b++)
   {
   // Everything derived from the thread index is re-derived per block behind an opaque copy:
@@ -1044,16 +1062,24 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // wave-uniform: keep it scalar
   const bool first = (b == 0);
   const bool cont = (b > b_first);                       // the previous block of the run is ours
+  const int hal = P.hal;
+  // de-emphasis geometry (rx_launch): tile i = [origin + i*kTile, +kTile), the last one ends at n256
+  constexpr int T = kTile;
+  const int wt = P.warm_tiles, M = P.seed_terms;
+  const int W = wt * T;
+  const int nkeep = (wt + M + 1) * T;                    // v history a block with a true start needs (<= kKeepMax)
   if (cont)
   {
     __syncthreads();                                     // the previous block's phase C is done with the buffer
-    lds[tid] = keep0;
-    if (tid + kThreads < P.hal)
+    if (tid < nkeep)
     {
-      lds[tid + kThreads] = keep1;
+      lds[hal - nkeep + tid] = keep0;
     }
   }
-  const int hal = P.hal;
+  else if (first && MODE == 3 && tid < nkeep)
+  {
+    lds[hal - nkeep + tid] = 0u;                         // nothing precedes the stream start: the seeds sum zeros
+  }
   const ChanState *st = P.state + c;
   const ChanCfg cfg = P.cfg[c];
   const size_t unit = (size_t)c * P.n_blocks + b;                    // launch-local scratch index
@@ -1145,6 +1171,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   {
     red[wave] = magsum;
   }
+  if (tid == 0)
+  {
+    anybad = 0u;                                         // read after phase B's verification barrier
+  }
   __syncthreads();
   uint32_t total = 0;
   for (int w = 0; w < kWaves; w++)
@@ -1189,16 +1219,23 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 
   // ----------------------------------------------------------------- phase B
   // y[n] = v[n] - a1*y[n-1] (IirFilter.cc:161-176 with one recursive tap), in place.
-  // 64 tiles of T samples end at n256; tile i = [origin + i*T, origin + (i+1)*T).
-  // Each lane first runs `warm` samples of history from y = 0 (from the carried
-  // y when the stream start lies inside its window), then its own tile.  A lane
-  // whose warmed-up y[s-1] is not bit-identical to its left neighbour's final y
-  // has not re-synchronised: its tile is re-derived and re-run from the true
-  // value (rare: DESIGN.md gives the measured rates).  Tile 0 would lie before the
-  // first history sample anybody reads (-kNeedHist is in tile 1): it is skipped.
-  const int T = P.tile;
-  const int origin = P.origin;
-  const int warm = P.warm;
+  // The recurrence rounds twice per step and cannot be re-associated, so it is run as up to 256
+  // tiles of T samples in parallel, one per lane of the first kBWaves waves (one wave per SIMD).
+  // Lane i first computes the geometric partial sum of v over its own tile; a lane's start
+  // value at W = wt*T samples before its tile is the sum of M such partials -- y to a few ulp.
+  // From there the float trajectory re-synchronises *bit for bit* with the true one during the
+  // warm-up (contraction 0.949 per step).  That is verified, not assumed: every lane compares
+  // its warmed-up y[s-1] with its left neighbour's final y; a tile that has not merged is
+  // re-derived and re-run from the true value, then the check moves right (rare).
+  //   first block of the call: lanes whose start precedes the stream start take the carried y
+  //     and skip the steps before position 0 (exact).
+  //   continuation block: v history and one true y (yanchor) are carried: lane j0 is exact.
+  //   other blocks (b > 0, first of a run): history re-derived from the raw input; the first
+  //     wt + M lanes cannot be seeded and do not run; lane wt + M is checked across blocks by
+  //     k_rx_epilogue (y at -645 as computed here vs. by the predecessor).
+  const int ntiles = P.ntiles, origin = P.origin;
+  const int j0 = (-origin) / T;                          // the tile that contains (or begins at) position 0
+  const int fa = (first || cont) ? j0 : (wt + M);        // first lane that runs; it is anchored
   HRFD_STAMP(2)
   if (wave == 0)
   {
@@ -1207,146 +1244,243 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
     // the neighbouring wave produced.  One lane per run boundary.  In a continuation block
     // the first run starts provisionally too: its two samples need the previous block's last
     // theta and b0*x, still in tailcarry[].
+    const int nruns = min(nch, kWaves);
+    if (cont && lane == 0)
     {
-      const int nruns = min(nch, kWaves);
-      if (cont && lane == 0)
-      {
-        const float tm1 = tailcarry[0], pm1 = tailcarry[1];
-        const float t0 = u2f(edges[0][0]), t1 = u2f(edges[0][1]);
-        const float p0 = numerator_p(t0, tm1, X.kgain);
-        const float p1 = numerator_p(t1, t0, X.kgain);
-        lds[0 + hal] = f2u(p0 + pm1);
-        lds[1 + hal] = f2u(p1 + p0);
-      }
-      if (lane >= 1 && lane < nruns)
-      {
-        const int w = lane;
-        const int sw = X.vstart + 64 * (w * cbase + min(w, cextra));   // first position of run w
-        const float tm2 = u2f(edges[w - 1][2]), tm1 = u2f(edges[w - 1][3]);
-        const float t0 = u2f(edges[w][0]), t1 = u2f(edges[w][1]);
-        const float pm1 = numerator_p(tm1, tm2, X.kgain);
-        const float p0 = numerator_p(t0, tm1, X.kgain);
-        const float p1 = numerator_p(t1, t0, X.kgain);
-        lds[sw + hal] = f2u(p0 + pm1);
-        lds[sw + 1 + hal] = f2u(p1 + p0);
-      }
-      if (lane == 0)
-      {
-        const float tl2 = u2f(edges[nruns - 1][2]), tl1 = u2f(edges[nruns - 1][3]);
-        tailcarry[0] = tl1;
-        tailcarry[1] = numerator_p(tl1, tl2, X.kgain);
-      }
+      const float tm1 = tailcarry[0], pm1 = tailcarry[1];
+      const float t0 = u2f(edges[0][0]), t1 = u2f(edges[0][1]);
+      const float p0 = numerator_p(t0, tm1, X.kgain);
+      const float p1 = numerator_p(t1, t0, X.kgain);
+      lds[0 + hal] = f2u(p0 + pm1);
+      lds[1 + hal] = f2u(p1 + p0);
+    }
+    if (lane >= 1 && lane < nruns)
+    {
+      const int w = lane;
+      const int sw = X.vstart + 64 * (w * cbase + min(w, cextra));   // first position of run w
+      const float tm2 = u2f(edges[w - 1][2]), tm1 = u2f(edges[w - 1][3]);
+      const float t0 = u2f(edges[w][0]), t1 = u2f(edges[w][1]);
+      const float pm1 = numerator_p(tm1, tm2, X.kgain);
+      const float p0 = numerator_p(t0, tm1, X.kgain);
+      const float p1 = numerator_p(t1, t0, X.kgain);
+      lds[sw + hal] = f2u(p0 + pm1);
+      lds[sw + 1 + hal] = f2u(p1 + p0);
+    }
+    if (lane == 0)
+    {
+      const float tl2 = u2f(edges[nruns - 1][2]), tl1 = u2f(edges[nruns - 1][3]);
+      tailcarry[0] = tl1;
+      tailcarry[1] = numerator_p(tl1, tl2, X.kgain);
     }
   }
+  __syncthreads();                                       // v is complete
   if (b + 1 < b_end)
   {
-    // the next block of the run continues from this one: keep the tail of v (phase B is about
-    // to overwrite it with y)
-    __syncthreads();
-    keep0 = lds[n256 + tid];                             // position n256 - hal + tid
-    keep1 = (tid + kThreads < hal) ? lds[n256 + kThreads + tid] : 0u;
-    __syncthreads();
+    // the next block of the run continues from this one: keep the tail of v (the chains below,
+    // behind the next barrier, overwrite it with y)
+    keep0 = (tid < nkeep) ? lds[n256 - nkeep + tid + hal] : 0u;
   }
-  if (wave == 0)
+  const float a1 = DEEMPH_A1;
+  const int ti = wave * 64 + lane;                       // this lane's tile (waves >= kBWaves have none)
+  const int s = origin + ti * T;
+  const bool bwave = wave < kBWaves;
+  float y = 0.0f, y_spec = 0.0f;
+  bool active = false;
+  if (P.serial)
   {
-    // the recurrence is a long dependent chain that needs few issue slots: let it
-    // win arbitration against the streaming waves of the neighbouring workgroup
-    __builtin_amdgcn_s_setprio(3);
-    const float a1 = DEEMPH_A1;
-    if (P.serial)
+    // exact replay path (n_blocks == 1): one lane, the whole block in order
+    __syncthreads();
+    if (tid == 0)
     {
-      // exact replay path (n_blocks == 1): one lane, the whole block in order
-      if (lane == 0)
+      float ys = st->wb_y;
+      for (int n = 0; n < n256; n++)
       {
-        float y = st->wb_y;
-        for (int n = 0; n < n256; n++)
-        {
-          const float r = a1 * y;
-          y = u2f(lds[n + hal]) - r;
-          lds[n + hal] = f2u(y);
-        }
+        const float r = a1 * ys;
+        ys = u2f(lds[n + hal]) - r;
+        lds[n + hal] = f2u(ys);
       }
     }
-    else if (!(ablate(P, 2)))                           // (flag 2: TIMING EXPERIMENT ONLY, skip phase B)
+    __syncthreads();
+  }
+  else
+  {
+    // B1: partial sums  P_i = sum_k c^k v[s + T-1 - k], c = -a1, as two interleaved Horner chains in c^2
+    if (bwave && M > 0 && ti < ntiles && !ablate(P, 2))
     {
-      // tile 0 would lie before the first history sample anybody reads: it is not
-      // materialised, lane 0 shadows lane 1 (same reads, same values written)
-      const int s = origin + max(lane, 1) * T;
-      float y = first ? st->wb_y : 0.0f;
-      // In a first block positions n < 0 do not exist: those steps are skipped
-      // (y keeps the carried value).  kskip = steps to skip, counted from the
-      // start of the warm-up; it is 0 for every lane of a later block.
-      const int kskip = first ? max(0, warm - s) : 0;
-      const uint32_t *vp = lds + (s - warm + hal);       // lane stride T is odd: bank-conflict free
-      uint32_t *yp = lds + (s + hal);
-      float y_spec;                                      // speculated y[s-1]
+      const float cc = -a1;
+      const float c2 = cc * cc;
+      const uint2 *p2 = reinterpret_cast<const uint2 *>(lds + (s + hal));
+      float pa = 0.0f, pb = 0.0f;
+#pragma unroll 7
+      for (int j = 0; j < T / 2; j++)
+      {
+        const uint2 w = p2[j];
+        pa = __builtin_fmaf(pa, c2, u2f(w.x));
+        pb = __builtin_fmaf(pb, c2, u2f(w.y));
+      }
+      float p = __builtin_fmaf(pa, cc, pb);
+      if (first && ti == j0)
+      {
+        p += deemph_pow(s + T) * st->wb_y;               // the stream's past, as seen from the end of this tile
+      }
+      parr[ti] = p;
+    }
+    __syncthreads();                                     // partial sums visible; every keep0 read is done
+    active = bwave && ti >= fa && ti < ntiles && !ablate(P, 2);   // (flag 2: TIMING EXPERIMENT ONLY, skip phase B)
+    if (active)
+    {
+      // the recurrence is a long dependent chain that needs few issue slots: let it
+      // win arbitration against the streaming waves of the neighbouring workgroup
+      __builtin_amdgcn_s_setprio(3);
+      if (M > 0)
+      {
+        // y at the end of tile ti - wt - 1:  sum_{m < M} (c^T)^m P[ti - wt - 1 - m], oldest first
+        float acc = 0.0f;
+        for (int m = M; m >= 1; m--)
+        {
+          acc = __builtin_fmaf(acc, P.seed_ct, parr[ti - wt - m]);
+        }
+        y = acc;
+      }
+      int kskip = 0;
       if (first)
       {
-        y = iir_run<false, true>(vp, nullptr, warm, kskip, y);
+        if (s <= W)
+        {
+          // the start lies at or before the stream start: carried y, steps at n < 0 skipped
+          y = st->wb_y;
+          kskip = W - s;
+        }
+      }
+      else if (cont && ti == j0)
+      {
+        y = yanchor;                                     // true y[s - W - 1], saved by the previous block
+      }
+      const uint32_t *vp = lds + (s - W + hal);          // lane stride T = 2 (mod 4): 64-bit accesses, no bank conflicts
+      uint32_t *yp = lds + (s + hal);
+      if (first && wave == 0)
+      {
+        y = iir_run<false, true>(vp, nullptr, W, kskip, y);
         y_spec = y;
-        y = iir_run<true, true>(yp, yp, T, kskip - warm, y);
+        y = iir_run<true, true>(yp, yp, T, kskip - W, y);
       }
       else
       {
-        y = iir_run<false, false>(vp, nullptr, warm, 0, y);
+        y = iir_run<false, false>(vp, nullptr, W, 0, y);
         y_spec = y;
         y = iir_run<true, false>(yp, yp, T, 0, y);
       }
-      // Anchors: lanes 0 and 1 (tile 1 is the first one; the chain behind it is checked
-      // across blocks by k_rx_epilogue) and, in a first block, lanes whose
-      // window contains the true stream state (s - warm <= 0).
-      const bool anchored = (lane <= 1) || (first && (s - warm) <= 0);
-      const float y_left = u2f(shr1(f2u(y), f2u(y_spec)));
-      unsigned long long bad = __ballot(!anchored && !same_trajectory(y_left, y_spec));
-      uint32_t repairs = 0;
-      while (bad != 0ull)
+      __builtin_amdgcn_s_setprio(0);
+      if (lane == 63)
       {
-        const int j = __ffsll((long long)bad) - 1;       // wave-uniform, >= 1
-        bad &= ~(1ull << j);
-        repairs++;
-        const int sj = origin + j * T;
-        // re-derive v over tile j (it was overwritten by the mis-started y)
-        const int rc0 = (sj - X.vstart) >> 6;
-        const int rc1 = (sj + T - X.vstart + 63) >> 6;
-        uint32_t dummy_mag = 0, dummy_e[4];
-        produce_stream<MODE, true, false, S256, ARITH>(X, rc0, rc1, sj, sj + T, dummy_mag, dummy_e);
-        // re-run the tile from the true y[sj - 1] = final y of lane j-1
-        const float y_true = u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(y), j - 1));
-        if (lane == j)
-        {
-          uint32_t *rp = lds + (sj + hal);
-          y = iir_run<true, false>(rp, rp, T, 0, y_true);
-        }
-        // the right neighbour's speculation must now match the corrected final y
-        if (j + 1 < 64)
-        {
-          const uint32_t yj = (uint32_t)__builtin_amdgcn_readlane((int)f2u(y), j);
-          const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)f2u(y_spec), j + 1);
-          const int s1 = origin + (j + 1) * T;
-          const bool anch1 = first && (s1 - warm) <= 0;
-          if (!anch1 && !same_trajectory(u2f(yj), u2f(sp)))
-          {
-            bad |= 1ull << (j + 1);
-          }
-        }
-      }
-      if (repairs != 0 && lane == 0)
-      {
-        atomicAdd(&P.counters[kCntRepair], repairs);
+        wfin[wave] = y;
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();                                     // all chains done
+    // B3: every lane but the anchored one checks its speculated start against its left neighbour's end
+    if (bwave)
+    {
+      float y_left = u2f(shr1(f2u(y), f2u(y)));
+      if (lane == 0 && wave > 0)
+      {
+        y_left = wfin[wave - 1];
+      }
+      const bool bad = active && ti > fa && !same_trajectory(y_left, y_spec);
+      const unsigned long long bm = __ballot(bad);
+      if (lane == 0)
+      {
+        badmask[wave] = bm;
+        if (bm != 0ull)
+        {
+          anybad = 1u;
+        }
+      }
+    }
+    __syncthreads();
+    if (anybad != 0u)
+    {
+      // rare: repair in ascending order.  A tile's true start is the y in front of it in the
+      // buffer (its left neighbour is final by then); the speculated starts go to parr[].
+      if (bwave && ti < ntiles)
+      {
+        parr[ti] = y_spec;
+      }
+      __syncthreads();
+      if (wave == 0)
+      {
+        unsigned long long bm[kBWaves];
+#pragma unroll
+        for (int w = 0; w < kBWaves; w++)
+        {
+          bm[w] = badmask[w];
+        }
+        uint32_t repairs = 0;
+#pragma unroll
+        for (int w = 0; w < kBWaves; w++)
+        {
+          while (bm[w] != 0ull)
+          {
+            const int l = __ffsll((long long)bm[w]) - 1;   // wave-uniform
+            bm[w] &= ~(1ull << l);
+            repairs++;
+            const int j = w * 64 + l;
+            const int sj = origin + j * T;
+            // re-derive v over tile j (it was overwritten by the mis-started y)
+            const int rc0 = (sj - X.vstart) >> 6;
+            const int rc1 = (sj + T - X.vstart + 63) >> 6;
+            uint32_t dummy_mag = 0, dummy_e[4];
+            produce_stream<MODE, true, false, S256, ARITH>(X, rc0, rc1, sj, sj + T, dummy_mag, dummy_e);
+            if (lane == 0)
+            {
+              uint32_t *rp = lds + (sj + hal);
+              const float y_true = u2f(rp[-1]);
+              iir_run<true, false>(rp, rp, T, 0, y_true);
+            }
+            // the right neighbour's speculation must now match the corrected final y
+            if (j + 1 < ntiles)
+            {
+              const float yj = u2f(lds[sj + T - 1 + hal]);
+              const float sp = parr[j + 1];
+              if (!same_trajectory(yj, sp))
+              {
+                if (l == 63)
+                {
+                  if (w + 1 < kBWaves)
+                  {
+                    bm[w + 1 < kBWaves ? w + 1 : w] |= 1ull;
+                  }
+                }
+                else
+                {
+                  bm[w] |= 1ull << (l + 1);
+                }
+              }
+            }
+          }
+        }
+        if (lane == 0)
+        {
+          atomicAdd(&P.counters[kCntRepair], repairs);
+        }
+      }
+      __syncthreads();
+    }
   }
   HRFD_STAMP(3)
-  __syncthreads();
   HRFD_STAMP(4)
   if (tid == 0)
   {
     // cross-block check values: position -645 precedes every history sample the
-    // integer stages read (-644) and lies in tile 1.
+    // integer stages read (-644); a block that re-derived its history computed it in tile wt + M.
     const int chk = -kHist + 59;
-    P.chk_spec[unit] = first ? 0.0f : u2f(lds[chk + hal]);
-    P.chk_pub[unit] = u2f(lds[n256 + chk + hal]);
+    const float pub = u2f(lds[n256 + chk + hal]);
+    P.chk_spec[unit] = first ? 0.0f : (cont ? chk_prev : u2f(lds[chk + hal]));
+    P.chk_pub[unit] = pub;
+    chk_prev = pub;
+    if (b + 1 < b_end)
+    {
+      yanchor = u2f(lds[n256 + (origin + j0 * T) - W - 1 + hal]);   // the next block's y[s_j0 - W - 1]
+    }
   }
 
   if (ablate(P, 4))                                     // TIMING EXPERIMENT ONLY: skip phase C
@@ -1356,7 +1490,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   // ----------------------------------------------------------------- phase C
   // C1: s[n] = (int16_t)y[n] (WbFmDemodulator.cc:476), repacked in place as
   // int16 pairs at the bottom of the buffer: all reads, barrier, all writes.
-  const int smin = first ? 0 : -kHist;
+  const bool carried = first || cont;                    // the integer stages' histories are carried, not re-derived
+  const int smin = carried ? 0 : -kHist;
   const int npairs = (n256 - smin) >> 1;
   uint32_t packed[kPairsPerThread];
 #pragma unroll
@@ -1391,27 +1526,30 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   }
   uint16_t *U16 = reinterpret_cast<uint16_t *>(lds + kUOff);
   uint16_t *V16 = reinterpret_cast<uint16_t *>(lds + kVOff);
-  if (first)
+  if (carried)
   {
-    // histories of the three integer stages from the carried state
+    // histories of the three integer stages: from the carried state, or from the previous block of the run
+    const int16_t *hs = first ? st->wb_s : ctail;
+    const int16_t *hu = first ? st->wb_u : ctail + kWbS;
+    const int16_t *hv = first ? st->wb_v : ctail + kWbS + kWbU;
     if (tid < kWbS / 2)
     {
-      lds[((kHist - kWbS) >> 1) + tid] = reinterpret_cast<const uint32_t *>(st->wb_s)[tid];
+      lds[((kHist - kWbS) >> 1) + tid] = reinterpret_cast<const uint32_t *>(hs)[tid];
     }
     if (tid < kWbU)
     {
-      U16[kUHist - kWbU + tid] = (uint16_t)st->wb_u[tid];
+      U16[kUHist - kWbU + tid] = (uint16_t)hu[tid];
     }
     if (tid < kWbV)
     {
-      V16[kVHist - kWbV + tid] = (uint16_t)st->wb_v[tid];
+      V16[kVHist - kWbV + tid] = (uint16_t)hv[tid];
     }
   }
   __syncthreads();
 
   // C2: U[m] = D(8,4)(S), WbFmDemodulator.cc:468-472; two outputs per thread
   {
-    const int mmin = first ? 0 : -kUHist;
+    const int mmin = carried ? 0 : -kUHist;
     const int nU = (n256 >> 2) - mmin;
     for (int q = tid; q < (nU >> 1); q += kThreads)
     {
@@ -1437,12 +1575,12 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   __syncthreads();
 
   // C3: V[k] = D(12,4)(U);  C4: PCM[p] = D(40,2)(V)
-  stage_d12(lds, first ? 0 : -kVHist, n256 >> 4, tid);
+  stage_d12(lds, carried ? 0 : -kVHist, n256 >> 4, tid);
   __syncthreads();
   stage_d40(lds, n256 >> 5, reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)(n256 >> 5)), tid);
 
   HRFD_STAMP(5)
-  // carried histories for the next call
+  // carried histories: for the next call, and for the next block of the run
   if (last)
   {
     if (tid < kWbS / 2)
@@ -1456,6 +1594,21 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
     if (tid < kWbV)
     {
       so->wb_v[tid] = (int16_t)V16[kVHist + (n256 >> 4) - kWbV + tid];
+    }
+  }
+  if (b + 1 < b_end)
+  {
+    if (tid < kWbS / 2)
+    {
+      reinterpret_cast<uint32_t *>(ctail)[tid] = lds[((n256 + kHist - kWbS) >> 1) + tid];
+    }
+    if (tid < kWbU)
+    {
+      ctail[kWbS + tid] = (int16_t)U16[kUHist + (n256 >> 2) - kWbU + tid];
+    }
+    if (tid < kWbV)
+    {
+      ctail[kWbS + kWbU + tid] = (int16_t)V16[kVHist + (n256 >> 4) - kWbV + tid];
     }
   }
   }  // blocks of the run
