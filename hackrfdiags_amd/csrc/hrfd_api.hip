@@ -191,6 +191,7 @@ struct hrfd_rx
   int warm = kWarm;
   int stagger = 4;
   int run_len = 0;                     // test hook: blocks per workgroup run of k_rx_wbfm (0 = automatic)
+  int use_stream = 1;                  // test hook: 0 = batches use k_rx_wbfm instead of k_rx_wbfm_stream
   uint32_t last_counters[kNumCounters] = {0};
 };
 
@@ -510,9 +511,9 @@ extern "C" int hrfd_rx_debug_stamps(hrfd_rx *h, uint32_t cap_groups, unsigned lo
   }
   if (cap_groups > 0)
   {
-    HIP_TRY(hipMalloc((void **)&h->d_dbg, (size_t)cap_groups * 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->d_dbg, 0, (size_t)cap_groups * 8 * sizeof(unsigned long long)));
-    h->dbg_cap = (size_t)cap_groups * 8;
+    HIP_TRY(hipMalloc((void **)&h->d_dbg, (size_t)cap_groups * kDbgSlots * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_dbg, 0, (size_t)cap_groups * kDbgSlots * sizeof(unsigned long long)));
+    h->dbg_cap = (size_t)cap_groups * kDbgSlots;
   }
   return HRFD_OK;
 }
@@ -525,6 +526,18 @@ extern "C" int hrfd_rx_debug_set_run_len(hrfd_rx *h, int blocks)
     return fail(HRFD_EINVAL, "hrfd_rx_debug_set_run_len: 0..64");
   }
   h->run_len = blocks;
+  return HRFD_OK;
+}
+
+// test hook: 0 = WBFM batches run on k_rx_wbfm (phases in sequence, two workgroups per CU) instead of
+// k_rx_wbfm_stream (one workgroup per CU, phases overlapped)
+extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL");
+  }
+  h->use_stream = on ? 1 : 0;
   return HRFD_OK;
 }
 
@@ -780,12 +793,14 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     P.chan_list = h->d_lists + (size_t)m * h->n_channels;
     P.n_list = n;
     // runs of consecutive blocks per workgroup (only a run's first block re-produces the history
-    // in front of it): as long as possible while the launch still fills both workgroup slots of
-    // every CU
+    // in front of it): as long as possible while the launch still fills the chip --
+    // k_rx_wbfm_stream holds one workgroup per CU (256), k_rx_wbfm two (512)
     const uint32_t groups = 8u * ((n + 7u) / 8u);
-    uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : 8u;
+    const bool streaming = (m == HRFD_MODE_WBFM) && h->use_stream && n_blocks > 1 && !opt.serial && !opt.src256;
+    const uint32_t fill = streaming ? 256u : 512u;
+    uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : (streaming ? 16u : 8u);
     run_len = std::min(run_len, n_blocks);
-    while (h->run_len <= 0 && run_len > 1 && groups * ((n_blocks + run_len - 1) / run_len) < 512u)
+    while (h->run_len <= 0 && run_len > 1 && groups * ((n_blocks + run_len - 1) / run_len) < fill)
     {
       run_len--;
     }
@@ -796,7 +811,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     P.run_len = run_len;
     P.n_runs = (n_blocks + run_len - 1) / run_len;
     const uint32_t grid = groups * P.n_runs;
-    P.dbg = (h->d_dbg != nullptr && (size_t)grid * 8 <= h->dbg_cap && m == HRFD_MODE_WBFM) ? h->d_dbg : nullptr;
+    P.dbg = (h->d_dbg != nullptr && (size_t)grid * kDbgSlots <= h->dbg_cap && m == HRFD_MODE_WBFM) ? h->d_dbg : nullptr;
     if (m == HRFD_MODE_NONE)
     {
       hipLaunchKernelGGL((k_rx_wbfm<0, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
@@ -806,6 +821,17 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       if (opt.src256)
       {
         hipLaunchKernelGGL((k_rx_wbfm<3, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else if (streaming)
+      {
+        if (h->arith_ok && h->atan_mode != 0)
+        {
+          hipLaunchKernelGGL((k_rx_wbfm_stream<true>), dim3(grid), dim3(kThreads), 0, s, P);
+        }
+        else
+        {
+          hipLaunchKernelGGL((k_rx_wbfm_stream<false>), dim3(grid), dim3(kThreads), 0, s, P);
+        }
       }
       else if (h->arith_ok && h->atan_mode != 0)
       {

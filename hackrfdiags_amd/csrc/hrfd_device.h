@@ -12,9 +12,15 @@ namespace hrfd {
 // samples of the 256 kS/s stream.  For blocks after the first of a call the
 // workgroup also re-derives `hal` samples of history from the tail of the
 // previous block's raw input (time-parallelism along one channel).
-constexpr int kThreads = 1024;                // 16 wave64 per workgroup (2 workgroups = 32 waves per CU)
+#ifndef HRFD_THREADS
+#define HRFD_THREADS 1024
+#endif
+#ifndef HRFD_MAXN256
+#define HRFD_MAXN256 16384
+#endif
+constexpr int kThreads = HRFD_THREADS;        // 16 wave64 per workgroup (2 workgroups = 32 waves per CU)
 constexpr int kWaves = kThreads / 64;
-constexpr int kMaxN256 = 16384;               // 262144-byte block
+constexpr int kMaxN256 = HRFD_MAXN256;        // 262144-byte block
 // de-emphasis recurrence (phase B of k_rx_wbfm): the block is cut into tiles of kTile samples,
 // one per lane of the first four waves.  A lane starts kWarmTiles tiles early from an
 // APPROXIMATE y (a truncated geometric sum over kSeedTerms tiles, "seed") and is verified
@@ -128,7 +134,7 @@ struct RxParams
   float *chk_pub;              // [C][n_blocks] y at (n256 - kHist + 59) of this block
   float *chk_spec;             // [C][n_blocks] y at (-kHist + 59) as speculated by this block
   uint32_t *counters;          // kCnt*
-  unsigned long long *dbg;     // optional [grid][8] s_memtime stamps at phase boundaries (diagnostic builds of bench only)
+  unsigned long long *dbg;     // optional [grid][kDbgSlots] s_memtime stamps at phase boundaries (diagnostic builds of bench only)
 };
 
 struct EpilogueParams
@@ -161,6 +167,7 @@ constexpr int kNumCounters = 8;   // counters visible through hrfd_rx_debug_coun
 constexpr int kCntPoison = 8;     // sticky: a launch was not committed and the host has not repaired it yet --
                                   // later launches must not commit either (pipelined submission, hrfd_ingest_*)
 constexpr int kNumDevCounters = 10;
+constexpr int kDbgSlots = 32;      // RxParams::dbg: per workgroup 0..5 phase stamps of thread 0, 6 placement, 8..23 end of phase A per wave, 24..27 end of the recurrence per wave
 
 } // namespace hrfd
 

@@ -278,9 +278,9 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
       }
     }
     __syncthreads();
-    stage_d12(lds, first ? 0 : -kVHist, n16, tid);
+    stage_d12(lds + kUOff, lds + kVOff, first ? 0 : -kVHist, n16, tid);
     __syncthreads();
-    stage_d40(lds, n8, reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)n8), tid);
+    stage_d40(lds + kVOff, n8, reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)n8), tid);
     if (last)
     {
       if (tid < kWbU)

@@ -407,7 +407,7 @@ constexpr int kPairsPerThread = ((kMaxN256 + kHist) / 2 + kThreads - 1) / kThrea
 // front, V (16 kS/s) at kVOff with kVHist; both tables are the reference's
 // postDemodDecimator2 / audioDecimator (WbFmDemodulator.cc:28-86 ==
 // FmDemodulator.cc:53-111).
-constexpr int kUOff = 8576;                                   // dword offset of U (16-B aligned)
+constexpr int kUOff = (kSDwords + 31) / 32 * 32;               // dword offset of U (16-B aligned): 8576
 constexpr int kUHist = 160;
 constexpr int kVOff = kUOff + (kMaxN256 / 4 + kUHist) / 2;    // 10704
 constexpr int kVHist = 38;
@@ -415,14 +415,16 @@ static_assert(kVOff + (kMaxN256 / 16 + kVHist) / 2 + 1 <= kMaxNV, "LDS map");
 static_assert(kSDwords <= kUOff && (kUOff % 4) == 0, "LDS map");
 
 // V[k] = D(12,4)(U) for k in [kmin, n16); kmin even; two outputs per thread
-__device__ __forceinline__ void stage_d12(uint32_t *lds, const int kmin, const int n16, const int tid)
+// (ubase / vbase: dword pointers to U[-kUHist] and V[-kVHist]; nthreads threads take part)
+__device__ __forceinline__ void stage_d12(const uint32_t *ubase, uint32_t *vbase, const int kmin, const int n16,
+                                          const int tid, const int nthreads = kThreads)
 {
   const int nV = n16 - kmin;
-  for (int q = tid; q < (nV >> 1); q += kThreads)
+  for (int q = tid; q < (nV >> 1); q += nthreads)
   {
     const int k = kmin + 2 * q;
     // U[4k-8 .. 4k+7] -> 8 dwords from (4k - 8 + kUHist)/2
-    const uint32_t *up = lds + kUOff + ((4 * k - 8 + kUHist) >> 1);
+    const uint32_t *up = ubase + ((4 * k - 8 + kUHist) >> 1);
     uint32_t u[8];
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -439,18 +441,19 @@ __device__ __forceinline__ void stage_d12(uint32_t *lds, const int kmin, const i
       acc1 = dot2(u[j + 2], kRevD12.p[j], acc1);
     }
     const uint32_t w = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
-    lds[kVOff + ((k + kVHist) >> 1)] = w;
+    vbase[(k + kVHist) >> 1] = w;
   }
 }
 
 // PCM[p] = D(40,2)(V) for p in [0, nP); two outputs per thread, one packed store
-__device__ __forceinline__ void stage_d40(const uint32_t *lds, const int nP, uint32_t *pcm32, const int tid)
+__device__ __forceinline__ void stage_d40(const uint32_t *vbase, const int nP, uint32_t *pcm32, const int tid,
+                                          const int nthreads = kThreads)
 {
-  for (int q = tid; q < (nP >> 1); q += kThreads)
+  for (int q = tid; q < (nP >> 1); q += nthreads)
   {
     const int p = 2 * q;
     // V[2p-38 .. 2p+3] -> 21 dwords from (2p - 38 + kVHist)/2 = p
-    const uint32_t *vq = lds + kVOff + p;
+    const uint32_t *vq = vbase + p;
     int acc0 = 1 << 14, acc1 = 1 << 14;
     uint32_t prev = vq[0];
 #pragma unroll
@@ -573,19 +576,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // offset is a constant VGPR, the chunk offset a scalar, so a load costs no
 // vector ALU work; reads past the end of the channel's input return zeros.
 template <bool S256>
-__device__ __forceinline__ uint4 load_chunk(const StreamCtx &X, int chunk)
+__device__ __forceinline__ uint4 load_chunk(const StreamCtx &X, int chunk, int limit)
 {
+  // prefetches past the end of the run (chunk >= limit) are pointed outside the buffer: they
+  // return zeros without touching memory, and the pipeline needs no branch
+  const bool live = chunk < limit;
   if (S256)
   {
     // inner demodulator API: the stream is already at 256 kS/s, one (I,Q) byte pair per lane
-    const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 64 * chunk) * 2);
+    const uint32_t soff = live ? X.blk_off + (uint32_t)((X.vstart + 64 * chunk) * 2) : 0xfffff000u;
     const uint32_t w = __builtin_amdgcn_raw_buffer_load_b16(X.rsrc, X.lane * 2, soff, 0);
     return make_uint4(w, 0u, 0u, 0u);
   }
 #if (HRFD_ABLATE_EARLY & 128)
   return make_uint4(X.lane * 0x01010101u + chunk, X.lane * 0x3010501u, chunk * 0x10101u, X.lane ^ chunk);   // TIMING EXPERIMENT ONLY: no HBM reads
 #endif
-  const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 64 * chunk) * 16);
+  const uint32_t soff = live ? X.blk_off + (uint32_t)((X.vstart + 64 * chunk) * 16) : 0xfffff000u;
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, X.lane * 16, soff, HRFD_STREAM_AUX);
   return make_uint4(v.x, v.y, v.z, v.w);
 }
@@ -664,7 +670,7 @@ __device__ __forceinline__ void dispatch_residue(const int r, F &f, std::integer
   ((r == Rs ? (f(std::integral_constant<int, Rs>{}), 0) : 0), ...);
 }
 
-template <int MODE, bool REPAIR, bool DUMP, bool S256, bool ARITH = false>
+template <int MODE, bool REPAIR, bool DUMP, bool S256, bool ARITH = false, int DEPTH = kDepth, int FENCE = HRFD_SCHED_FENCE>
 __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0, const int c1,
                                                const int wlo, const int whi, uint32_t &magsum,
                                                uint32_t (&edge)[4])
@@ -795,7 +801,7 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
     // a run too short for the pipeline: one chunk at a time
     for (int j = 0; j < n; j++)
     {
-      const float t = front(load_chunk<S256>(X, cbeg + j), cbeg + j);
+      const float t = front(load_chunk<S256>(X, cbeg + j, c1), cbeg + j);
       if (MODE == 3)
       {
         finish(t, cbeg + j, j == 0 ? !lead : true);
@@ -817,13 +823,13 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   // compiler's s_waitcnt bookkeeping reaches the loop header with exactly the pending
   // loads the loop body leaves behind (a conditional prologue makes it drain the
   // pipeline once per loop iteration).
-  float th[kDepth];
-  uint4 q[kDepth];
-  // chunk j lives in slot (j - cbeg) % kDepth, both for its raw data and its theta
+  float th[DEPTH];
+  uint4 q[DEPTH];
+  // chunk j lives in slot (j - cbeg) % DEPTH, both for its raw data and its theta
 #pragma unroll
-  for (int k = 0; k < kDepth; k++)
+  for (int k = 0; k < DEPTH; k++)
   {
-    q[k] = load_chunk<S256>(X, cbeg + k);
+    q[k] = load_chunk<S256>(X, cbeg + k, c1);
     th[k] = 0.0f;
   }
   if (ARITH && !REPAIR && X.publish)
@@ -835,11 +841,11 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
   for (int k = 0; k < LOOK; k++)
   {
     th[k] = front(q[k], cbeg + k);
-    q[k] = load_chunk<S256>(X, cbeg + k + kDepth);
+    q[k] = load_chunk<S256>(X, cbeg + k + DEPTH, c1);
   }
   // first step, peeled: it yields the leading edge
-  th[LOOK % kDepth] = front(q[LOOK % kDepth], cbeg + LOOK);
-  q[LOOK % kDepth] = load_chunk<S256>(X, cbeg + LOOK + kDepth);
+  th[LOOK % DEPTH] = front(q[LOOK % DEPTH], cbeg + LOOK);
+  q[LOOK % DEPTH] = load_chunk<S256>(X, cbeg + LOOK + DEPTH, c1);
   if (MODE == 3)
   {
     finish(th[0], cbeg, !lead);
@@ -849,70 +855,68 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
       edge[1] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th[0]), 1);
     }
   }
-  // main loop: front chunk fr+k (slot (LOOK+1+k) % kDepth), finish chunk fr+k-LOOK
-  // (slot (1+k) % kDepth); branch-free groups of kDepth
+  // main loop: front chunk fr+k (slot (LOOK+1+k) % DEPTH), finish chunk fr+k-LOOK
+  // (slot (1+k) % DEPTH); branch-free groups of DEPTH
   int fr = cbeg + LOOK + 1;
-  for (; fr + kDepth <= c1; fr += kDepth)
+  for (; fr + DEPTH <= c1; fr += DEPTH)
   {
 #pragma unroll
-    for (int k = 0; k < kDepth; k++)
+    for (int k = 0; k < DEPTH; k++)
     {
-      const int sf = (LOOK + 1 + k) % kDepth;
+      const int sf = (LOOK + 1 + k) % DEPTH;
       th[sf] = front(q[sf], fr + k);
-      q[sf] = load_chunk<S256>(X, fr + k + kDepth);            // refill this slot
+      q[sf] = load_chunk<S256>(X, fr + k + DEPTH, c1);            // refill this slot
       if (MODE == 3)
       {
-        finish(th[(1 + k) % kDepth], fr + k - LOOK, true);
+        finish(th[(1 + k) % DEPTH], fr + k - LOOK, true);
       }
-#if HRFD_SCHED_FENCE
-      if ((k + 1) % HRFD_SCHED_FENCE == 0)
+      if (FENCE > 0 && (k + 1) % (FENCE > 0 ? FENCE : 1) == 0)
       // one chunk at a time: without the fence the scheduler hoists the front ends of all
-      // kDepth chunks to the top of the loop body, which needs every prefetched chunk at once
+      // DEPTH chunks to the top of the loop body, which needs every prefetched chunk at once
       // (s_waitcnt vmcnt(0)) and leaves the refills a few instructions of lead time
       {
         __builtin_amdgcn_sched_barrier(0);
       }
-#endif
     }
   }
-  // remainder: 0..kDepth-1 more fronts, each with its finish
+  // remainder: 0..DEPTH-1 more fronts, each with its finish
 #pragma unroll
-  for (int k = 0; k < kDepth - 1; k++)
+  for (int k = 0; k < DEPTH - 1; k++)
   {
     if (fr + k < c1)
     {
-      const int sf = (LOOK + 1 + k) % kDepth;
+      const int sf = (LOOK + 1 + k) % DEPTH;
       th[sf] = front(q[sf], fr + k);
       if (MODE == 3)
       {
-        finish(th[(1 + k) % kDepth], fr + k - LOOK, true);
+        finish(th[(1 + k) % DEPTH], fr + k - LOOK, true);
       }
     }
   }
   // drain: the last min(LOOK, n-1) chunks are fronted but not finished.  Their slots depend
-  // on n mod kDepth; one specialisation per residue keeps every slot index a constant (a
+  // on n mod DEPTH; one specialisation per residue keeps every slot index a constant (a
   // run-time select chain makes the compiler spill th[] to scratch).
   auto drain = [&](auto residue) {
-    constexpr int R = decltype(residue)::value;          // n % kDepth
+    constexpr int R = decltype(residue)::value;          // n % DEPTH
 #pragma unroll
     for (int d = LOOK; d >= 1; d--)
     {
       if (n - d >= 1)
       {
-        finish(th[(R - d + 2 * kDepth) % kDepth], c1 - d, true);
+        finish(th[(R - d + 2 * DEPTH) % DEPTH], c1 - d, true);
       }
     }
     if (!REPAIR)
     {
-      const float th_last = th[(R - 1 + kDepth) % kDepth];
+      const float th_last = th[(R - 1 + DEPTH) % DEPTH];
       edge[2] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last), 62);
       edge[3] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last), 63);
     }
   };
   if (MODE == 3)
   {
-    const int res = n % kDepth;
-    dispatch_residue(res, drain, std::make_integer_sequence<int, kDepth>{});
+    const int res = n % DEPTH;
+    dispatch_residue(res, drain, std::make_integer_sequence<int, DEPTH>{});
   }
 }
 
@@ -1128,7 +1132,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 #define HRFD_STAMP(i)                                                         \
   if (P.dbg != nullptr && tid == 0)                                           \
   {                                                                           \
-    P.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();       \
+    P.dbg[(size_t)blockIdx.x * kDbgSlots + (i)] = __builtin_readcyclecounter();       \
   }
   HRFD_STAMP(0)
   if (P.dbg != nullptr && tid == 0)
@@ -1136,7 +1140,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
     // where did the dispatcher put this workgroup?  HW_REG_HW_ID (4), HW_REG_XCC_ID (20)
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
     const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
-    P.dbg[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)xcc << 32) | hw;
+    P.dbg[(size_t)blockIdx.x * kDbgSlots + 6] = ((unsigned long long)xcc << 32) | hw;
   }
   // ----------------------------------------------------------------- phase A
   // the block's chunks, dealt to the waves as contiguous, balanced runs
@@ -1162,6 +1166,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   }
 
   HRFD_STAMP(1)
+  if (P.dbg != nullptr && lane == 0)
+  {
+    P.dbg[(size_t)blockIdx.x * kDbgSlots + 8 + wave] = __builtin_readcyclecounter();
+  }
   // block-mean magnitude: wave reduce, then across waves
   for (int off = 32; off > 0; off >>= 1)
   {
@@ -1374,6 +1382,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
       if (lane == 63)
       {
         wfin[wave] = y;
+        if (P.dbg != nullptr)
+        {
+          P.dbg[(size_t)blockIdx.x * kDbgSlots + 24 + wave] = __builtin_readcyclecounter();
+        }
       }
     }
     __syncthreads();                                     // all chains done
@@ -1575,9 +1587,9 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   __syncthreads();
 
   // C3: V[k] = D(12,4)(U);  C4: PCM[p] = D(40,2)(V)
-  stage_d12(lds, carried ? 0 : -kVHist, n256 >> 4, tid);
+  stage_d12(lds + kUOff, lds + kVOff, carried ? 0 : -kVHist, n256 >> 4, tid);
   __syncthreads();
-  stage_d40(lds, n256 >> 5, reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)(n256 >> 5)), tid);
+  stage_d40(lds + kVOff, n256 >> 5, reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)(n256 >> 5)), tid);
 
   HRFD_STAMP(5)
   // carried histories: for the next call, and for the next block of the run
@@ -1613,6 +1625,602 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   }
   }  // blocks of the run
 }
+
+// =============================================================================
+//  WBFM, batches (n_blocks > 1): one persistent workgroup per CU, phases overlapped
+// =============================================================================
+// k_rx_wbfm above runs the phases of a block one after the other, and the two workgroups of a
+// CU overlap them only by luck of the wave arbiter (measured: a second workgroup per CU buys
+// 12 %).  Here ONE workgroup owns the CU, keeps TWO blocks in its 160 KB of LDS and splits
+// its waves by role:
+//   waves 4..15 ("stream")   phase A of block b + 1: raw IQ -> v, into the other buffer
+//   waves 0..3  ("service")  phase B (the recurrence, one wave per SIMD) and phase C (the
+//                            integer stages) of block b
+// with one workgroup barrier per block.  The service waves synchronise among themselves with
+// a monotonic LDS counter (svc_barrier): the hardware barrier spans the whole workgroup.
+// Four waves per SIMD leave 128 VGPRs per wave.  Arithmetic, tiles, seeds, verification and
+// the cross-block checks are those of k_rx_wbfm; a run's first block (the one that may have
+// to re-derive kMaxHal samples of history) always lands in buffer 0.
+constexpr int kSvcWaves = kBWaves;
+constexpr int kStreamWaves = kWaves - kSvcWaves;
+constexpr int kSvcThreads = 64 * kSvcWaves;
+constexpr int kHoff0 = kMaxHal;                          // index of position 0 in buffer 0 / buffer 1
+constexpr int kHoff1 = (kKeepMax + 63) / 64 * 64;
+// The stream waves do not get equal shares of a block: the wave arbiter serves the oldest wave of a
+// SIMD first, so equal shares finish as a staircase and the youngest wave ends alone (measured:
+// 54 / 72 / 91 % busy).  They take runs of kRunChunks chunks from an LDS counter instead.
+#ifndef HRFD_STREAM_DEPTH
+#define HRFD_STREAM_DEPTH 8
+#endif
+#ifndef HRFD_STREAM_FENCE
+#define HRFD_STREAM_FENCE 2
+#endif
+constexpr int kStreamDepth = HRFD_STREAM_DEPTH;          // raw chunks in flight per stream wave (128 VGPRs per wave)
+constexpr int kStreamFence = HRFD_STREAM_FENCE;          // chunks the scheduler may interleave
+#ifndef HRFD_RUN_CHUNKS
+#define HRFD_RUN_CHUNKS 6
+#endif
+constexpr int kRunChunks = HRFD_RUN_CHUNKS;
+constexpr int kMaxRuns = 64;                             // one lane of wave 0 patches each run boundary
+static_assert((kMaxN256 + kMaxHal) / 64 <= kRunChunks * kMaxRuns, "runs per block");
+
+__device__ __forceinline__ void svc_barrier(uint32_t *ctr, uint32_t &target, const int lane)
+{
+  target += (uint32_t)kSvcWaves;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0)
+  {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+  {
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ uint32_t pack_s16(float lo, float hi)
+{
+  return ((uint32_t)f2i16(lo) & 0xffffu) | ((uint32_t)f2i16(hi) << 16);
+}
+
+template <bool ARITH>
+__global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t buf0[kHoff0 + kMaxN256];
+  __shared__ __attribute__((aligned(16))) uint32_t buf1[kHoff1 + kMaxN256];
+  __shared__ __attribute__((aligned(16))) uint8_t atcorr[ARITH ? kCorrBytes : 16];
+  __shared__ __attribute__((aligned(16))) float atinv[ARITH ? kInvEntries : 4];
+  __shared__ __attribute__((aligned(16))) uint32_t ubuf[(kMaxN256 / 4 + kUHist) / 2];       // U[-kUHist ..)
+  __shared__ __attribute__((aligned(16))) uint32_t vbuf[(kMaxN256 / 16 + kVHist) / 2 + 1];  // V[-kVHist ..)
+  __shared__ uint32_t red[2][kWaves];
+  __shared__ int8_t dbfs8[128];
+  __shared__ float tailcarry[2];
+  __shared__ uint32_t edges[2][kMaxRuns][4];
+  __shared__ uint32_t grab[2];          // next run of the block being streamed into buffer 0 / 1
+  __shared__ float parr[kMaxTiles + 8];
+  __shared__ float wfin[kBWaves];
+  __shared__ unsigned long long badmask[kBWaves];
+  __shared__ uint32_t anybad, svc_ctr;
+  __shared__ float yanchor, chk_prev;
+  __shared__ __attribute__((aligned(4))) int16_t ctail[kWbS + kWbU + kWbV + 2];
+  static_assert(sizeof(uint32_t) * (kHoff0 + kHoff1 + 2 * kMaxN256) + kCorrBytes + sizeof(float) * kInvEntries +
+                        sizeof(uint32_t) * ((kMaxN256 / 4 + kUHist) / 2 + (kMaxN256 / 16 + kVHist) / 2 + 1) + 3960 <= 163840,
+                "one workgroup per CU: 160 KiB of LDS");
+
+  uint32_t ci, run;
+  if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
+  {
+    return;
+  }
+  const uint32_t c = P.chan_list[ci];
+  const int n256 = (int)P.n256;
+  const uint32_t b_first = run * P.run_len;
+  const uint32_t b_end = min(P.n_blocks, b_first + P.run_len);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool svc = wave < kSvcWaves;
+
+  // the atan2 tables and the dBFS table go to LDS once
+  if (ARITH)
+  {
+    if (tid < kCorrBytes / 16)
+    {
+      reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr)[tid];
+    }
+    else if (tid < kCorrBytes / 16 + kInvEntries / 4)
+    {
+      reinterpret_cast<uint4 *>(atinv)[tid - kCorrBytes / 16] = reinterpret_cast<const uint4 *>(P.at_inv)[tid - kCorrBytes / 16];
+    }
+  }
+  if (tid >= 640 && tid < 768)
+  {
+    dbfs8[tid - 640] = (int8_t)P.dbfs[tid - 640];
+  }
+  if (tid == 0)
+  {
+    svc_ctr = 0u;
+    anybad = 0u;
+    grab[0] = 0u;
+  }
+  __syncthreads();
+
+  const int hal = P.hal;
+  constexpr int T = kTile;
+  const int wt = P.warm_tiles, M = P.seed_terms;
+  const int W = wt * T;
+  const int nkeep = (wt + M + 1) * T;
+  const int ntiles = P.ntiles, origin = P.origin;
+  const int j0 = (-origin) / T;
+  const ChanState *st = P.state + c;
+  ChanState *so = P.state_out + c;
+  const ChanCfg cfg = P.cfg[c];
+  float kgain = cfg.gain_wbfm / 75000.0f;                // K = (gain/75000)*32767 in float, that order
+  kgain = kgain * 32767.0f;
+  const float a1 = DEEMPH_A1;
+  uint32_t svc_target = 0;
+  // diagnostics (hrfd_rx_debug_stamps): cycles each wave spent working (not waiting at the block barrier)
+  unsigned long long busy = 0, t_enter = 0;
+  const unsigned long long t_kernel = __builtin_readcyclecounter();
+
+  // everything a (re)production of v needs; `bsel` is the block's buffer
+  auto make_ctx = [&](const uint32_t b, uint32_t *lds, const int hoff) {
+    StreamCtx X;
+    X.P = &P;
+    X.rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int8_t *>(P.iq + (uint64_t)c * P.ch_stride), 0,
+        (int)(P.n_blocks * P.block_bytes), 0x00020000);
+    X.blk_off = b * P.block_bytes;
+    X.st = st;
+    X.lds = lds;
+    X.ounit = (size_t)c * P.out_blocks + P.out_b0 + b;
+    X.kgain = kgain;
+    X.hal = hoff;
+    X.vstart = (b == 0 || b > b_first) ? 0 : -hal;
+    X.n256 = n256;
+    X.lane = lane;
+    X.qoff = 0;
+    X.first = (b == 0);
+    X.atc = atcorr;
+    X.ati = atinv;
+    X.tab = make_uint4(0u, 0u, 0u, 0u);
+    X.publish = false;
+    return X;
+  };
+
+  for (uint32_t step = b_first; step <= b_end; step++)
+  {
+    t_enter = __builtin_readcyclecounter();
+    if (tid == 0)
+    {
+      grab[(step + 1 - b_first) & 1u] = 0u;              // the next step's counter: idle since the barrier before last
+    }
+    if (svc && step > b_first)
+    {
+      // --------------------------------------------------------------- service: phases B and C of block `step - 1`
+      const uint32_t b = step - 1;
+      const int bi = (int)((b - b_first) & 1u);
+      uint32_t *lds = bi ? buf1 : buf0;
+      const int hoff = bi ? kHoff1 : kHoff0;
+      const bool first = (b == 0);
+      const bool cont = (b > b_first);
+      const bool last = (b + 1 == P.n_blocks);
+      const size_t unit = (size_t)c * P.n_blocks + b;
+      const StreamCtx X = make_ctx(b, lds, hoff);
+      const int fa = (first || cont) ? j0 : (wt + M);
+      const int nch = (n256 - X.vstart) >> 6;
+      if (wave == 0)
+      {
+        // the two provisional samples at the start of every run (see k_rx_wbfm)
+        const int nruns = (nch + kRunChunks - 1) / kRunChunks;
+        if (cont && lane == 0)
+        {
+          const float tm1 = tailcarry[0], pm1 = tailcarry[1];
+          const float t0 = u2f(edges[bi][0][0]), t1 = u2f(edges[bi][0][1]);
+          const float p0 = numerator_p(t0, tm1, kgain);
+          const float p1 = numerator_p(t1, t0, kgain);
+          lds[0 + hoff] = f2u(p0 + pm1);
+          lds[1 + hoff] = f2u(p1 + p0);
+        }
+        if (lane >= 1 && lane < nruns)
+        {
+          const int w = lane;
+          const int sw = X.vstart + 64 * kRunChunks * w;
+          const float tm2 = u2f(edges[bi][w - 1][2]), tm1 = u2f(edges[bi][w - 1][3]);
+          const float t0 = u2f(edges[bi][w][0]), t1 = u2f(edges[bi][w][1]);
+          const float pm1 = numerator_p(tm1, tm2, kgain);
+          const float p0 = numerator_p(t0, tm1, kgain);
+          const float p1 = numerator_p(t1, t0, kgain);
+          lds[sw + hoff] = f2u(p0 + pm1);
+          lds[sw + 1 + hoff] = f2u(p1 + p0);
+        }
+        if (lane == 0)
+        {
+          const float tl2 = u2f(edges[bi][nruns - 1][2]), tl1 = u2f(edges[bi][nruns - 1][3]);
+          tailcarry[0] = tl1;
+          tailcarry[1] = numerator_p(tl1, tl2, kgain);
+          anybad = 0u;
+        }
+      }
+      svc_barrier(&svc_ctr, svc_target, lane);           // v is complete
+      if (b + 1 < b_end)
+      {
+        // the next block of the run continues from this one: its history slot gets the tail of v
+        // (the chains below, behind the next barrier, overwrite it with y)
+        uint32_t *nl = bi ? buf0 : buf1;
+        const int nh = bi ? kHoff0 : kHoff1;
+        for (int i = tid; i < nkeep; i += kSvcThreads)
+        {
+          nl[nh - nkeep + i] = lds[n256 - nkeep + i + hoff];
+        }
+      }
+      const int ti = tid;                                // this lane's tile
+      const int s = origin + ti * T;
+      float y = 0.0f, y_spec = 0.0f;
+      bool active = false;
+      // B1: partial sums (k_rx_wbfm); tiles that lie in front of this buffer's history slot are never needed
+      if (M > 0 && ti < ntiles && s + hoff >= 0)
+      {
+        const float cc = -a1;
+        const float c2 = cc * cc;
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(lds + (s + hoff));
+        float pa = 0.0f, pb = 0.0f;
+#pragma unroll 7
+        for (int j = 0; j < T / 2; j++)
+        {
+          const uint2 w = p2[j];
+          pa = __builtin_fmaf(pa, c2, u2f(w.x));
+          pb = __builtin_fmaf(pb, c2, u2f(w.y));
+        }
+        float p = __builtin_fmaf(pa, cc, pb);
+        if (first && ti == j0)
+        {
+          p += deemph_pow(s + T) * st->wb_y;
+        }
+        parr[ti] = p;
+      }
+      svc_barrier(&svc_ctr, svc_target, lane);           // partial sums visible; the tail copy has read v
+      active = ti >= fa && ti < ntiles;
+      if (active)
+      {
+        if (M > 0)
+        {
+          float acc = 0.0f;
+          for (int m = M; m >= 1; m--)
+          {
+            acc = __builtin_fmaf(acc, P.seed_ct, parr[ti - wt - m]);
+          }
+          y = acc;
+        }
+        int kskip = 0;
+        if (first)
+        {
+          if (s <= W)
+          {
+            y = st->wb_y;
+            kskip = W - s;
+          }
+        }
+        else if (cont && ti == j0)
+        {
+          y = yanchor;
+        }
+        const uint32_t *vp = lds + (s - W + hoff);
+        uint32_t *yp = lds + (s + hoff);
+        if (first && wave == 0)
+        {
+          y = iir_run<false, true>(vp, nullptr, W, kskip, y);
+          y_spec = y;
+          y = iir_run<true, true>(yp, yp, T, kskip - W, y);
+        }
+        else
+        {
+          y = iir_run<false, false>(vp, nullptr, W, 0, y);
+          y_spec = y;
+          y = iir_run<true, false>(yp, yp, T, 0, y);
+        }
+        if (lane == 63)
+        {
+          wfin[wave] = y;
+        }
+      }
+      svc_barrier(&svc_ctr, svc_target, lane);           // all chains done
+      {
+        float y_left = u2f(shr1(f2u(y), f2u(y)));
+        if (lane == 0 && wave > 0)
+        {
+          y_left = wfin[wave - 1];
+        }
+        const bool bad = active && ti > fa && !same_trajectory(y_left, y_spec);
+        const unsigned long long bm = __ballot(bad);
+        if (lane == 0)
+        {
+          badmask[wave] = bm;
+          if (bm != 0ull)
+          {
+            anybad = 1u;
+          }
+        }
+      }
+      svc_barrier(&svc_ctr, svc_target, lane);
+      if (anybad != 0u)
+      {
+        if (ti < ntiles)
+        {
+          parr[ti] = y_spec;
+        }
+        svc_barrier(&svc_ctr, svc_target, lane);
+        if (wave == 0)
+        {
+          unsigned long long bm[kBWaves];
+#pragma unroll
+          for (int w = 0; w < kBWaves; w++)
+          {
+            bm[w] = badmask[w];
+          }
+          uint32_t repairs = 0;
+#pragma unroll
+          for (int w = 0; w < kBWaves; w++)
+          {
+            while (bm[w] != 0ull)
+            {
+              const int l = __ffsll((long long)bm[w]) - 1;
+              bm[w] &= ~(1ull << l);
+              repairs++;
+              const int j = w * 64 + l;
+              const int sj = origin + j * T;
+              const int rc0 = (sj - X.vstart) >> 6;
+              const int rc1 = (sj + T - X.vstart + 63) >> 6;
+              uint32_t dummy_mag = 0, dummy_e[4];
+              produce_stream<3, true, false, false, ARITH>(X, rc0, rc1, sj, sj + T, dummy_mag, dummy_e);
+              if (lane == 0)
+              {
+                uint32_t *rp = lds + (sj + hoff);
+                const float y_true = u2f(rp[-1]);
+                iir_run<true, false>(rp, rp, T, 0, y_true);
+              }
+              if (j + 1 < ntiles)
+              {
+                const float yj = u2f(lds[sj + T - 1 + hoff]);
+                const float sp = parr[j + 1];
+                if (!same_trajectory(yj, sp))
+                {
+                  if (l == 63)
+                  {
+                    if (w + 1 < kBWaves)
+                    {
+                      bm[w + 1 < kBWaves ? w + 1 : w] |= 1ull;
+                    }
+                  }
+                  else
+                  {
+                    bm[w] |= 1ull << (l + 1);
+                  }
+                }
+              }
+            }
+          }
+          if (lane == 0)
+          {
+            atomicAdd(&P.counters[kCntRepair], repairs);
+          }
+        }
+        svc_barrier(&svc_ctr, svc_target, lane);
+      }
+      if (tid == 0)
+      {
+        const int chk = -kHist + 59;
+        const float pub = u2f(lds[n256 + chk + hoff]);
+        P.chk_spec[unit] = first ? 0.0f : (cont ? chk_prev : u2f(lds[chk + hoff]));
+        P.chk_pub[unit] = pub;
+        chk_prev = pub;
+        if (b + 1 < b_end)
+        {
+          yanchor = u2f(lds[n256 + (origin + j0 * T) - W - 1 + hoff]);
+        }
+      }
+      // ----------------------------------------------------------------- phase C on the service waves
+      // C1+C2 fused: U[m] = D(8,4)((int16_t)y), two outputs per thread straight from the float stream
+      // (WbFmDemodulator.cc:468-476); the integer stages' histories are carried (ctail / state)
+      // unless this block re-derived its history.
+      const bool carried = first || cont;
+      uint16_t *U16 = reinterpret_cast<uint16_t *>(ubuf);
+      uint16_t *V16 = reinterpret_cast<uint16_t *>(vbuf);
+      const int16_t *hs = first ? st->wb_s : ctail;
+      const int16_t *hu = first ? st->wb_u : ctail + kWbS;
+      const int16_t *hv = first ? st->wb_v : ctail + kWbS + kWbU;
+      if (carried)
+      {
+        if (tid < kWbU)
+        {
+          U16[kUHist - kWbU + tid] = (uint16_t)hu[tid];
+        }
+        if (tid >= 64 && tid < 64 + kWbV)
+        {
+          V16[kVHist - kWbV + tid - 64] = (uint16_t)hv[tid - 64];
+        }
+      }
+      {
+        const int mmin = carried ? 0 : -kUHist;
+        const int nq = ((n256 >> 2) - mmin) >> 1;
+        for (int q = tid; q < nq; q += kSvcThreads)
+        {
+          const int m = mmin + 2 * q;
+          // y[4m-4 .. 4m+7]: three 16-byte reads
+          const uint4 *yq = reinterpret_cast<const uint4 *>(lds + (4 * m - 4 + hoff));
+          const uint4 a = yq[0], bq = yq[1], cq = yq[2];
+          uint32_t s0 = pack_s16(u2f(a.x), u2f(a.y)), s1 = pack_s16(u2f(a.z), u2f(a.w));
+          const uint32_t s2 = pack_s16(u2f(bq.x), u2f(bq.y)), s3 = pack_s16(u2f(bq.z), u2f(bq.w));
+          const uint32_t s4 = pack_s16(u2f(cq.x), u2f(cq.y)), s5 = pack_s16(u2f(cq.z), u2f(cq.w));
+          if (carried && m == 0)
+          {
+            s0 = reinterpret_cast<const uint32_t *>(hs)[0];   // S[-4 .. -1]: the previous block's last samples
+            s1 = reinterpret_cast<const uint32_t *>(hs)[1];
+          }
+          int acc0 = 1 << 14, acc1 = 1 << 14;
+          acc0 = dot2(s0, kRevWbD1.p[0], acc0);
+          acc0 = dot2(s1, kRevWbD1.p[1], acc0);
+          acc0 = dot2(s2, kRevWbD1.p[2], acc0);
+          acc0 = dot2(s3, kRevWbD1.p[3], acc0);
+          acc1 = dot2(s2, kRevWbD1.p[0], acc1);
+          acc1 = dot2(s3, kRevWbD1.p[1], acc1);
+          acc1 = dot2(s4, kRevWbD1.p[2], acc1);
+          acc1 = dot2(s5, kRevWbD1.p[3], acc1);
+          ubuf[(m + kUHist) >> 1] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+        }
+      }
+      // the last four S samples and the last y, before anybody may overwrite anything
+      uint32_t stail = 0u;
+      if (tid < kWbS / 2)
+      {
+        stail = pack_s16(u2f(lds[n256 - kWbS + 2 * tid + hoff]), u2f(lds[n256 - kWbS + 2 * tid + 1 + hoff]));
+      }
+      svc_barrier(&svc_ctr, svc_target, lane);
+      stage_d12(ubuf, vbuf, carried ? 0 : -kVHist, n256 >> 4, tid, kSvcThreads);
+      svc_barrier(&svc_ctr, svc_target, lane);
+      stage_d40(vbuf, n256 >> 5, reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)(n256 >> 5)), tid, kSvcThreads);
+      // carried histories: for the next call, and for the next block of the run
+      if (last)
+      {
+        if (tid < kWbS / 2)
+        {
+          reinterpret_cast<uint32_t *>(so->wb_s)[tid] = stail;
+        }
+        if (tid < kWbU)
+        {
+          so->wb_u[tid] = (int16_t)U16[kUHist + (n256 >> 2) - kWbU + tid];
+        }
+        if (tid >= 64 && tid < 64 + kWbV)
+        {
+          so->wb_v[tid - 64] = (int16_t)V16[kVHist + (n256 >> 4) - kWbV + tid - 64];
+        }
+        if (tid == 128)
+        {
+          so->wb_y = u2f(lds[n256 - 1 + hoff]);
+          so->wb_theta = tailcarry[0];
+          so->wb_p = tailcarry[1];
+        }
+      }
+      if (b + 1 < b_end)
+      {
+        // (every read of ctail of this block lies before the two barriers above)
+        if (tid < kWbS / 2)
+        {
+          reinterpret_cast<uint32_t *>(ctail)[tid] = stail;
+        }
+        if (tid < kWbU)
+        {
+          ctail[kWbS + tid] = (int16_t)U16[kUHist + (n256 >> 2) - kWbU + tid];
+        }
+        if (tid >= 64 && tid < 64 + kWbV)
+        {
+          ctail[kWbS + kWbU + tid - 64] = (int16_t)V16[kVHist + (n256 >> 4) - kWbV + tid - 64];
+        }
+      }
+    }
+    {
+      if (step < b_end)
+      {
+        // ------------------------------------------------------------- stream: phase A of block `step`
+        // (every wave: the service waves join as soon as they are done with block `step - 1`)
+        const uint32_t b = step;
+        const int bi = (int)((b - b_first) & 1u);
+        uint32_t *lds = bi ? buf1 : buf0;
+        const int hoff = bi ? kHoff1 : kHoff0;
+        const int stid = tid - kSvcThreads;
+        if (b == 0 && stid >= 0 && stid < nkeep)
+        {
+          lds[hoff - nkeep + stid] = 0u;                 // nothing precedes the stream start: the seeds sum zeros
+        }
+        const StreamCtx X = make_ctx(b, lds, hoff);
+        const int nch = (n256 - X.vstart) >> 6;
+        uint32_t magsum = 0;
+        for (;;)
+        {
+          uint32_t g = 0;
+          if (lane == 0)
+          {
+            g = atomicAdd(&grab[bi], 1u);
+          }
+          g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+          const int c0 = (int)g * kRunChunks;
+          if (c0 >= nch)
+          {
+            break;
+          }
+          const int c1 = min(c0 + kRunChunks, nch);
+          uint32_t e[4] = {0u, 0u, 0u, 0u};
+          if (P.iq256 != nullptr)
+          {
+            produce_stream<3, false, true, false, ARITH, kStreamDepth, kStreamFence>(X, c0, c1, X.vstart, n256, magsum, e);
+          }
+          else
+          {
+            produce_stream<3, false, false, false, ARITH, kStreamDepth, kStreamFence>(X, c0, c1, X.vstart, n256, magsum, e);
+          }
+          if (lane < 4)
+          {
+            edges[bi][g][lane] = (lane == 0) ? e[0] : (lane == 1) ? e[1] : (lane == 2) ? e[2] : e[3];
+          }
+        }
+        for (int off = 32; off > 0; off >>= 1)
+        {
+          magsum += __shfl_down(magsum, off);
+        }
+        if (lane == 0)
+        {
+          red[bi][wave] = magsum;
+        }
+        if (b + 1 == P.n_blocks && stid >= 0 && stid < 4)
+        {
+          // front-end carry for the next call: the last 16 raw bytes of this block
+          const int8_t *blk = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)b * P.block_bytes;
+          reinterpret_cast<uint32_t *>(so->fe_tail)[stid] =
+              reinterpret_cast<const uint32_t *>(blk + P.block_bytes - 16)[stid];
+        }
+      }
+    }
+    busy += __builtin_readcyclecounter() - t_enter;
+    __syncthreads();
+    if (step < b_end)
+    {
+      // block `step` has been streamed: block-mean magnitude, squelch detector (k_rx_wbfm)
+      const uint32_t b = step;
+      const int bi = (int)((b - b_first) & 1u);
+      uint32_t total = 0;
+      for (int w = 0; w < kWaves; w++)
+      {
+        total += red[bi][w];
+      }
+      const uint32_t mean_mag = total / (uint32_t)n256;
+      int32_t dbfs = (int32_t)dbfs8[min(mean_mag, 127u)] - 42;
+      dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
+      const bool present = dbfs >= cfg.threshold;
+      const bool allowed = (b == 0) ? (present || st->tracking != 0) : true;
+      if (tid == 0)
+      {
+        P.magnitude[(size_t)c * P.out_blocks + P.out_b0 + b] = mean_mag;
+        P.present[(size_t)c * P.n_blocks + b] = present ? 1 : 0;
+      }
+      if (!allowed)
+      {
+        break;                                           // gate violation of a batch: not committed, replayed by the host
+      }
+    }
+  }
+  if (P.dbg != nullptr && lane == 0)
+  {
+    P.dbg[(size_t)blockIdx.x * kDbgSlots + 8 + wave] = busy;
+    if (tid == 0)
+    {
+      P.dbg[(size_t)blockIdx.x * kDbgSlots + 0] = __builtin_readcyclecounter() - t_kernel;
+    }
+  }
+}
+
+template __global__ void k_rx_wbfm_stream<false>(const RxParams);
+template __global__ void k_rx_wbfm_stream<true>(const RxParams);
 
 // =============================================================================
 //  epilogue: squelch tracker over the batch, verification of both speculations,

@@ -17,8 +17,8 @@ import numpy as np
 sys.path.insert(0, %r)
 import torch
 from hackrfdiags_amd import api
-BLK = 262144
-C, B = 256, 16
+BLK = int(os.environ.get('HRFD_BLK', '262144'))
+C, B = int(os.environ.get('HRFD_C', '256')), int(os.environ.get('HRFD_B', '16'))
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(1)
 x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev, generator=g)

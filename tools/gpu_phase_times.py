@@ -14,11 +14,11 @@ x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev)
 pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
 torch.cuda.synchronize()
 rx = api.Rx(C); rx.set_mode(api.WBFM); rx.debug_set_stagger(stag)
-if os.environ.get('HRFD_RUNLEN'):
-    rx.debug_set_run_len(int(os.environ['HRFD_RUNLEN']))
 if os.environ.get('HRFD_WARM'):
     rx.debug_set_warm(int(os.environ['HRFD_WARM']))
-grid = 8 * ((C + 7) // 8) * B
+RL = int(os.environ.get('HRFD_RUNLEN', '8'))
+rx.debug_set_run_len(RL)
+grid = 8 * ((C + 7) // 8) * ((B + RL - 1) // RL)   # one workgroup per run; the stamps are those of a run's LAST block
 for _ in range(3):
     rx.process_device(x.data_ptr(), B * BLK, BLK, B, pcm.data_ptr()); rx.sync()
 rx.debug_stamps(grid)
@@ -28,12 +28,17 @@ st = rx.debug_stamps(grid, read=True)
 ms = rx.debug_kernel_ms(0)
 hw = (st[:, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64); xcc = (st[:, 6] >> np.uint64(32)).astype(np.int64) & 0xF
 st = st.astype(np.int64)
-names = ["A: front end+LUT+v", "reduce+gate", "B: de-emphasis (wave0)", "barrier wait", "C: cvt+D8+D12+D40"]
+names = ["A: front end+atan2+v", "reduce+gate", "B: patch+seeds+chains+check", "-", "C: cvt+D8+D12+D40"]
 d = np.diff(st[:, :6], axis=1)
 print(f"kernel {ms:.3f} ms with stamps; grid {grid}; stagger {stag}")
 for i, n in enumerate(names):
     print(f"  {n:28s} mean {d[:, i].mean():9.0f}  p50 {np.median(d[:, i]):9.0f}  max {d[:, i].max():9.0f} cycles")
 print(f"  total per workgroup          mean {(st[:,5]-st[:,0]).mean():9.0f} cycles")
+wa = st[:, 8:24] - st[:, 0:1]
+print("  end of phase A per wave (mean cycles since block start):", np.round(wa.mean(axis=0)).astype(int).tolist())
+print("  slowest wave index histogram:", np.bincount(np.argmax(wa, axis=1), minlength=16).tolist())
+wb = st[:, 24:28] - st[:, 2:3]
+print("  end of recurrence per B-wave (mean cycles since B start):", np.round(wb.mean(axis=0)).astype(int).tolist())
 cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1
 key = xcc * 1000 + se * 100 + sh * 50 + cu
 print("  distinct (xcc,se,sh,cu):", len(np.unique(key)), " xcc of WG0..15:", xcc[:16].tolist())

@@ -47,16 +47,33 @@ KERNEL(k_dep_add, asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %0, %0, %4\n v_
 KERNEL(k_dep_mulf, asm volatile("v_mul_f32 %0, %0, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %0, %0, %4\n v_mul_f32 %0, %0, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
 KERNEL(k_dep_pk, asm volatile("v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %0, %0, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
 
+// literal operands (64-bit encodings of VOP2), scalar operands, and the other instruction kinds of the WBFM chunk loop
+KERNEL(k_add_lit, asm volatile("v_add_u32 %0, 0x12345678, %0\n v_add_u32 %1, 0x12345678, %1\n v_add_u32 %2, 0x12345678, %2\n v_add_u32 %3, 0x12345678, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+KERNEL(k_and_lit, asm volatile("v_and_b32 %0, 0x00ff00ff, %0\n v_and_b32 %1, 0x00ff00ff, %1\n v_and_b32 %2, 0x00ff00ff, %2\n v_and_b32 %3, 0x00ff00ff, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+KERNEL(k_add_sgpr, asm volatile("v_add_u32 %0, %4, %0\n v_add_u32 %1, %4, %1\n v_add_u32 %2, %4, %2\n v_add_u32 %3, %4, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(iters));)
+KERNEL(k_add_inline, asm volatile("v_add_u32 %0, 17, %0\n v_add_u32 %1, 17, %1\n v_add_u32 %2, 17, %2\n v_add_u32 %3, 17, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+KERNEL(k_fmaak, asm volatile("v_fmaak_f32 %0, %0, %4, 0x3d27d12b\n v_fmaak_f32 %1, %1, %4, 0x3d27d12b\n v_fmaak_f32 %2, %2, %4, 0x3d27d12b\n v_fmaak_f32 %3, %3, %4, 0x3d27d12b" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+KERNEL(k_fmac, asm volatile("v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %4, %5\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_fma_e64, asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_cndmask_vcc, asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "vcc");)
+KERNEL(k_cndmask_e64, asm volatile("v_cndmask_b32 %0, %0, %4, s[20:21]\n v_cndmask_b32 %1, %1, %4, s[20:21]\n v_cndmask_b32 %2, %2, %4, s[20:21]\n v_cndmask_b32 %3, %3, %4, s[20:21]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "s20", "s21");)
+KERNEL(k_bfe, asm volatile("v_bfe_i32 %0, %0, %4, 2\n v_bfe_i32 %1, %1, %4, 2\n v_bfe_i32 %2, %2, %4, 2\n v_bfe_i32 %3, %3, %4, 2" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+KERNEL(k_lerp, asm volatile("v_lerp_u8 %0, %0, %4, %5\n v_lerp_u8 %1, %1, %4, %5\n v_lerp_u8 %2, %2, %4, %5\n v_lerp_u8 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_cvt_f32_u32, asm volatile("v_cvt_f32_u32 %0, %0\n v_cvt_f32_u32 %1, %1\n v_cvt_f32_u32 %2, %2\n v_cvt_f32_u32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+KERNEL(k_lshr, asm volatile("v_lshrrev_b32 %0, 7, %0\n v_lshrrev_b32 %1, 7, %1\n v_lshrrev_b32 %2, 7, %2\n v_lshrrev_b32 %3, 7, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+KERNEL(k_mul_u24, asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+KERNEL(k_cmp_e32, asm volatile("v_cmp_gt_u32 vcc, %0, %4\n v_cmp_gt_u32 vcc, %1, %4\n v_cmp_gt_u32 vcc, %2, %4\n v_cmp_gt_u32 vcc, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "vcc");)
+KERNEL(k_xad, asm volatile("v_xad_u32 %0, %0, %4, %5\n v_xad_u32 %1, %1, %4, %5\n v_xad_u32 %2, %2, %4, %5\n v_xad_u32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+
 typedef void (*kern_t)(unsigned long long *, int);
 // grid = 512 workgroups of 1024 threads = 8 waves on every SIMD of the chip; wall clock by
 // HIP events -> ns per wave-instruction per SIMD (a SIMD16 at 2.4 GHz would give 1.67 ns)
-static void run(const char *name, kern_t k, int threads)
+static double run(kern_t k, int threads, int grid)
 {
   static unsigned long long h[16384];
   unsigned long long *d;
   hipMalloc(&d, sizeof(h));
   const int iters = 2000;
-  const int grid = (threads == 1024) ? 512 : 256;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(k, dim3(grid), dim3(threads), 0, 0, d, iters);
@@ -68,18 +85,24 @@ static void run(const char *name, kern_t k, int threads)
   hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
   double sum = 0, rsum = 0; int n = grid * (threads / 64);
   for (int i = 0; i < n; i++) { sum += (double)h[i]; rsum += (double)h[8192 + i]; }
-  const double per_wave = sum / n / (iters * 64.0);          // ticks per instruction as seen by one wave
   const double waves_per_simd = (double)grid * (threads / 64) / 1024.0;
   const double instr_per_simd = waves_per_simd * iters * 64.0;
-  printf("%-14s %4d thr/WG x %d: %6.2f ticks/instr/wave; wall %.3f ms -> %5.2f ns/instr/SIMD (%.2f cycles at 2.4 GHz); s_memtime/s_memrealtime = %.2f\n", name, threads, grid,
-         per_wave, ms, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4, sum / rsum);
+  const double ghz = sum / rsum * 0.1;                       // s_memtime ticks per 100 MHz s_memrealtime tick
   hipFree(d);
+  return ms * 1e6 / instr_per_simd * ghz;                    // shader cycles per wave64 instruction per SIMD
 }
-#define RUN(k) run(#k, k, 256); run(#k, k, 1024);
+static void run4(const char *name, kern_t k)
+{
+  printf("%-14s cycles per wave64 instruction per SIMD at 1 / 2 / 4 / 8 waves per SIMD: %5.2f %5.2f %5.2f %5.2f\n", name,
+         run(k, 256, 256), run(k, 512, 256), run(k, 1024, 256), run(k, 1024, 512));
+}
+#define RUN(k) run4(#k, k);
 int main()
 {
   RUN(k_add_u32) RUN(k_pk_add_u16) RUN(k_pk_mad_u16) RUN(k_pk_ashr) RUN(k_perm) RUN(k_dpp_shr) RUN(k_dpp_row)
   RUN(k_mad_u24) RUN(k_dot2) RUN(k_mul_f32) RUN(k_lshl_add) RUN(k_add3) RUN(k_sad_u8) RUN(k_add_sdwa)
   RUN(k_dep_add) RUN(k_dep_mulf) RUN(k_dep_pk)
+  RUN(k_add_lit) RUN(k_and_lit) RUN(k_add_sgpr) RUN(k_add_inline) RUN(k_fmaak) RUN(k_fmac) RUN(k_fma_e64) RUN(k_cndmask_vcc) RUN(k_cndmask_e64)
+  RUN(k_bfe) RUN(k_lerp) RUN(k_cvt_f32_u32) RUN(k_lshr) RUN(k_mul_u24) RUN(k_cmp_e32) RUN(k_xad)
   return 0;
 }
