@@ -372,7 +372,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic_bytes(args, C, B),
-                "kernel": ("hrfd::k_rx_wbfm<3, false, true> (arithmetic atan2)" if args.workload == "wbfm"
+                "kernel": ("hrfd::k_rx_wbfm_stream<true> (one workgroup per CU, arithmetic atan2)" if args.workload == "wbfm"
                            else "all demodulator kernels of a step"),
                 "kernel_ms_mean": round(mean_ms, 4),
                 "kernel_ms_min": round(float(np.min(kernel_ms)), 4),

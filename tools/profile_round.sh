@@ -26,7 +26,7 @@ acc=collections.defaultdict(list)
 for c in ("FETCH_SIZE","WRITE_SIZE"):
     for f in glob.glob(O+"/pmc_"+c+"/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_rx_wbfm<3" in r["Kernel_Name"] or "k_rx_wbfmILi3" in r["Kernel_Name"]:
+            if "k_rx_wbfm" in r["Kernel_Name"]:   # k_rx_wbfm_stream<..> (batches) or k_rx_wbfm<3,..>
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 summ={k:{"n":len(v),"mean":sum(v)/len(v)} for k,v in acc.items()}
 json.dump(summ, open(O+"/pmc_traffic.json","w"), indent=1)
