@@ -119,6 +119,14 @@ def load() -> C.CDLL:
     L.hrfd_mod_process.argtypes = [_vp, _vp, C.c_uint32, _vp, _u32p]
     L.hrfd_mod_process_device.argtypes = [_vp, _vp, C.c_uint32, _vp, _vp]
     L.hrfd_mod_sync.argtypes = [_vp]
+    L.hrfd_play_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(_vp)]
+    L.hrfd_play_destroy.argtypes = [_vp]
+    L.hrfd_play_load_file.argtypes = [_vp, C.c_char_p]
+    L.hrfd_play_load.argtypes = [_vp, _vp, C.c_uint32]
+    L.hrfd_play_set_position.argtypes = [_vp, C.c_uint32, C.c_uint32]
+    L.hrfd_play_get_position.argtypes = [_vp, C.c_uint32, _u32p]
+    L.hrfd_play_get_device.argtypes = [_vp, _vp, C.c_uint64, C.c_uint32, _vp]
+    L.hrfd_play_get.argtypes = [_vp, _vp, C.c_uint32]
     L.hrfd_nco_create.argtypes = [C.c_uint32, C.c_float, C.c_float, C.c_int, C.POINTER(_vp)]
     L.hrfd_nco_destroy.argtypes = [_vp]
     L.hrfd_nco_set_frequency.argtypes = [_vp, C.c_uint32, C.c_float]

@@ -202,6 +202,7 @@ class Demod:
 
 
 MOD_SSB, MOD_INTERP, MOD_AM, MOD_FM, MOD_WBFM = 1, 2, 3, 4, 5
+MOD_SIG_AM, MOD_SIG_DSB, MOD_SIG_PM, MOD_SIG_FM = 6, 7, 8, 9   # signals/{am,dsb,pm,fm}.cc | interpolateSignal
 
 
 class Ingest:
@@ -306,6 +307,46 @@ class Mod:
 
     def sync(self):
         check(self.L.hrfd_mod_sync(self.h), "hrfd_mod_sync")
+
+
+class Play:
+    """hrfd_play_*: DataProvider's cyclic .iq playback, one read position per channel, image in HBM."""
+
+    def __init__(self, n_channels: int = 1, device: int = -1):
+        self.L = _lib.load()
+        self.h = C.c_void_p()
+        self.C = n_channels
+        check(self.L.hrfd_play_create(n_channels, device, C.byref(self.h)), "hrfd_play_create")
+
+    def close(self):
+        if self.h:
+            self.L.hrfd_play_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def load_file(self, path: str):
+        check(self.L.hrfd_play_load_file(self.h, path.encode()), "hrfd_play_load_file")
+
+    def load(self, data: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.int8)
+        check(self.L.hrfd_play_load(self.h, _ptr(data), data.size), "hrfd_play_load")
+
+    def set_position(self, index: int, channel=ALL):
+        check(self.L.hrfd_play_set_position(self.h, channel, index), "hrfd_play_set_position")
+
+    def position(self, channel: int) -> int:
+        v = C.c_uint32()
+        check(self.L.hrfd_play_get_position(self.h, channel, C.byref(v)), "hrfd_play_get_position")
+        return v.value
+
+    def get(self, nbytes: int) -> np.ndarray:
+        out = np.zeros((self.C, nbytes), dtype=np.int8)
+        check(self.L.hrfd_play_get(self.h, _ptr(out), nbytes), "hrfd_play_get")
+        return out
+
+    def get_device(self, d_out, channel_stride: int, nbytes: int, stream=None):
+        check(self.L.hrfd_play_get_device(self.h, d_out, channel_stride, nbytes, stream), "hrfd_play_get_device")
 
 
 class Nco:

@@ -1238,10 +1238,9 @@ static int mod_free(hrfd_mod *h)
 extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out)
 {
   if (out == nullptr || n_channels == 0 ||
-      (kind != HRFD_MOD_SSB && kind != HRFD_MOD_INTERP && kind != HRFD_MOD_AM && kind != HRFD_MOD_FM &&
-       kind != HRFD_MOD_WBFM))
+      kind < HRFD_MOD_SSB || kind > HRFD_MOD_SIG_FM)
   {
-    return fail(HRFD_EINVAL, "hrfd_mod_create: kind must be HRFD_MOD_SSB, _INTERP, _AM, _FM or _WBFM, n_channels > 0");
+    return fail(HRFD_EINVAL, "hrfd_mod_create: kind must be HRFD_MOD_SSB, _INTERP, _AM, _FM, _WBFM or _SIG_*, n_channels > 0");
   }
   *out = nullptr;
   if (hrfd_device_count() <= 0)
@@ -1406,11 +1405,13 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
       {
         HIP_TRY(hipMemsetAsync(h->d_tail[h->cur], 0, per * h->n_channels, s));
         if (h->kind == HRFD_MOD_WBFM) HIP_TRY(hipMemsetAsync(h->d_wbtail[h->cur], 0, 8 * (size_t)h->n_channels, s));
+        if (h->kind == HRFD_MOD_SIG_FM) HIP_TRY(hipMemsetAsync(h->d_acc, 0, sizeof(float) * h->n_channels, s));   // a fresh run of the tool
       }
       else
       {
         HIP_TRY(hipMemsetAsync(h->d_tail[h->cur] + (size_t)ch * 4 * kModTail, 0, per, s));
         if (h->kind == HRFD_MOD_WBFM) HIP_TRY(hipMemsetAsync(h->d_wbtail[h->cur] + (size_t)ch * 2, 0, 8, s));
+        if (h->kind == HRFD_MOD_SIG_FM) HIP_TRY(hipMemsetAsync(h->d_acc + ch, 0, sizeof(float), s));
       }
     }
     h->resets.clear();
@@ -1500,6 +1501,44 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     }
     M.in = h->d_rails;
     hipLaunchKernelGGL(k_mod<HRFD_MOD_RAILS>, dim3(grid), dim3(kModThreads), 0, s, M);
+  }
+  else if (h->kind >= HRFD_MOD_SIG_AM)
+  {
+    // signals/{am,dsb,pm,fm}.cc | interpolateSignal: baseband pairs, then the x256 cascade with
+    // interpolateSignal's own stage-1 table
+    const size_t samples = (size_t)n_per_channel * h->n_channels;
+    int rc;
+    if (samples * 4 > h->cap_rails)
+    {
+      HIP_TRY(hipStreamSynchronize(s));
+      if ((rc = grow((void **)&h->d_rails, &h->cap_rails, samples * 4)) != HRFD_OK) return rc;
+    }
+    BaseParams B;
+    memset(&B, 0, sizeof(B));
+    B.pcm = d_pcm;
+    B.rails = h->d_rails;
+    B.acc = h->d_acc;
+    B.n = n_per_channel;
+    B.n_channels = h->n_channels;
+    const uint32_t gs = (uint32_t)((samples + 255) / 256);
+    if (h->kind == HRFD_MOD_SIG_AM)
+    {
+      hipLaunchKernelGGL(k_sig_rails<HRFD_MOD_SIG_AM>, dim3(gs), dim3(256), 0, s, B);
+    }
+    else if (h->kind == HRFD_MOD_SIG_DSB)
+    {
+      hipLaunchKernelGGL(k_sig_rails<HRFD_MOD_SIG_DSB>, dim3(gs), dim3(256), 0, s, B);
+    }
+    else if (h->kind == HRFD_MOD_SIG_PM)
+    {
+      hipLaunchKernelGGL(k_sig_rails<HRFD_MOD_SIG_PM>, dim3(gs), dim3(256), 0, s, B);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_sig_fm, dim3((h->n_channels + 63) / 64), dim3(64), 0, s, B);
+    }
+    M.in = h->d_rails;
+    hipLaunchKernelGGL(k_mod<HRFD_MOD_INTERP>, dim3(grid), dim3(kModThreads), 0, s, M);
   }
   else if (h->kind == HRFD_MOD_SSB)
   {

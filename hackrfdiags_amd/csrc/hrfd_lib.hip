@@ -8,3 +8,4 @@
 #include "hrfd_api.hip"
 #include "hrfd_ingest.hip"
 #include "hrfd_txring.hip"
+#include "hrfd_play.hip"

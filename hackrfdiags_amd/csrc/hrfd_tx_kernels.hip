@@ -417,6 +417,79 @@ __global__ void k_am_rails(const BaseParams B)
   reinterpret_cast<uint32_t *>(B.rails)[t] = ((uint32_t)v & 0xffffu) * 0x00010001u;
 }
 
+// The baseband generators of signals/ (am.cc:40-52, dsb.cc:38-46, pm.cc:41-53): one thread per
+// sample, float operations in the reference's order ("*= 0.8" and "*= M_PI" are double
+// multiplications rounded back to float; cos/sin of a float argument are the float overloads
+// there, evaluated here in double and rounded: +-1 LSB).  Output: (I,Q) int16 pairs for k_mod<INTERP>.
+template <int KIND>
+__global__ void k_sig_rails(const BaseParams B)
+{
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)B.n * B.n_channels)
+  {
+    return;
+  }
+  float s = (float)B.pcm[t];
+  int vi, vq;
+  if (KIND == HRFD_MOD_SIG_AM)
+  {
+    s = (float)((double)s * 0.8);
+    s = s + 65536.0f;
+    s = s / 4.0f;
+    vi = vq = (int)s;
+  }
+  else if (KIND == HRFD_MOD_SIG_DSB)
+  {
+    s = s / 4.0f;
+    vi = vq = (int)s;
+  }
+  else
+  {
+    s = s / 60000.0f;
+    s = (float)((double)s * 3.14159265358979323846);
+    const float ci = (float)cos((double)s) * 16000.0f;
+    const float sq = (float)sin((double)s) * 16000.0f;
+    vi = (int)ci;
+    vq = (int)sq;
+  }
+  reinterpret_cast<uint32_t *>(B.rails)[t] = ((uint32_t)vi & 0xffffu) | ((uint32_t)vq << 16);
+}
+
+// signals/fm.cc:44-77: theta += (pcm / 65536) * 3.5 (float), wrapped into [-2pi, 2pi] with double
+// compares and double subtractions stored back to float, then 16000*cos/sin.  The phase is a
+// serial float recurrence per channel: one thread per channel (tooling, 8 kS/s).
+__global__ void k_sig_fm(const BaseParams B)
+{
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B.n_channels)
+  {
+    return;
+  }
+  const double two_pi = 2 * 3.14159265358979323846;
+  float theta = B.acc[c];
+  const int16_t *in = B.pcm + (size_t)c * B.n;
+  uint32_t *out = reinterpret_cast<uint32_t *>(B.rails) + (size_t)c * B.n;
+  for (uint32_t k = 0; k < B.n; k++)
+  {
+    float tn = (float)in[k];
+    tn = tn / 65536.0f;
+    tn = tn * 3.5f;
+    theta = theta + tn;
+    while ((double)theta > two_pi)
+    {
+      theta = (float)((double)theta - two_pi);
+    }
+    while ((double)theta < -two_pi)
+    {
+      theta = (float)((double)theta + two_pi);
+    }
+    const float ci = (float)cos((double)theta) * 16000.0f;
+    const float sq = (float)sin((double)theta) * 16000.0f;
+    out[k] = ((uint32_t)(int)ci & 0xffffu) | ((uint32_t)(int)sq << 16);
+  }
+  B.acc[c] = theta;
+}
+
 // FmModulator::modulateSignal (FmModulator.cc:586-627).  Pass 1, one thread per sample: the Nco
 // step, f = deviation * pcm / 32768 (float), step = (float)((2*M_PI*f)/8000) (double expression,
 // PhaseAccumulator.cc:95-107).  Pass 2 is k_phase_scan (the recurrence), pass 3 k_fm_rails.

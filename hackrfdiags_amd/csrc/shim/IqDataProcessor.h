@@ -11,6 +11,7 @@
 #include "FmDemodulator.h"
 #include "WbFmDemodulator.h"
 #include "SsbDemodulator.h"
+#include "UdpClient.h"
 
 class IqDataProcessor
 {
@@ -55,9 +56,9 @@ class IqDataProcessor
   void disableIqDump(void);
   bool isIqDumpEnabled(void);
 
-  // Not in the reference: where `enable iqdump` data goes.  The reference sends
-  // decimatedData by UDP (UdpClient::sendData); networking is outside the hot
-  // path, so the host application registers a sink and forwards it itself.
+  // Not in the reference: an alternative destination of the `enable iqdump` data.  By default
+  // it is sent as the reference does, by UDP in 2048-byte datagrams (UdpClient::sendData,
+  // IqDataProcessor.cc:953-957); a registered sink receives it instead.
   void registerIqDumpSink(void (*sinkPtr)(int8_t *bufferPtr,uint32_t byteCount,void *contextPtr),
                           void *contextPtr);
 
@@ -69,6 +70,7 @@ class IqDataProcessor
   void pushGains(void);
 
   hrfd_rx *handle;
+  UdpClient *networkInterfacePtr;
   demodulatorType demodulatorMode;
   int32_t signalDetectThreshold;
 

@@ -21,6 +21,7 @@
 #include "FmModulator.h"
 #include "WbFmModulator.h"
 #include "Nco.h"
+#include "DataProvider.h"
 
 // symbols of the host application the reference code also expects
 // (Radio.cc:15, diagUi.cc:2881)
@@ -157,8 +158,9 @@ void SsbDemodulator::displayInternalInformation(void) { display("SSB Demodulator
 // ---------------------------------------------------------------- IqDataProcessor
 IqDataProcessor::IqDataProcessor(char *hostIpAddress,int hostPort)
 {
-  (void)hostIpAddress;     // the UDP dump of the 256 kS/s stream is the host application's
-  (void)hostPort;          // business here: see registerIqDumpSink()
+  // IqDataProcessor.cc:139: the `enable iqdump` stream goes to hostIpAddress:hostPort as
+  // 2048-byte datagrams (UdpClient, hrfd_shim_io.cc) unless a sink is registered instead
+  networkInterfacePtr = new UdpClient(hostIpAddress, hostPort);
   handle = NULL;
   demodulatorMode = None;
   signalDetectThreshold = -200;
@@ -180,6 +182,10 @@ IqDataProcessor::IqDataProcessor(char *hostIpAddress,int hostPort)
 
 IqDataProcessor::~IqDataProcessor(void)
 {
+  if (networkInterfacePtr != NULL)
+  {
+    delete networkInterfacePtr;
+  }
   if (handle != NULL)
   {
     hrfd_rx_destroy(handle);
@@ -262,9 +268,16 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
   if (rc != HRFD_OK) fatal("hrfd_rx_process_block", rc);
 
   // same order as the reference (IqDataProcessor.cc:953-1034)
-  if (iqDumpEnabled && iqDumpSinkPtr != NULL)
+  if (iqDumpEnabled)
   {
-    iqDumpSinkPtr(decimatedData, (uint32_t)(byteCount / 8), iqDumpContextPtr);
+    if (iqDumpSinkPtr != NULL)
+    {
+      iqDumpSinkPtr(decimatedData, (uint32_t)(byteCount / 8), iqDumpContextPtr);
+    }
+    else
+    {
+      networkInterfacePtr->sendData(decimatedData, (int)(byteCount / 8));   // IqDataProcessor.cc:956
+    }
   }
   if (signalNotificationEnabled && signalCallbackPtr != NULL)
   {
@@ -653,4 +666,57 @@ void Nco::runFast(float *iValuePtr,float *qValuePtr)
 {
   int rc = hrfd_nco_run(handle, 1, 1, iValuePtr, qValuePtr);
   if (rc != HRFD_OK) fatal("hrfd_nco_run", rc);
+}
+
+// ---------------------------------------------------------------- DataProvider
+DataProvider::DataProvider(void)
+{
+  handle = NULL;
+  iqFileName[0] = 0;
+}
+
+DataProvider::~DataProvider(void)
+{
+  if (handle != NULL)
+  {
+    hrfd_play_destroy(handle);
+  }
+}
+
+// DataProvider.cc:235-300
+bool DataProvider::loadIqFile(char *fileNamePtr)
+{
+  if (handle == NULL)
+  {
+    const int rc = hrfd_play_create(1, -1, &handle);
+    if (rc != HRFD_OK) hrfd_shim::fatal("hrfd_play_create", rc);
+  }
+  if (hrfd_play_load_file(handle, fileNamePtr) != HRFD_OK)
+  {
+    return false;
+  }
+  strncpy(iqFileName, fileNamePtr, sizeof(iqFileName) - 1);
+  iqFileName[sizeof(iqFileName) - 1] = 0;
+  return true;
+}
+
+// DataProvider.cc:122-131: nothing happens while no file is loaded
+void DataProvider::getIqData(int8_t *bufferPtr,uint32_t bufferLength)
+{
+  if (handle != NULL)
+  {
+    const int rc = hrfd_play_get(handle, bufferPtr, bufferLength);
+    if (rc != HRFD_OK) hrfd_shim::fatal("hrfd_play_get", rc);
+  }
+}
+
+void DataProvider::displayInternalInformation(void)
+{
+  uint32_t index = 0;
+  if (handle != NULL) (void)hrfd_play_get_position(handle, 0, &index);
+  nprintf(stderr, "\n--------------------------------------------\n");
+  nprintf(stderr, "Data Provider Internal Information (libhrfd, MI355X)\n");
+  nprintf(stderr, "--------------------------------------------\n");
+  nprintf(stderr, "IQ File Name            : %s\n", iqFileName);
+  nprintf(stderr, "IQ Sample Buffer Index  : %u\n", index);
 }

@@ -189,6 +189,16 @@ int hrfd_ingest_replayed(hrfd_ingest *g, uint64_t *n_batches);
  * a 256 kS/s Nco with runFast's table driven by deviation * x / 1024, x900, then x8): bit-exact
  * (the tables are built with the host's libm like the reference's). */
 #define HRFD_MOD_WBFM   5
+/* kinds HRFD_MOD_SIG_* replace the baseband generators of signals/ piped into interpolateSignal
+ * (signals/makeThem.sh, generateBaseband.sh: `./a.out < pcm.raw | ./interpolateSignal > x.iq`):
+ * am.cc:40-52 ((pcm*0.8 + 65536)/4 on both rails), dsb.cc:38-46 (pcm/4), pm.cc:41-53
+ * (phase = pcm/60000*pi, 16000*cos/sin), fm.cc:44-77 (theta += pcm/65536*3.5, wrapped at +-2pi).
+ * PCM in, int8 IQ at 2.048 MS/s out -- the .iq files that `load iqfile` plays (hrfd_play).
+ * AM and DSB are bit-exact; PM and FM go through cos/sin: int8 IQ within +-1 LSB of the reference. */
+#define HRFD_MOD_SIG_AM  6
+#define HRFD_MOD_SIG_DSB 7
+#define HRFD_MOD_SIG_PM  8
+#define HRFD_MOD_SIG_FM  9
 int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out);
 int hrfd_mod_destroy(hrfd_mod *h);
 int hrfd_mod_reset(hrfd_mod *h, uint32_t channel);
@@ -223,6 +233,25 @@ int hrfd_txring_set_running(hrfd_txring *r, uint32_t channel, int running);
 int hrfd_txring_write(hrfd_txring *r, uint32_t channel, const int16_t *pcm512);
 int hrfd_txring_read_batch(hrfd_txring *r, int16_t *batch);
 int hrfd_txring_stats(hrfd_txring *r, uint32_t channel, uint32_t *out6);
+
+/* ------------------------------------------------------------------------------
+ * Cyclic playback of an .iq file (raw int8 IQ at 2.048 MS/s): DataProvider::loadIqFile /
+ * getIqData (src_diags/DataProvider.cc:235-300, 122-131, 174-231) with the file image resident in
+ * HBM and one read position per channel, so that one recording drives many receive channels
+ * (SURVEY 8f rank 4).  hrfd_play_get_device fills d_out[c][bytes_per_channel] (channel_stride bytes
+ * apart) from every channel's position and advances it modulo the file length, exactly like
+ * retrieveIqDataFromBuffer; nothing is written while no file is loaded (as in the reference).
+ */
+typedef struct hrfd_play hrfd_play;
+int hrfd_play_create(uint32_t n_channels, int device, hrfd_play **out);
+int hrfd_play_destroy(hrfd_play *h);
+int hrfd_play_load_file(hrfd_play *h, const char *path);
+int hrfd_play_load(hrfd_play *h, const int8_t *bytes, uint32_t n_bytes);
+int hrfd_play_set_position(hrfd_play *h, uint32_t channel, uint32_t byte_index);
+int hrfd_play_get_position(hrfd_play *h, uint32_t channel, uint32_t *byte_index);
+int hrfd_play_get_device(hrfd_play *h, int8_t *d_out, uint64_t channel_stride,
+                         uint32_t bytes_per_channel, void *stream);
+int hrfd_play_get(hrfd_play *h, int8_t *out, uint32_t bytes_per_channel);
 
 /* ------------------------------------------------------------------------------
  * Nco (Nco/Nco.cc:186-257, Nco/PhaseAccumulator.cc:157-181): n_channels

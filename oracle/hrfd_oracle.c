@@ -1540,3 +1540,64 @@ int orc_table(const char *name, float *out, int cap)
   }
   return 0;
 }
+
+/* ---- signals/{am,dsb,pm,fm}.cc ------------------------------------------------------------
+ * Each tool reads int16 PCM from stdin and writes int16 (I,Q) pairs to stdout, float arithmetic.
+ * The C++ sources include <math.h> under `using namespace std`, so cos/sin of a float argument
+ * are the float overloads (cosf/sinf), as SURVEY 8(a) N2 found for Nco::run; "x *= 0.8" and
+ * "x *= M_PI" multiply in double and round back to float. */
+void orc_siggen(int kind, const int16_t *pcm, uint32_t n, int16_t *iq_pairs, float *theta_io)
+{
+  float theta = theta_io ? *theta_io : 0.0f;
+  for (uint32_t k = 0; k < n; k++)
+  {
+    float s = (float)pcm[k];
+    int16_t vi, vq;
+    if (kind == 0)
+    {                                   /* am.cc:44-49 */
+      s = (float)((double)s * 0.8);
+      s = s + 65536;
+      s = s / 4;
+      vi = vq = (int16_t)s;
+    }
+    else if (kind == 1)
+    {                                   /* dsb.cc:42-45 */
+      s = s / 4;
+      vi = vq = (int16_t)s;
+    }
+    else if (kind == 2)
+    {                                   /* pm.cc:45-52 */
+      s = s / 60000;
+      s = (float)((double)s * M_PI);
+      const float i = cosf(s) * 16000;
+      const float q = sinf(s) * 16000;
+      vi = (int16_t)i;
+      vq = (int16_t)q;
+    }
+    else
+    {                                   /* fm.cc:53-74, kF = 3.5 */
+      float tn = (float)pcm[k];
+      tn = tn / 65536;
+      tn *= 3.5f;
+      theta = theta + tn;
+      while (theta > (2 * M_PI))
+      {
+        theta = (float)(theta - (2 * M_PI));
+      }
+      while (theta < (-(2 * M_PI)))
+      {
+        theta = (float)(theta + (2 * M_PI));
+      }
+      const float i = cosf(theta) * 16000;
+      const float q = sinf(theta) * 16000;
+      vi = (int16_t)i;
+      vq = (int16_t)q;
+    }
+    iq_pairs[2 * k] = vi;
+    iq_pairs[2 * k + 1] = vq;
+  }
+  if (theta_io)
+  {
+    *theta_io = theta;
+  }
+}

@@ -87,6 +87,11 @@ void orc_txring_write(orc_txring *h, const int16_t *pcm512);
 void orc_txring_read(orc_txring *h, int16_t *pcm512);
 void orc_txring_stats(const orc_txring *h, uint32_t *out6);
 
+/* signals/{am,dsb,pm,fm}.cc: int16 PCM -> int16 (I,Q) pairs, the input of interpolateSignal.
+ * kind 0 am (am.cc:40-52), 1 dsb (dsb.cc:38-46), 2 pm (pm.cc:41-53), 3 fm (fm.cc:44-77; *theta is
+ * the tool's phase variable, 0 at program start and carried across calls). */
+void orc_siggen(int kind, const int16_t *pcm, uint32_t n, int16_t *iq_pairs, float *theta);
+
 orc_interp *orc_interp_create(void);
 void orc_interp_destroy(orc_interp *h);
 /* n_pairs IQ pairs in (2*n_pairs int16), 512*n_pairs bytes out */

@@ -38,6 +38,8 @@
 #include "FmModulator.h"
 #include "WbFmModulator.h"
 #include "BasebandDataProcessor.h"
+#include "UdpClient.h"
+#include "DataProvider.h"
 #include "Nco.h"
 #include "Interpolator_int16.h"
 #include "FirFilter_int16.h"
@@ -502,6 +504,19 @@ int32_t ref_magnitude_to_dbfs(uint32_t magnitude)
   DbfsCalculator c(7);
   return c.convertMagnitudeToDbFs(magnitude);
 }
+
+// UdpClient::sendData (UdpClient.cc:173-241): the wire format of `enable iqdump`
+int ref_udp_send(const char *ip, int port, void *buffer, int length)
+{
+  UdpClient c(const_cast<char *>(ip), port);
+  return c.sendData(buffer, length) ? 1 : 0;
+}
+
+// DataProvider (DataProvider.cc:174-231, 235-300): cyclic playback of an .iq file
+void *ref_provider_create(void) { return new DataProvider(); }
+void ref_provider_destroy(void *p) { delete static_cast<DataProvider *>(p); }
+int ref_provider_load(void *p, const char *path) { return static_cast<DataProvider *>(p)->loadIqFile(const_cast<char *>(path)) ? 1 : 0; }
+void ref_provider_get(void *p, int8_t *out, uint32_t bytes) { static_cast<DataProvider *>(p)->getIqData(out, bytes); }
 
 // The UB-dependent float -> int16 narrowing, as the host compiler does it.
 int16_t ref_float_to_int16(float value)

@@ -3,7 +3,9 @@
 // drop-in shim classes: blocks of int8 IQ on stdin -> PCM on stdout, driven through
 //   IqDataProcessor::acceptIqData            (outer boundary, argv[2] == "outer")
 //   XDemodulator::acceptIqData on 256 kS/s   (inner boundary, argv[2] == "inner")
-// usage: shim_demo <mode 1..5> <outer|inner> <block_bytes>
+// usage: shim_demo <mode 1..5> <outer|inner> <block_bytes> [iqdump udp port]
+//        shim_demo <port> udp <bytes per sendData>            (stdin -> UdpClient datagrams)
+//        shim_demo <calls> provider <bytes per call> <file>   (DataProvider playback -> stdout)
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,6 +18,7 @@
 #include "AmModulator.h"
 #include "FmModulator.h"
 #include "WbFmModulator.h"
+#include "DataProvider.h"
 
 uint32_t radio_adjustableReceiveGainInDb = 0;          // Radio.cc:15
 void nprintf(FILE *s, const char *formatPtr, ...)      // diagUi.cc:2881
@@ -87,8 +90,43 @@ int main(int argc, char **argv)
     return 0;
   }
 
+  if (strcmp(argv[2], "udp") == 0)
+  {
+    // UdpClient alone: stdin -> datagrams towards 127.0.0.1:<mode>, <block_bytes> per sendData call
+    static char ip[] = "127.0.0.1";
+    UdpClient client(ip, mode);
+    size_t got;
+    while ((got = fread(buf.data(), 1, blockBytes, stdin)) > 0)
+    {
+      client.sendData(buf.data(), (int)got);
+    }
+    return 0;
+  }
+  if (strcmp(argv[2], "provider") == 0)
+  {
+    // `load iqfile` playback: DataProvider::getIqData, <mode> calls of <block_bytes>, file = argv[4]
+    DataProvider provider;
+    if (argc < 5 || !provider.loadIqFile(argv[4]))
+    {
+      fprintf(stderr, "cannot load the iq file\n");
+      return 3;
+    }
+    for (int i = 0; i < mode; i++)
+    {
+      provider.getIqData(buf.data(), (uint32_t)blockBytes);
+      fwrite(buf.data(), 1, blockBytes, stdout);
+    }
+    provider.displayInternalInformation();
+    return 0;
+  }
+
   static char ip[] = "127.0.0.1";
-  IqDataProcessor proc(ip, 8001);
+  // argv[4], when present: the UDP port of the `enable iqdump` stream (IqDataProcessor.cc:953-957)
+  IqDataProcessor proc(ip, argc >= 5 ? atoi(argv[4]) : 8001);
+  if (argc >= 5)
+  {
+    proc.enableIqDump();
+  }
   AmDemodulator am(processPcmData);
   FmDemodulator fm(processPcmData);
   WbFmDemodulator wbfm(processPcmData);

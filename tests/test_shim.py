@@ -18,7 +18,8 @@ DEMO = os.path.join(ROOT, "tests", "cpp", "shim_demo")
 def _build_demo():
     lib = os.path.join(ROOT, "hackrfdiags_amd", "lib")
     cmd = ["g++", "-O2", "-std=c++17", "-o", DEMO, os.path.join(ROOT, "tests", "cpp", "shim_demo.cc"),
-           os.path.join(SHIM, "hrfd_shim.cc"), "-I", os.path.join(ROOT, "include"), "-I", SHIM,
+           os.path.join(SHIM, "hrfd_shim.cc"), os.path.join(SHIM, "hrfd_shim_io.cc"),
+           "-I", os.path.join(ROOT, "include"), "-I", SHIM,
            "-L", lib, "-lhrfd", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
 
