@@ -28,7 +28,10 @@ constexpr int kMaxN256 = HRFD_MAXN256;        // 262144-byte block
 constexpr int kTile = 70;                     // = 2 (mod 4): 64-bit LDS accesses, 32 lanes in 32 different 8-byte banks
 constexpr int kBWaves = 4;                    // waves that run the recurrence (one per SIMD)
 constexpr int kMaxTiles = 64 * kBWaves;
-constexpr int kWarmTiles = 3;                 // warm-up = 210 samples behind a seed that is good to a few ulp
+#ifndef HRFD_WARM_TILES
+#define HRFD_WARM_TILES 3
+#endif
+constexpr int kWarmTiles = HRFD_WARM_TILES;   // warm-up = 210 samples behind a seed that is good to a few ulp
 constexpr int kSeedTerms = 5;                 // 0.949^350 = 1.2e-8
 constexpr int kWarm = 512;                    // argument of the test hook hrfd_rx_debug_set_warm that means "default"
 constexpr int kHist = 704;                    // exact history kept in front of a block (>= 644)

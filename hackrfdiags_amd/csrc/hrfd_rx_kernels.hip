@@ -333,6 +333,17 @@ __device__ __forceinline__ int f2i16(float f)
   return (int)(short)v;
 }
 
+template <bool FIX = true>
+__device__ __forceinline__ uint32_t pack_s16(float lo, float hi)
+{
+  if (FIX)
+  {
+    return ((uint32_t)f2i16(lo) & 0xffffu) | ((uint32_t)f2i16(hi) << 16);
+  }
+  // |y| < 2^31 is known: v_cvt_i32_f32 cannot saturate, the low 16 bits are x86's
+  return ((uint32_t)(int)lo & 0xffffu) | ((uint32_t)(int)hi << 16);
+}
+
 // Have two runs of the de-emphasis recurrence become the same trajectory?
 // Bitwise-equal values stay equal forever (same inputs from here on).  +0/-0
 // compare equal: the next step erases the sign and (int16_t) maps both to 0.
@@ -1503,6 +1514,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   // C1: s[n] = (int16_t)y[n] (WbFmDemodulator.cc:476), repacked in place as
   // int16 pairs at the bottom of the buffer: all reads, barrier, all writes.
   const bool carried = first || cont;                    // the integer stages' histories are carried, not re-derived
+  const bool small_y = fabsf(X.kgain) * 3.3f < 2147483000.0f;
   const int smin = carried ? 0 : -kHist;
   const int npairs = (n256 - smin) >> 1;
   uint32_t packed[kPairsPerThread];
@@ -1516,7 +1528,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
       const int pos = smin + 2 * q;
       const float ya = u2f(lds[pos + hal]);
       const float yb = u2f(lds[pos + 1 + hal]);
-      w = ((uint32_t)f2i16(ya) & 0xffffu) | ((uint32_t)f2i16(yb) << 16);
+      // |y| <= |K| pi (unit DC gain, positive impulse response): below 2^31 the cast cannot overflow
+      w = small_y ? pack_s16<false>(ya, yb) : pack_s16<true>(ya, yb);
       if (last && pos + 2 == n256)
       {
         so->wb_y = yb;
@@ -1627,6 +1640,207 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 }
 
 // =============================================================================
+//  phase A, "quad" layout (k_rx_wbfm_stream only): a lane owns FOUR consecutive groups
+// =============================================================================
+// produce_stream gives lane L of a wave the 16-byte group L of each 1 KiB chunk, so every value a
+// stage needs from the previous group comes from the neighbouring lane: 10 DPP moves per chunk
+// (slow-class instructions, tools/ubench/valu_rate.hip).  With 128 VGPRs per wave a lane can own
+// the 64 contiguous bytes of FOUR consecutive groups of a 4 KiB piece and run the stages
+// breadth-first over them: the previous group is in the lane's own registers for three groups
+// out of four (10 DPP per 4 KiB instead of 40), the Fs/4 rotation of a group is a compile-time
+// constant (position mod 4 == group), and the four v go to LDS in one 16-byte store.
+// The loads are four dwordx4 per lane, 64 bytes apart across lanes (every 128-byte line is
+// touched by all four of them back to back).  Same arithmetic, same carries, same edges as
+// produce_stream; positions are counted in pieces of 256 samples.
+template <int ROT>
+__device__ __forceinline__ uint32_t mix_fs4_const(uint32_t y3)
+{
+  // rot 0 (I,Q), 1 (-Q,I), 2 (-I,-Q), 3 (Q,-I) in offset-binary index form, see mix_fs4
+  if (ROT == 0)
+  {
+    return y3 & 0x00ff00ffu;
+  }
+  if (ROT == 2)
+  {
+    return ((y3 ^ 0x00ff00ffu) + 0x00010001u) & 0x00ff00ffu;
+  }
+  const uint32_t sw = __builtin_amdgcn_alignbit(y3, y3, 16);
+  if (ROT == 1)
+  {
+    return ((sw ^ 0x000000ffu) + 0x00000001u) & 0x00ff00ffu;
+  }
+  return ((sw ^ 0x00ff0000u) + 0x00010000u) & 0x00ff00ffu;
+}
+
+struct QuadCarry
+{
+  FeCarry fe;
+  uint32_t theta, p;          // lane 0: theta and b0*x of the sample before the piece
+};
+
+// one 4 KiB piece: raw[j] = the lane's group j (16 bytes) -> v[4]; returns the four thetas
+template <bool ARITH>
+__device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, const StreamCtx &X,
+                                           uint32_t (&vout)[4], float (&theta)[4], uint32_t &mag4)
+{
+  uint32_t r[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    r[j][0] = raw[j].x ^ 0x80808080u;
+    r[j][1] = raw[j].y ^ 0x80808080u;
+    r[j][2] = raw[j].z ^ 0x80808080u;
+    r[j][3] = raw[j].w ^ 0x80808080u;
+  }
+  // stage 1 (bytes) and its outputs as 16-bit (I,Q) fields
+  uint32_t y1[4][4];
+  const uint32_t rm1_0 = shr1(r[3][3], c.fe.x7);
+  c.fe.x7 = ror1(r[3][3]);
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    const uint32_t rm1 = (j == 0) ? rm1_0 : r[j > 0 ? j - 1 : 0][3];
+    const uint32_t a01 = __builtin_amdgcn_perm(r[j][0], rm1, 0x07060302u);
+    const uint32_t b01 = __builtin_amdgcn_perm(r[j][1], r[j][0], 0x05040100u);
+    const uint32_t c01 = __builtin_amdgcn_perm(r[j][1], r[j][0], 0x07060302u);
+    const uint32_t a23 = __builtin_amdgcn_perm(r[j][2], r[j][1], 0x07060302u);
+    const uint32_t b23 = __builtin_amdgcn_perm(r[j][3], r[j][2], 0x05040100u);
+    const uint32_t c23 = __builtin_amdgcn_perm(r[j][3], r[j][2], 0x07060302u);
+    const uint32_t y01 = hb1_bytes(a01, b01, c01);
+    const uint32_t y23 = hb1_bytes(a23, b23, c23);
+    y1[j][0] = __builtin_amdgcn_perm(0u, y01, 0x0c010c00u);
+    y1[j][1] = __builtin_amdgcn_perm(0u, y01, 0x0c030c02u);
+    y1[j][2] = __builtin_amdgcn_perm(0u, y23, 0x0c010c00u);
+    y1[j][3] = __builtin_amdgcn_perm(0u, y23, 0x0c030c02u);
+  }
+  // stage 2
+  uint32_t y20b[4], y21[4];
+  const uint32_t y1m1_0 = shr1(y1[3][3], c.fe.y13);
+  c.fe.y13 = ror1(y1[3][3]);
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    const uint32_t y1m1 = (j == 0) ? y1m1_0 : y1[j > 0 ? j - 1 : 0][3];
+    y20b[j] = form_b2(hb2_sum(y1m1, y1[j][0] << 1, y1[j][1]));
+    y21[j] = form_ac(hb2_sum(y1[j][1], y1[j][2] << 1, y1[j][3]));
+  }
+  // stage 3, mixer, magnitude, theta
+  const uint32_t y2m1_0 = shr1(y21[3], c.fe.y21);
+  c.fe.y21 = ror1(y21[3]);
+  uint32_t mixed[4];
+  {
+    const uint32_t y30 = hb3_sum(y2m1_0, y20b[0], y21[0]) >> 2;
+    const uint32_t y31 = hb3_sum(y21[0], y20b[1], y21[1]) >> 2;
+    const uint32_t y32 = hb3_sum(y21[1], y20b[2], y21[2]) >> 2;
+    const uint32_t y33 = hb3_sum(y21[2], y20b[3], y21[3]) >> 2;
+    mixed[0] = mix_fs4_const<0>(y30);
+    mixed[1] = mix_fs4_const<1>(y31);
+    mixed[2] = mix_fs4_const<2>(y32);
+    mixed[3] = mix_fs4_const<3>(y33);
+  }
+  mag4 = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    mag4 += magnitude(mixed[j]);
+    if (ARITH)
+    {
+      theta[j] = theta_arith(mixed[j], X.atc, X.ati);
+    }
+    else
+    {
+      theta[j] = X.P->atan2_lut[__builtin_amdgcn_perm(0u, mixed[j], 0x0c0c0200u)];
+    }
+  }
+  // phase difference -> de-emphasis numerator
+  const float thp0 = u2f(shr1(f2u(theta[3]), c.theta));
+  c.theta = ror1(f2u(theta[3]));
+  float p[4];
+  p[0] = numerator_p(theta[0], thp0, X.kgain);
+  p[1] = numerator_p(theta[1], theta[0], X.kgain);
+  p[2] = numerator_p(theta[2], theta[1], X.kgain);
+  p[3] = numerator_p(theta[3], theta[2], X.kgain);
+  const float pp0 = u2f(shr1(f2u(p[3]), c.p));
+  c.p = ror1(f2u(p[3]));
+  vout[0] = f2u(p[0] + pp0);
+  vout[1] = f2u(p[1] + p[0]);
+  vout[2] = f2u(p[2] + p[1]);
+  vout[3] = f2u(p[3] + p[2]);
+}
+
+// pieces [q0, q1) of 256 samples (piece q covers positions vstart + 256 q ..); wave-uniform arguments
+template <bool ARITH>
+__device__ __forceinline__ void produce_quads(const StreamCtx &X, const int q0, const int q1, uint32_t &magsum,
+                                              uint32_t (&edge)[4])
+{
+  const int lane = X.lane;
+  if (q0 >= q1)
+  {
+    return;
+  }
+  QuadCarry c;
+  c.fe = {0x80808080u, 0x00800080u, 0x00800080u};
+  c.theta = 0u;
+  c.p = 0u;
+  if (X.first && q0 == 0)
+  {
+    c.fe = carry_from_16(*reinterpret_cast<const uint4 *>(X.st->fe_tail));
+    c.theta = f2u(X.st->wb_theta);
+    c.p = f2u(X.st->wb_p);
+  }
+  else
+  {
+    const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 256 * q0) * 16 - 16);
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, 0, soff, 0);
+    c.fe = carry_from_16(make_uint4(t.x, t.y, t.z, t.w));
+  }
+  const int nskipq = (-X.vstart) >> 8;                   // pieces of history in front of the block: not in the squelch sum
+  auto load_piece = [&](uint4 (&q)[4], const int piece) {
+    // pieces past the end of the run are pointed outside the buffer: zeros, no memory traffic
+    const uint32_t soff = (piece < q1) ? X.blk_off + (uint32_t)((X.vstart + 256 * piece) * 16) : 0xffff0000u;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, lane * 64 + 16 * j, soff, HRFD_STREAM_AUX);
+      q[j] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  uint4 qa[4], qb[4];
+  load_piece(qa, q0);
+  load_piece(qb, q0 + 1);
+  float th_first[2] = {0.0f, 0.0f}, th_last[2] = {0.0f, 0.0f};
+  auto step = [&](uint4 (&q)[4], const int piece) {
+    uint32_t v[4], mag4;
+    float theta[4];
+    quad_piece<ARITH>(q, c, X, v, theta, mag4);
+    load_piece(q, piece + 2);                            // refill this slot
+    magsum += (piece >= nskipq) ? mag4 : 0u;
+    *reinterpret_cast<uint4 *>(X.lds + (X.vstart + 256 * piece + 4 * lane + X.hal)) = make_uint4(v[0], v[1], v[2], v[3]);
+    if (piece == q0)
+    {
+      th_first[0] = theta[0];
+      th_first[1] = theta[1];
+    }
+    th_last[0] = theta[2];
+    th_last[1] = theta[3];
+  };
+  int piece = q0;
+  for (; piece + 2 <= q1; piece += 2)
+  {
+    step(qa, piece);
+    step(qb, piece + 1);
+  }
+  if (piece < q1)
+  {
+    step(qa, piece);
+  }
+  edge[0] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_first[0]), 0);
+  edge[1] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_first[1]), 0);
+  edge[2] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last[0]), 63);
+  edge[3] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last[1]), 63);
+}
+
+// =============================================================================
 //  WBFM, batches (n_blocks > 1): one persistent workgroup per CU, phases overlapped
 // =============================================================================
 // k_rx_wbfm above runs the phases of a block one after the other, and the two workgroups of a
@@ -1658,7 +1872,7 @@ constexpr int kHoff1 = (kKeepMax + 63) / 64 * 64;
 constexpr int kStreamDepth = HRFD_STREAM_DEPTH;          // raw chunks in flight per stream wave (128 VGPRs per wave)
 constexpr int kStreamFence = HRFD_STREAM_FENCE;          // chunks the scheduler may interleave
 #ifndef HRFD_RUN_CHUNKS
-#define HRFD_RUN_CHUNKS 6
+#define HRFD_RUN_CHUNKS 8   /* two 4 KiB pieces of the quad layout */
 #endif
 constexpr int kRunChunks = HRFD_RUN_CHUNKS;
 constexpr int kMaxRuns = 64;                             // one lane of wave 0 patches each run boundary
@@ -1679,11 +1893,6 @@ __device__ __forceinline__ void svc_barrier(uint32_t *ctr, uint32_t &target, con
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-__device__ __forceinline__ uint32_t pack_s16(float lo, float hi)
-{
-  return ((uint32_t)f2i16(lo) & 0xffffu) | ((uint32_t)f2i16(hi) << 16);
-}
-
 template <bool ARITH>
 __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P)
 {
@@ -1693,7 +1902,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
   __shared__ __attribute__((aligned(16))) float atinv[ARITH ? kInvEntries : 4];
   __shared__ __attribute__((aligned(16))) uint32_t ubuf[(kMaxN256 / 4 + kUHist) / 2];       // U[-kUHist ..)
   __shared__ __attribute__((aligned(16))) uint32_t vbuf[(kMaxN256 / 16 + kVHist) / 2 + 1];  // V[-kVHist ..)
-  __shared__ uint32_t red[2][kWaves];
+  __shared__ uint32_t magtot[2];        // sum of the sample magnitudes of the block in buffer 0 / 1
   __shared__ int8_t dbfs8[128];
   __shared__ float tailcarry[2];
   __shared__ uint32_t edges[2][kMaxRuns][4];
@@ -1743,6 +1952,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
     svc_ctr = 0u;
     anybad = 0u;
     grab[0] = 0u;
+    magtot[0] = 0u;
+    magtot[1] = 0u;
   }
   __syncthreads();
 
@@ -1759,7 +1970,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
   float kgain = cfg.gain_wbfm / 75000.0f;                // K = (gain/75000)*32767 in float, that order
   kgain = kgain * 32767.0f;
   const float a1 = DEEMPH_A1;
+  const bool small_y = fabsf(kgain) * 3.3f < 2147483000.0f;   // NaN gain: false
   uint32_t svc_target = 0;
+  // the quad layout of phase A needs whole 4 KiB pieces everywhere and has no iq-dump variant
+#ifndef HRFD_NO_QUADS
+  const bool quads = (n256 & 255) == 0 && (hal & 255) == 0 && P.iq256 == nullptr && (kRunChunks & 3) == 0;
+#else
+  const bool quads = false;
+#endif
   // diagnostics (hrfd_rx_debug_stamps): cycles each wave spent working (not waiting at the block barrier)
   unsigned long long busy = 0, t_enter = 0;
   const unsigned long long t_kernel = __builtin_readcyclecounter();
@@ -2044,30 +2262,43 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
       {
         const int mmin = carried ? 0 : -kUHist;
         const int nq = ((n256 >> 2) - mmin) >> 1;
-        for (int q = tid; q < nq; q += kSvcThreads)
-        {
-          const int m = mmin + 2 * q;
-          // y[4m-4 .. 4m+7]: three 16-byte reads
-          const uint4 *yq = reinterpret_cast<const uint4 *>(lds + (4 * m - 4 + hoff));
-          const uint4 a = yq[0], bq = yq[1], cq = yq[2];
-          uint32_t s0 = pack_s16(u2f(a.x), u2f(a.y)), s1 = pack_s16(u2f(a.z), u2f(a.w));
-          const uint32_t s2 = pack_s16(u2f(bq.x), u2f(bq.y)), s3 = pack_s16(u2f(bq.z), u2f(bq.w));
-          const uint32_t s4 = pack_s16(u2f(cq.x), u2f(cq.y)), s5 = pack_s16(u2f(cq.z), u2f(cq.w));
-          if (carried && m == 0)
+        auto d8 = [&](auto fixtag) {
+          constexpr bool FIX = decltype(fixtag)::value;
+          for (int q = tid; q < nq; q += kSvcThreads)
           {
-            s0 = reinterpret_cast<const uint32_t *>(hs)[0];   // S[-4 .. -1]: the previous block's last samples
-            s1 = reinterpret_cast<const uint32_t *>(hs)[1];
+            const int m = mmin + 2 * q;
+            // y[4m-4 .. 4m+7]: three 16-byte reads
+            const uint4 *yq = reinterpret_cast<const uint4 *>(lds + (4 * m - 4 + hoff));
+            const uint4 a = yq[0], bq = yq[1], cq = yq[2];
+            uint32_t s0 = pack_s16<FIX>(u2f(a.x), u2f(a.y)), s1 = pack_s16<FIX>(u2f(a.z), u2f(a.w));
+            const uint32_t s2 = pack_s16<FIX>(u2f(bq.x), u2f(bq.y)), s3 = pack_s16<FIX>(u2f(bq.z), u2f(bq.w));
+            const uint32_t s4 = pack_s16<FIX>(u2f(cq.x), u2f(cq.y)), s5 = pack_s16<FIX>(u2f(cq.z), u2f(cq.w));
+            if (carried && m == 0)
+            {
+              s0 = reinterpret_cast<const uint32_t *>(hs)[0];   // S[-4 .. -1]: the previous block's last samples
+              s1 = reinterpret_cast<const uint32_t *>(hs)[1];
+            }
+            int acc0 = 1 << 14, acc1 = 1 << 14;
+            acc0 = dot2(s0, kRevWbD1.p[0], acc0);
+            acc0 = dot2(s1, kRevWbD1.p[1], acc0);
+            acc0 = dot2(s2, kRevWbD1.p[2], acc0);
+            acc0 = dot2(s3, kRevWbD1.p[3], acc0);
+            acc1 = dot2(s2, kRevWbD1.p[0], acc1);
+            acc1 = dot2(s3, kRevWbD1.p[1], acc1);
+            acc1 = dot2(s4, kRevWbD1.p[2], acc1);
+            acc1 = dot2(s5, kRevWbD1.p[3], acc1);
+            ubuf[(m + kUHist) >> 1] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
           }
-          int acc0 = 1 << 14, acc1 = 1 << 14;
-          acc0 = dot2(s0, kRevWbD1.p[0], acc0);
-          acc0 = dot2(s1, kRevWbD1.p[1], acc0);
-          acc0 = dot2(s2, kRevWbD1.p[2], acc0);
-          acc0 = dot2(s3, kRevWbD1.p[3], acc0);
-          acc1 = dot2(s2, kRevWbD1.p[0], acc1);
-          acc1 = dot2(s3, kRevWbD1.p[1], acc1);
-          acc1 = dot2(s4, kRevWbD1.p[2], acc1);
-          acc1 = dot2(s5, kRevWbD1.p[3], acc1);
-          ubuf[(m + kUHist) >> 1] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+        };
+        // |d| <= pi after the wrap, x = K d, and the de-emphasis filter has unit DC gain with positive
+        // impulse response: |y| <= |K| pi (1 + rounding).  Below 2^31 the cast cannot overflow.
+        if (small_y)
+        {
+          d8(std::false_type{});
+        }
+        else
+        {
+          d8(std::true_type{});
         }
       }
       // the last four S samples and the last y, before anybody may overwrite anything
@@ -2151,7 +2382,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
           }
           const int c1 = min(c0 + kRunChunks, nch);
           uint32_t e[4] = {0u, 0u, 0u, 0u};
-          if (P.iq256 != nullptr)
+          if (quads)
+          {
+            produce_quads<ARITH>(X, c0 >> 2, c1 >> 2, magsum, e);
+          }
+          else if (P.iq256 != nullptr)
           {
             produce_stream<3, false, true, false, ARITH, kStreamDepth, kStreamFence>(X, c0, c1, X.vstart, n256, magsum, e);
           }
@@ -2170,7 +2405,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
         }
         if (lane == 0)
         {
-          red[bi][wave] = magsum;
+          atomicAdd(&magtot[bi], magsum);
         }
         if (b + 1 == P.n_blocks && stid >= 0 && stid < 4)
         {
@@ -2188,20 +2423,30 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
       // block `step` has been streamed: block-mean magnitude, squelch detector (k_rx_wbfm)
       const uint32_t b = step;
       const int bi = (int)((b - b_first) & 1u);
-      uint32_t total = 0;
-      for (int w = 0; w < kWaves; w++)
+      // only the call's first block is gated here (a batch speculates "open" for the others and
+      // k_rx_epilogue checks): everybody needs the verdict for b == 0, one wave otherwise
+      bool allowed = true;
+      if (b == 0 || wave == 0)
       {
-        total += red[bi][w];
+        const uint32_t total = magtot[bi];
+        const uint32_t mean_mag = total / (uint32_t)n256;
+        int32_t dbfs = (int32_t)dbfs8[min(mean_mag, 127u)] - 42;
+        dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
+        const bool present = dbfs >= cfg.threshold;
+        allowed = (b == 0) ? (present || st->tracking != 0) : true;
+        if (tid == 0)
+        {
+          P.magnitude[(size_t)c * P.out_blocks + P.out_b0 + b] = mean_mag;
+          P.present[(size_t)c * P.n_blocks + b] = present ? 1 : 0;
+        }
       }
-      const uint32_t mean_mag = total / (uint32_t)n256;
-      int32_t dbfs = (int32_t)dbfs8[min(mean_mag, 127u)] - 42;
-      dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
-      const bool present = dbfs >= cfg.threshold;
-      const bool allowed = (b == 0) ? (present || st->tracking != 0) : true;
+      if (b == 0)
+      {
+        __syncthreads();                                 // every wave has read the sum (once per call)
+      }
       if (tid == 0)
       {
-        P.magnitude[(size_t)c * P.out_blocks + P.out_b0 + b] = mean_mag;
-        P.present[(size_t)c * P.n_blocks + b] = present ? 1 : 0;
+        magtot[bi] = 0u;                                 // ready for the block after next
       }
       if (!allowed)
       {

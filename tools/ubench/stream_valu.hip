@@ -63,6 +63,69 @@ __global__ __launch_bounds__(1024, 8) void k_stream(const uint4 *__restrict__ in
   }
 }
 
+
+// Same stream, but every lane owns 64 CONTIGUOUS bytes of each 4 KiB piece (four dwordx4 loads whose
+// lanes are 64 bytes apart): what a "four consecutive groups per lane" layout of the WBFM chunk loop
+// would issue.  Does the per-CU L1 keep up with 64-byte-strided 16-byte requests?
+template <int NV, int DEPTH>
+__global__ __launch_bounds__(1024, 8) void k_stream_strided(const uint4 *__restrict__ in, uint32_t *out, int chunks_per_wave)
+{
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_readcyclecounter();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t base = ((size_t)blockIdx.x * 16 + wave) * (size_t)chunks_per_wave * 64;
+  const uint4 *p = in + base + lane * 4;                  // lane stride 64 bytes
+  const int pieces = chunks_per_wave / 4;                 // 4 KiB pieces
+  uint4 q[DEPTH][4];
+#pragma unroll
+  for (int k = 0; k < DEPTH; k++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[k][j] = p[(size_t)k * 256 + j];
+  uint32_t acc = 0;
+  for (int c = 0; c + DEPTH <= pieces; c += DEPTH)
+  {
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++)
+    {
+      const int nxt = min(c + k + DEPTH, pieces - 1);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        uint32_t a = q[k][j].x, b = q[k][j].y, d = q[k][j].z, e = q[k][j].w;
+        q[k][j] = p[(size_t)nxt * 256 + j];
+#pragma unroll
+        for (int i = 0; i < NV / 4; i++)
+          asm volatile("v_pk_add_u16 %0, %0, %1\n v_pk_add_u16 %1, %1, %2\n v_pk_add_u16 %2, %2, %3\n v_pk_add_u16 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(d), "+v"(e));
+        acc += a ^ b ^ d ^ e;
+      }
+    }
+  }
+  if (acc == 0x12345678u) out[blockIdx.x] = acc;
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[4096 + 2 * blockIdx.x] = (uint32_t)(t1 - t0);
+    out[4096 + 2 * blockIdx.x + 1] = (uint32_t)(r1 - r0);
+  }
+}
+
+template <int NV, int DEPTH>
+static void run_strided(const uint4 *in, uint32_t *out, int grid, int cpw, double bytes)
+{
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e9;
+  for (int r = 0; r < 5; r++)
+  {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_stream_strided<NV, DEPTH>), dim3(grid), dim3(1024), 0, 0, in, out, cpw);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0 && ms < best) best = ms;
+  }
+  printf("strided 64 B per lane, NV %3d depth %d x 4 KiB: %.4f ms  %.0f GB/s\n", NV, DEPTH, best, bytes / best / 1e6);
+}
+
 template <int NV, int DEPTH, bool E32, int GATHER>
 static void run(const uint4 *in, uint32_t *out, int grid, int cpw, double bytes, const uint32_t *lut)
 {
@@ -107,6 +170,11 @@ int main()
   run<128, 4, false, 0>(in, out, grid, cpw, bytes, lut);
   run<192, 4, false, 0>(in, out, grid, cpw, bytes, lut);
   run<192, 4, true, 0>(in, out, grid, cpw, bytes, lut);
+  run_strided<0, 1>(in, out, grid, cpw, bytes);
+  run_strided<0, 2>(in, out, grid, cpw, bytes);
+  run_strided<64, 1>(in, out, grid, cpw, bytes);
+  run_strided<96, 1>(in, out, grid, cpw, bytes);
+  run_strided<96, 2>(in, out, grid, cpw, bytes);
   run<0, 4, false, 1>(in, out, grid, cpw, bytes, lut);
   run<64, 4, false, 1>(in, out, grid, cpw, bytes, lut);
   run<96, 4, false, 1>(in, out, grid, cpw, bytes, lut);

@@ -65,6 +65,12 @@ KERNEL(k_mul_u24, asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1,
 KERNEL(k_cmp_e32, asm volatile("v_cmp_gt_u32 vcc, %0, %4\n v_cmp_gt_u32 vcc, %1, %4\n v_cmp_gt_u32 vcc, %2, %4\n v_cmp_gt_u32 vcc, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "vcc");)
 KERNEL(k_xad, asm volatile("v_xad_u32 %0, %0, %4, %5\n v_xad_u32 %1, %1, %4, %5\n v_xad_u32 %2, %2, %4, %5\n v_xad_u32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
 
+// mixed streams: do the fast-class instructions keep their rate between slow-class ones?
+KERNEL(k_mix_add_perm, asm volatile("v_add_u32 %0, %0, %4\n v_perm_b32 %1, %1, %4, %5\n v_add_u32 %2, %2, %4\n v_perm_b32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_mix_3add_perm, asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_perm_b32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_mix_fma_dpp, asm volatile("v_fmac_f32 %0, %4, %5\n v_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_fmac_f32 %2, %4, %5\n v_mov_b32_dpp %3, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+KERNEL(k_mix_dep, asm volatile("v_add_u32 %0, %0, %4\n v_perm_b32 %0, %0, %4, %5\n v_add_u32 %0, %0, %4\n v_perm_b32 %0, %0, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
+
 typedef void (*kern_t)(unsigned long long *, int);
 // grid = 512 workgroups of 1024 threads = 8 waves on every SIMD of the chip; wall clock by
 // HIP events -> ns per wave-instruction per SIMD (a SIMD16 at 2.4 GHz would give 1.67 ns)
@@ -103,6 +109,7 @@ int main()
   RUN(k_mad_u24) RUN(k_dot2) RUN(k_mul_f32) RUN(k_lshl_add) RUN(k_add3) RUN(k_sad_u8) RUN(k_add_sdwa)
   RUN(k_dep_add) RUN(k_dep_mulf) RUN(k_dep_pk)
   RUN(k_add_lit) RUN(k_and_lit) RUN(k_add_sgpr) RUN(k_add_inline) RUN(k_fmaak) RUN(k_fmac) RUN(k_fma_e64) RUN(k_cndmask_vcc) RUN(k_cndmask_e64)
+  RUN(k_mix_add_perm) RUN(k_mix_3add_perm) RUN(k_mix_fma_dpp) RUN(k_mix_dep)
   RUN(k_bfe) RUN(k_lerp) RUN(k_cvt_f32_u32) RUN(k_lshr) RUN(k_mul_u24) RUN(k_cmp_e32) RUN(k_xad)
   return 0;
 }
