@@ -6,7 +6,7 @@ that is already resident in HBM: `channels` independent WBFM channels x `blocks`
 consecutive 262144-byte blocks of int8 IQ (2.048 MS/s) -> 8 kS/s int16 PCM.
 Streams continue from step to step (per-channel state is carried on the device).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: channels are independent, so every rank owns its own `channels`
@@ -249,8 +249,9 @@ def pmc_traffic_bytes(args, C, B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100,
+                    help="untimed steps; the clock governor needs ~25 ms of this load to settle (DESIGN.md 5)")
     ap.add_argument("--channels", type=int, default=256, help="channels per GPU (BASELINE config 2)")
     ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
     ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")

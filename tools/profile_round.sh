@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu > $O/bench_under_rocprof.json 2> $O/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 200 --warmup 100 --no-cpu > $O/bench_under_rocprof.json 2> $O/trace.log
 for CNT in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc_$CNT -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu > /dev/null 2> $O/pmc_$CNT.log
 done
