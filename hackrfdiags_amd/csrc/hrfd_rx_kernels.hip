@@ -36,6 +36,9 @@
 #ifndef HRFD_IIR_U
 #define HRFD_IIR_U 10   /* divides kTile and the warm-up: no scalar tail */
 #endif
+#ifndef HRFD_PRIO_ROTATE
+#define HRFD_PRIO_ROTATE 0   /* experiment: rotating issue priority among the waves of a SIMD -- evens out the waves, 5 % slower */
+#endif
 #ifdef HRFD_ABLATE
 #define HRFD_ABLATE_EARLY HRFD_ABLATE
 #else
@@ -573,6 +576,7 @@ struct StreamCtx
   const float *ati;
   uint4 tab;                     // this thread's 16 bytes of them, loaded at kernel entry (in flight)
   bool publish;                  // ... and still to be published to LDS by this produce_stream call
+  int prio_phase;                // produce_quads: wave id / 4, the phase of the rotating issue priority
   bool first;
 };
 
@@ -1810,6 +1814,18 @@ __device__ __forceinline__ void produce_quads(const StreamCtx &X, const int q0, 
   load_piece(qb, q0 + 1);
   float th_first[2] = {0.0f, 0.0f}, th_last[2] = {0.0f, 0.0f};
   auto step = [&](uint4 (&q)[4], const int piece) {
+#if HRFD_PRIO_ROTATE
+    // The arbiter serves the oldest wave of a SIMD first: without this the youngest wave of
+    // each SIMD is still working while the others wait at the block barrier.  The four waves of a
+    // SIMD (ids w, w+4, w+8, w+12) hold four different priorities that rotate with every piece.
+    switch ((piece + X.prio_phase) & 3)
+    {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#endif
     uint32_t v[4], mag4;
     float theta[4];
     quad_piece<ARITH>(q, c, X, v, theta, mag4);
@@ -1834,6 +1850,9 @@ __device__ __forceinline__ void produce_quads(const StreamCtx &X, const int q0, 
   {
     step(qa, piece);
   }
+#if HRFD_PRIO_ROTATE
+  __builtin_amdgcn_s_setprio(0);
+#endif
   edge[0] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_first[0]), 0);
   edge[1] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_first[1]), 0);
   edge[2] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last[0]), 63);
@@ -1872,11 +1891,28 @@ constexpr int kHoff1 = (kKeepMax + 63) / 64 * 64;
 constexpr int kStreamDepth = HRFD_STREAM_DEPTH;          // raw chunks in flight per stream wave (128 VGPRs per wave)
 constexpr int kStreamFence = HRFD_STREAM_FENCE;          // chunks the scheduler may interleave
 #ifndef HRFD_RUN_CHUNKS
-#define HRFD_RUN_CHUNKS 8   /* two 4 KiB pieces of the quad layout */
+#define HRFD_RUN_CHUNKS 16  /* four 4 KiB pieces of the quad layout */
+#endif
+#ifndef HRFD_RUN_BIG
+#define HRFD_RUN_BIG 12    /* this many runs of kRunChunks ... */
+#endif
+#ifndef HRFD_RUN_SMALL
+#define HRFD_RUN_SMALL 16  /* ... then runs of this many chunks for the late joiners */
 #endif
 constexpr int kRunChunks = HRFD_RUN_CHUNKS;
+constexpr int kRunBig = HRFD_RUN_BIG, kRunSmall = HRFD_RUN_SMALL;
+// run g of a block: first chunk
+__device__ __forceinline__ int run_start(const int g)
+{
+  return (g < kRunBig) ? g * kRunChunks : kRunBig * kRunChunks + (g - kRunBig) * kRunSmall;
+}
+__device__ __forceinline__ int run_count(const int nch)
+{
+  return (nch <= kRunBig * kRunChunks) ? (nch + kRunChunks - 1) / kRunChunks
+                                       : kRunBig + (nch - kRunBig * kRunChunks + kRunSmall - 1) / kRunSmall;
+}
 constexpr int kMaxRuns = 64;                             // one lane of wave 0 patches each run boundary
-static_assert((kMaxN256 + kMaxHal) / 64 <= kRunChunks * kMaxRuns, "runs per block");
+static_assert(kRunBig + ((kMaxN256 + kMaxHal) / 64 - kRunBig * kRunChunks + kRunSmall - 1) / kRunSmall <= kMaxRuns, "runs per block");
 
 __device__ __forceinline__ void svc_barrier(uint32_t *ctr, uint32_t &target, const int lane)
 {
@@ -1974,7 +2010,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
   uint32_t svc_target = 0;
   // the quad layout of phase A needs whole 4 KiB pieces everywhere and has no iq-dump variant
 #ifndef HRFD_NO_QUADS
-  const bool quads = (n256 & 255) == 0 && (hal & 255) == 0 && P.iq256 == nullptr && (kRunChunks & 3) == 0;
+  const bool quads = (n256 & 255) == 0 && (hal & 255) == 0 && P.iq256 == nullptr && (kRunChunks & 3) == 0 && (kRunSmall & 3) == 0;
 #else
   const bool quads = false;
 #endif
@@ -2004,6 +2040,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
     X.ati = atinv;
     X.tab = make_uint4(0u, 0u, 0u, 0u);
     X.publish = false;
+    X.prio_phase = wave >> 2;
     return X;
   };
 
@@ -2017,6 +2054,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
     if (svc && step > b_first)
     {
       // --------------------------------------------------------------- service: phases B and C of block `step - 1`
+#if HRFD_PRIO_ROTATE
+      __builtin_amdgcn_s_setprio(3);                     // long dependent chains, few issue slots: never behind the streaming waves
+#endif
       const uint32_t b = step - 1;
       const int bi = (int)((b - b_first) & 1u);
       uint32_t *lds = bi ? buf1 : buf0;
@@ -2031,7 +2071,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
       if (wave == 0)
       {
         // the two provisional samples at the start of every run (see k_rx_wbfm)
-        const int nruns = (nch + kRunChunks - 1) / kRunChunks;
+        const int nruns = run_count(nch);
         if (cont && lane == 0)
         {
           const float tm1 = tailcarry[0], pm1 = tailcarry[1];
@@ -2044,7 +2084,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
         if (lane >= 1 && lane < nruns)
         {
           const int w = lane;
-          const int sw = X.vstart + 64 * kRunChunks * w;
+          const int sw = X.vstart + 64 * run_start(w);
           const float tm2 = u2f(edges[bi][w - 1][2]), tm1 = u2f(edges[bi][w - 1][3]);
           const float t0 = u2f(edges[bi][w][0]), t1 = u2f(edges[bi][w][1]);
           const float pm1 = numerator_p(tm1, tm2, kgain);
@@ -2375,12 +2415,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
             g = atomicAdd(&grab[bi], 1u);
           }
           g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-          const int c0 = (int)g * kRunChunks;
+          const int c0 = run_start((int)g);
           if (c0 >= nch)
           {
             break;
           }
-          const int c1 = min(c0 + kRunChunks, nch);
+          const int c1 = min(run_start((int)g + 1), nch);
           uint32_t e[4] = {0u, 0u, 0u, 0u};
           if (quads)
           {

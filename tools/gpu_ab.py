@@ -34,13 +34,16 @@ if os.environ.get("HRFD_ATAN"):
     rx.debug_set_atan(int(os.environ["HRFD_ATAN"]))
 if os.environ.get("HRFD_FLAGS"):
     rx.debug_set_stagger(4 + 256 * int(os.environ["HRFD_FLAGS"]))   # run-time ablation flags of old builds
+# the clock governor needs ~25 ms of this load to settle: warm up first, then time 64 launches
+for i in range(int(os.environ.get("HRFD_AB_WARM", "100"))):
+    rx.process_device(x.data_ptr(), B * BLK, BLK, B, pcm.data_ptr())
+rx.sync()
 ts = []
-for rep in range(3):
+for rep in range(8):
     for i in range(8):
         rx.process_device(x.data_ptr(), B * BLK, BLK, B, pcm.data_ptr())
     rx.sync()
     ts += [rx.debug_kernel_ms(i) for i in range(8)]
-ts = ts[8:]
 crc = zlib.crc32(pcm.cpu().numpy().tobytes())
 print(f"kernel ms min {min(ts):.4f} mean {np.mean(ts):.4f} -> {C*B*BLK/np.mean(ts)/1e6:.0f} GB/s  pcm crc {crc:08x}")
 ''' % ROOT
