@@ -71,6 +71,11 @@ KERNEL(k_mix_3add_perm, asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %
 KERNEL(k_mix_fma_dpp, asm volatile("v_fmac_f32 %0, %4, %5\n v_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_fmac_f32 %2, %4, %5\n v_mov_b32_dpp %3, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
 KERNEL(k_mix_dep, asm volatile("v_add_u32 %0, %0, %4\n v_perm_b32 %0, %0, %4, %5\n v_add_u32 %0, %0, %4\n v_perm_b32 %0, %0, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));)
 
+// v_cndmask with the mask in VCC: alone, behind the compare that writes VCC, and in the 64-bit encoding
+KERNEL(k_cmp_cnd_vcc, asm volatile("v_cmp_gt_u32 vcc, %0, %4\n v_cndmask_b32 %1, %1, %4, vcc\n v_cmp_gt_u32 vcc, %2, %4\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "vcc");)
+KERNEL(k_cnd_vcc_e64, asm volatile("v_cndmask_b32_e64 %0, %0, %4, vcc\n v_cndmask_b32_e64 %1, %1, %4, vcc\n v_cndmask_b32_e64 %2, %2, %4, vcc\n v_cndmask_b32_e64 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "vcc");)
+KERNEL(k_cmp_cnd_sgpr, asm volatile("v_cmp_gt_u32 s[20:21], %0, %4\n v_cndmask_b32 %1, %1, %4, s[20:21]\n v_cmp_gt_u32 s[22:23], %2, %4\n v_cndmask_b32 %3, %3, %4, s[22:23]" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "s20", "s21", "s22", "s23");)
+
 typedef void (*kern_t)(unsigned long long *, int);
 // grid = 512 workgroups of 1024 threads = 8 waves on every SIMD of the chip; wall clock by
 // HIP events -> ns per wave-instruction per SIMD (a SIMD16 at 2.4 GHz would give 1.67 ns)
@@ -110,6 +115,7 @@ int main()
   RUN(k_dep_add) RUN(k_dep_mulf) RUN(k_dep_pk)
   RUN(k_add_lit) RUN(k_and_lit) RUN(k_add_sgpr) RUN(k_add_inline) RUN(k_fmaak) RUN(k_fmac) RUN(k_fma_e64) RUN(k_cndmask_vcc) RUN(k_cndmask_e64)
   RUN(k_mix_add_perm) RUN(k_mix_3add_perm) RUN(k_mix_fma_dpp) RUN(k_mix_dep)
+  RUN(k_cmp_cnd_vcc) RUN(k_cnd_vcc_e64) RUN(k_cmp_cnd_sgpr)
   RUN(k_bfe) RUN(k_lerp) RUN(k_cvt_f32_u32) RUN(k_lshr) RUN(k_mul_u24) RUN(k_cmp_e32) RUN(k_xad)
   return 0;
 }
