@@ -500,3 +500,34 @@ def test_odd_shapes_mixed_modes_and_runs(oracle):
             want = o.process(xs[c, b])[0]
             assert n_pcm[c, b] == len(want), (c, m, b)
             assert (pcm[c, b, :len(want)] == want).all(), (c, m, b)
+
+
+@pytest.mark.parametrize("stream", [True, False], ids=["stream_kernel", "per_block_kernel"])
+@pytest.mark.parametrize("bb,dump", [(262144, False), (262144, True), (36864, False), (21504, False), (21504, True)],
+                         ids=["full", "full_iqdump", "n256_2304_quads", "n256_1344_no_quads", "n256_1344_iqdump"])
+def test_wbfm_batches_on_both_kernels_and_layouts(oracle, stream, bb, dump):
+    """WBFM batches through k_rx_wbfm_stream (default) and k_rx_wbfm (hook): the quad layout of phase A
+    (n256 a multiple of 256, no iq dump), its chunk-layout fallbacks, block sizes down to the shortest
+    a batch may have, runs that start with re-derived history (run_len 2 and 3) -- PCM, magnitudes and
+    the 256 kS/s dump bit-exact, every launch committed."""
+    C, B = 3, 6
+    n = C * B * bb
+    raw = np.concatenate([synth.make_input("fmtone" if c else "lcg", 120 + c, (B * bb + BLK - 1) // BLK)[: B * bb]
+                          for c in range(C)]).reshape(C, B, bb)
+    assert raw.size == n
+    for run_len in (0, 2, 3):
+        rx = api.Rx(C)
+        rx.set_mode(api.WBFM)
+        rx.debug_set_stream(stream)
+        rx.debug_set_run_len(run_len)
+        got = rx.process_block(raw, B, want_iq256=dump)
+        for c in range(C):
+            o = oracle.rx()
+            o.set_mode(WBFM)
+            for b in range(B):
+                p, m, _, i = o.process(raw[c, b])
+                assert (got[0][c, b, :len(p)] == p).all(), (stream, bb, run_len, c, b)
+                assert int(got[2][c, b]) == m
+                if dump:
+                    assert (got[4][c, b] == i).all(), (stream, bb, run_len, c, b)
+        assert rx.debug_counters()[5] == 0, "a launch was not committed (replayed instead)"
