@@ -183,6 +183,8 @@ struct hrfd_rx
 
   // measurement hook: HIP events around the demodulator kernels of a launch
   std::vector<hipEvent_t> ev;           // 2 events per slot; slot = launch index % slots
+  hipStream_t side = nullptr;           // the 8 kS/s AM / SSB recurrences run beside the next mode's kernel
+  hipEvent_t ev_fir[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
   uint32_t ev_launches = 0;
 
   // test hooks
@@ -203,6 +205,7 @@ static int rx_free(hrfd_rx *h)
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->side) (void)hipStreamSynchronize(h->side);
   void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_dbfs, h->d_counters,
                   h->d_lists, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
                   h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq};
@@ -214,6 +217,12 @@ static int rx_free(hrfd_rx *h)
   {
     (void)hipEventDestroy(e);
   }
+  for (int i = 0; i < 2; i++)
+  {
+    if (h->ev_fir[i]) (void)hipEventDestroy(h->ev_fir[i]);
+    if (h->ev_post[i]) (void)hipEventDestroy(h->ev_post[i]);
+  }
+  if (h->side) (void)hipStreamDestroy(h->side);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return HRFD_OK;
@@ -264,6 +273,12 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
     return true;
   };
   bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && ok; i++)
+  {
+    ok = hipEventCreateWithFlags(&h->ev_fir[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming) == hipSuccess;
+  }
   ok = ok && alloc((void **)&h->d_cfg, sizeof(ChanCfg) * n_channels);
   ok = ok && alloc((void **)&h->d_state, sizeof(ChanState) * n_channels);
   ok = ok && alloc((void **)&h->d_state_out, sizeof(ChanState) * n_channels);
@@ -783,6 +798,73 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   {
     HIP_TRY(hipEventRecord(h->ev[2 * ev_slot], s));
   }
+  // per-mode dispatch (BASELINE config 3): AM, SSB, FM first, WBFM / NONE last.  The 8 kS/s
+  // recurrences of AM and SSB are one workgroup per channel (a quarter of the chip for a 64-channel
+  // quarter of the bank): they go to a side stream behind their mode's front kernel and run beside
+  // the next mode's; the launch stream joins them before the epilogue.
+  P.dbg = nullptr;
+  int n_side = 0;
+  for (int m : {HRFD_MODE_AM, HRFD_MODE_LSB, HRFD_MODE_USB, HRFD_MODE_FM})
+  {
+    const uint32_t n = h->list_count[m];
+    if (n == 0)
+    {
+      continue;
+    }
+    P.chan_list = h->d_lists + (size_t)m * h->n_channels;
+    P.n_list = n;
+    const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+    if (m == HRFD_MODE_FM)
+    {
+      if (opt.src256)
+      {
+        hipLaunchKernelGGL((k_rx_fir<2, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else if (h->arith_ok && h->atan_mode != 0)
+      {
+        hipLaunchKernelGGL((k_rx_fir<2, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_fir<2, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+    }
+    else if (m == HRFD_MODE_AM)
+    {
+      if (opt.src256)
+      {
+        hipLaunchKernelGGL((k_rx_fir<1, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_fir<1, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      HIP_TRY(hipEventRecord(h->ev_fir[0], s));
+      HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fir[0], 0));
+      hipLaunchKernelGGL(k_rx_post<1>, dim3(n), dim3(256), 0, h->side, P);
+      HIP_TRY(hipEventRecord(h->ev_post[0], h->side));
+      n_side |= 1;
+    }
+    else
+    {
+      if (opt.src256)
+      {
+        hipLaunchKernelGGL((k_rx_fir<4, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_fir<4, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      // (LSB and USB channels are two lists: the side stream keeps their post kernels in order)
+      HIP_TRY(hipEventRecord(h->ev_fir[1], s));
+      HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fir[1], 0));
+      hipLaunchKernelGGL(k_rx_post<4>, dim3(n), dim3(256), 0, h->side, P);
+      HIP_TRY(hipEventRecord(h->ev_post[1], h->side));
+      n_side |= 2;
+    }
+    HIP_TRY(hipGetLastError());
+  }
+
   for (int m : {HRFD_MODE_NONE, HRFD_MODE_WBFM})
   {
     const uint32_t n = h->list_count[m];
@@ -844,61 +926,13 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     }
     HIP_TRY(hipGetLastError());
   }
-  // per-mode dispatch of the other demodulators (BASELINE config 3); the 8 kS/s
-  // recurrences of AM and SSB follow in their own one-workgroup-per-channel kernel
-  P.dbg = nullptr;
-  for (int m : {HRFD_MODE_FM, HRFD_MODE_AM, HRFD_MODE_LSB, HRFD_MODE_USB})
+  for (int i = 0; i < 2; i++)
   {
-    const uint32_t n = h->list_count[m];
-    if (n == 0)
+    if (n_side & (1 << i))
     {
-      continue;
+      HIP_TRY(hipStreamWaitEvent(s, h->ev_post[i], 0));
     }
-    P.chan_list = h->d_lists + (size_t)m * h->n_channels;
-    P.n_list = n;
-    const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
-    if (m == HRFD_MODE_FM)
-    {
-      if (opt.src256)
-      {
-        hipLaunchKernelGGL((k_rx_fir<2, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      else if (h->arith_ok && h->atan_mode != 0)
-      {
-        hipLaunchKernelGGL((k_rx_fir<2, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      else
-      {
-        hipLaunchKernelGGL((k_rx_fir<2, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-    }
-    else if (m == HRFD_MODE_AM)
-    {
-      if (opt.src256)
-      {
-        hipLaunchKernelGGL((k_rx_fir<1, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      else
-      {
-        hipLaunchKernelGGL((k_rx_fir<1, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      hipLaunchKernelGGL(k_rx_post<1>, dim3(n), dim3(256), 0, s, P);
-    }
-    else
-    {
-      if (opt.src256)
-      {
-        hipLaunchKernelGGL((k_rx_fir<4, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      else
-      {
-        hipLaunchKernelGGL((k_rx_fir<4, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      hipLaunchKernelGGL(k_rx_post<4>, dim3(n), dim3(256), 0, s, P);
-    }
-    HIP_TRY(hipGetLastError());
   }
-
   if (ev_slots)
   {
     HIP_TRY(hipEventRecord(h->ev[2 * ev_slot + 1], s));
