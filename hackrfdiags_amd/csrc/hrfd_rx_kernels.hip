@@ -1308,6 +1308,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   const int s = origin + ti * T;
   const bool bwave = wave < kBWaves;
   float y = 0.0f, y_spec = 0.0f;
+  int kskip_tile = 0;
   bool active = false;
   if (P.serial)
   {
@@ -1380,17 +1381,31 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
         y = yanchor;                                     // true y[s - W - 1], saved by the previous block
       }
       const uint32_t *vp = lds + (s - W + hal);          // lane stride T = 2 (mod 4): 64-bit accesses, no bank conflicts
-      uint32_t *yp = lds + (s + hal);
       if (first && wave == 0)
       {
         y = iir_run<false, true>(vp, nullptr, W, kskip, y);
-        y_spec = y;
-        y = iir_run<true, true>(yp, yp, T, kskip - W, y);
       }
       else
       {
         y = iir_run<false, false>(vp, nullptr, W, 0, y);
-        y_spec = y;
+      }
+      y_spec = y;
+      kskip_tile = kskip - W;
+      __builtin_amdgcn_s_setprio(0);
+    }
+    // The first lanes of a wave warm up over tiles of the wave before it: nobody may overwrite v
+    // with y before every warm-up has read it.
+    __syncthreads();
+    if (active)
+    {
+      __builtin_amdgcn_s_setprio(3);
+      uint32_t *yp = lds + (s + hal);
+      if (first && wave == 0)
+      {
+        y = iir_run<true, true>(yp, yp, T, kskip_tile, y);
+      }
+      else
+      {
         y = iir_run<true, false>(yp, yp, T, 0, y);
       }
       __builtin_amdgcn_s_setprio(0);
@@ -2116,6 +2131,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
       const int ti = tid;                                // this lane's tile
       const int s = origin + ti * T;
       float y = 0.0f, y_spec = 0.0f;
+      int kskip_tile = 0;
       bool active = false;
       // B1: partial sums (k_rx_wbfm); tiles that lie in front of this buffer's history slot are never needed
       if (M > 0 && ti < ntiles && s + hoff >= 0)
@@ -2165,17 +2181,30 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
           y = yanchor;
         }
         const uint32_t *vp = lds + (s - W + hoff);
-        uint32_t *yp = lds + (s + hoff);
         if (first && wave == 0)
         {
           y = iir_run<false, true>(vp, nullptr, W, kskip, y);
-          y_spec = y;
-          y = iir_run<true, true>(yp, yp, T, kskip - W, y);
         }
         else
         {
           y = iir_run<false, false>(vp, nullptr, W, 0, y);
-          y_spec = y;
+        }
+        y_spec = y;
+        kskip_tile = kskip - W;
+      }
+      // The first lanes of a wave warm up over tiles of the wave before it: nobody may overwrite v
+      // with y before every warm-up has read it (without this barrier a wave that runs 70 steps ahead
+      // spoils its neighbour's speculated start -- caught by the check, but a repair each time).
+      svc_barrier(&svc_ctr, svc_target, lane);
+      if (active)
+      {
+        uint32_t *yp = lds + (s + hoff);
+        if (first && wave == 0)
+        {
+          y = iir_run<true, true>(yp, yp, T, kskip_tile, y);
+        }
+        else
+        {
           y = iir_run<true, false>(yp, yp, T, 0, y);
         }
         if (lane == 63)
