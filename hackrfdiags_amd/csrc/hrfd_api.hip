@@ -156,7 +156,9 @@ struct hrfd_rx
   bool arith_ok = false;               // corrections fit: k_rx_wbfm computes theta instead of gathering it
   int atan_mode = -1;                  // test hook: -1 auto, 0 force the table gather, 1 require arithmetic
   int32_t *d_dbfs = nullptr;
-  uint32_t *d_counters = nullptr;
+  uint32_t *d_counters = nullptr;       // [kNumDevCounters] + a second set of the per-launch counters [kCntSticky]
+  uint32_t *d_local = nullptr;          // the per-launch counters of the latest launch (set 0 = d_counters, set 1 behind it)
+  int parity = 0;
   uint32_t *d_lists = nullptr;         // [6][n_channels] channel ids grouped by mode
   uint32_t list_count[6] = {0, 0, 0, 0, 0, 0};
 
@@ -286,7 +288,7 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && alloc((void **)&h->d_atcorr, kCorrBytes);
   ok = ok && alloc((void **)&h->d_atinv, sizeof(float) * kInvEntries);
   ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
-  ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * kNumDevCounters);
+  ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * (kNumDevCounters + kCntSticky));
   ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 6 * n_channels);
   if (!ok)
   {
@@ -314,7 +316,8 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   if (e == hipSuccess) e = hipMemcpy(h->d_state_out, init.data(), sizeof(ChanState) * n_channels, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_lut, lut.data(), sizeof(float) * 65536, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_dbfs, dbfs, sizeof(dbfs), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemset(h->d_counters, 0, sizeof(uint32_t) * kNumDevCounters);
+  if (e == hipSuccess) e = hipMemset(h->d_counters, 0, sizeof(uint32_t) * (kNumDevCounters + kCntSticky));
+  h->d_local = h->d_counters;
   // arithmetic atan2: reciprocals from the host (correctly rounded), correction bytes derived on
   // the device from the table just uploaded, with the kernel's own arithmetic (k_build_atan_corr)
   float inv[kInvEntries];
@@ -751,7 +754,11 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       if ((rc = grow((void **)&h->d_ssb_iq, &h->cap_ssb, need)) != HRFD_OK) return rc;
     }
   }
-  HIP_TRY(hipMemsetAsync(h->d_counters, 0, sizeof(uint32_t) * kCntSticky, s));   // the sticky totals survive
+  // per-launch counters: two sets used alternately, each cleared by the previous launch's k_rx_commit
+  h->parity ^= 1;
+  uint32_t *const local = h->parity ? h->d_counters + kNumDevCounters : h->d_counters;
+  uint32_t *const other = h->parity ? h->d_counters : h->d_counters + kNumDevCounters;
+  h->d_local = local;
 
   RxParams P;
   memset(&P, 0, sizeof(P));
@@ -789,7 +796,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.dbfs = h->d_dbfs;
   P.chk_pub = h->d_chk_pub;
   P.chk_spec = h->d_chk_spec;
-  P.counters = h->d_counters;
+  P.counters = local;
   P.dbg = nullptr;
 
   const size_t ev_slots = h->ev.size() / 2;
@@ -954,7 +961,9 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   E.n_pcm = d_n_pcm;
   E.chk_pub = h->d_chk_pub;
   E.chk_spec = h->d_chk_spec;
-  E.counters = h->d_counters;
+  E.counters = local;
+  E.sticky = h->d_counters;
+  E.next_local = other;
   hipLaunchKernelGGL(k_rx_epilogue, dim3(h->n_channels), dim3(64), 0, s, E);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_rx_commit, dim3(h->n_channels), dim3(64), 0, s, E);
@@ -987,7 +996,8 @@ extern "C" int hrfd_rx_sync(hrfd_rx *h, uint32_t *n_violations)
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t s = h->last_stream ? h->last_stream : h->stream;
   HIP_TRY(hipStreamSynchronize(s));
-  HIP_TRY(hipMemcpy(h->last_counters, h->d_counters, sizeof(h->last_counters), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(h->last_counters, h->d_counters, sizeof(h->last_counters), hipMemcpyDeviceToHost));   // the totals
+  HIP_TRY(hipMemcpy(h->last_counters, h->d_local, sizeof(uint32_t) * kCntSticky, hipMemcpyDeviceToHost)); // the latest launch
   h->total_repairs = h->last_counters[kCntTotRepair];
   uint32_t viol = h->last_counters[kCntGate] + h->last_counters[kCntSpec];
   if (viol == 0 && h->last_counters[kCntTotLaunch] != 0 && h->last_counters[kCntCommit] == 0)

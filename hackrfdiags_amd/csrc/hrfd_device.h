@@ -154,7 +154,9 @@ struct EpilogueParams
   uint32_t *n_pcm;             // optional out
   const float *chk_pub;
   const float *chk_spec;
-  uint32_t *counters;          // kCnt*
+  uint32_t *counters;          // kCnt* of THIS launch (kCntRepair .. kCntCommit): one of two sets, used alternately
+  uint32_t *sticky;            // the handle's counter block: kCntSticky.. (totals, kCntPoison) live here
+  uint32_t *next_local;        // the other set: k_rx_commit clears it for the next launch (no memset between launches)
 };
 
 constexpr int kCntRepair = 0;  // de-emphasis tiles re-run in place because their warm-up had not re-synchronised

@@ -185,7 +185,7 @@ extern "C" int hrfd_ingest_submit(hrfd_ingest *g, uint32_t gain_db)
   {
     return rc;
   }
-  HIP_TRY(hipMemcpyAsync(sl.h_counters, rx->d_counters, sizeof(uint32_t) * kNumCounters, hipMemcpyDeviceToHost, cs));
+  HIP_TRY(hipMemcpyAsync(sl.h_counters, rx->d_local, sizeof(uint32_t) * kCntSticky, hipMemcpyDeviceToHost, cs));   // this launch's set
   HIP_TRY(hipEventRecord(sl.e_comp, cs));
   HIP_TRY(hipStreamWaitEvent(g->s_out, sl.e_comp, 0));
   HIP_TRY(hipMemcpyAsync(sl.h_pcm, sl.d_pcm, g->pcm_elems * 2, hipMemcpyDeviceToHost, g->s_out));

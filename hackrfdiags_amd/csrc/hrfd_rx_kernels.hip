@@ -2605,17 +2605,21 @@ __global__ __launch_bounds__(64) void k_rx_commit(const EpilogueParams E)
   const uint32_t c = blockIdx.x;
   const int lane = threadIdx.x;
   // a launch behind an unrepaired failed one started from a stale state: it must not commit
-  const bool clean = (E.counters[kCntGate] | E.counters[kCntSpec] | E.counters[kCntPoison]) == 0u;
+  const bool clean = (E.counters[kCntGate] | E.counters[kCntSpec] | E.sticky[kCntPoison]) == 0u;
   if (c == 0 && lane == 0)
   {
     if (!clean)
     {
-      E.counters[kCntPoison] = 1u;
+      E.sticky[kCntPoison] = 1u;
     }
     E.counters[kCntCommit] = clean ? 1u : 0u;
-    E.counters[kCntTotRepair] += E.counters[kCntRepair];
-    E.counters[kCntTotViol] += clean ? 0u : 1u;
-    E.counters[kCntTotLaunch] += 1u;
+    E.sticky[kCntTotRepair] += E.counters[kCntRepair];
+    E.sticky[kCntTotViol] += clean ? 0u : 1u;
+    E.sticky[kCntTotLaunch] += 1u;
+  }
+  if (c == 0 && lane < kCntSticky)
+  {
+    E.next_local[lane] = 0u;                             // the next launch counts into the other set
   }
   if (c >= E.n_channels || !clean)
   {
