@@ -24,7 +24,10 @@ namespace hrfd {
 constexpr int HRFD_MOD_RAILS = 100;     // internal kind: int16 (I,Q) rails in, modulator tables
 constexpr int HRFD_MOD_WB_HEAD = 101;   // WBFM modulator: (pcm, 0) pairs in, rail 0 after stage 5 out (x32)
 constexpr int HRFD_MOD_WB_TAIL = 102;   // WBFM modulator: 256 kS/s (I,Q) rails in, stages 6-8 (x8)
-constexpr int kModTile = 32;            // input samples per workgroup
+#ifndef HRFD_MOD_TILE
+#define HRFD_MOD_TILE 32
+#endif
+constexpr int kModTile = HRFD_MOD_TILE;  // input samples per workgroup
 constexpr int kModThreads = 256;
 constexpr int kModTail = 64;            // carried input history per channel (>= 54)
 
