@@ -531,3 +531,24 @@ def test_wbfm_batches_on_both_kernels_and_layouts(oracle, stream, bb, dump):
                 if dump:
                     assert (got[4][c, b] == i).all(), (stream, bb, run_len, c, b)
         assert rx.debug_counters()[5] == 0, "a launch was not committed (replayed instead)"
+
+
+@pytest.mark.parametrize("C,B,bb", [(5, 17, 65536), (1, 2, 262144), (9, 33, 32768)])
+def test_wbfm_batches_with_ragged_runs(oracle, C, B, bb):
+    """block counts that leave a short last run (17 = 16 + 1, 33 = 2 x 16 + 1: a run of ONE block that
+    re-derives its history), channel counts that are not a multiple of 8 (idle workgroups), two calls"""
+    raw = np.concatenate([synth.make_input("lcg" if c % 2 else "fmtone", 200 + c, (2 * B * bb + BLK - 1) // BLK)[: 2 * B * bb]
+                          for c in range(C)]).reshape(C, 2 * B, bb)
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    got = [rx.process_block(np.ascontiguousarray(raw[:, :B]), B), rx.process_block(np.ascontiguousarray(raw[:, B:]), B)]
+    pcm = np.concatenate([g[0] for g in got], axis=1)
+    mag = np.concatenate([g[2] for g in got], axis=1)
+    for c in range(C):
+        o = oracle.rx()
+        o.set_mode(WBFM)
+        for b in range(2 * B):
+            p, m, _, _ = o.process(raw[c, b])
+            assert (pcm[c, b, :len(p)] == p).all(), (C, B, bb, c, b)
+            assert int(mag[c, b]) == m
+    assert rx.debug_counters()[5] == 0
