@@ -1022,6 +1022,234 @@ __device__ __forceinline__ float deemph_pow(int n)
   return exp2f((float)n * -0.07517338f);                 // log2(0.9492274)
 }
 
+// ---- phase B: the de-emphasis recurrence of one block, in place (v -> y) ------------------------
+// Shared by k_rx_wbfm (every wave of the workgroup calls it, `sync` is the workgroup barrier) and
+// k_rx_wbfm_stream (the four service waves call it, `sync` is their counter barrier); the waves
+// 0..kBWaves-1 own the tiles.  See the comment in k_rx_wbfm for the scheme (partial sums, seeds,
+// warm-up, tiles, verification, repair).  hoff = index of position 0 in lds[].
+struct RecurShared
+{
+  float *parr;                    // [kMaxTiles + 8] partial sums; in the repair path the speculated starts
+  float *wfin;                    // [kBWaves] final y of each wave's last lane
+  unsigned long long *badmask;    // [kBWaves]
+  uint32_t *anybad;               // zeroed by the caller before the first sync of the block
+  const float *yanchor;           // true y in front of tile j0's warm-up (continuation blocks)
+};
+
+template <int MODE, bool S256, bool ARITH, bool PERBLOCK, class Sync>
+__device__ __forceinline__ void recurrence_phase(const RxParams &P, const StreamCtx &X, uint32_t *lds, const int hoff,
+                                                 const RecurShared &R, const bool first, const bool cont,
+                                                 const int wave, const int lane, Sync &&sync)
+{
+  constexpr int T = kTile;
+  const int wt = P.warm_tiles, M = P.seed_terms;
+  const int W = wt * T;
+  const int ntiles = P.ntiles, origin = P.origin;
+  const int j0 = (-origin) / T;                          // the tile that contains (or begins at) position 0
+  const int fa = (first || cont) ? j0 : (wt + M);        // first lane that runs; it is anchored
+  const float a1 = DEEMPH_A1;
+  const bool bwave = wave < kBWaves;
+  const int ti = wave * 64 + lane;                       // this lane's tile (waves >= kBWaves have none)
+  const int s = origin + ti * T;
+  const ChanState *st = X.st;
+  float y = 0.0f, y_spec = 0.0f;
+  int kskip_tile = 0;
+  // B1: partial sums  P_i = sum_k c^k v[s + T-1 - k], c = -a1, as two interleaved Horner chains in c^2
+  // (tiles that lie in front of this buffer's history slot are never needed)
+  if (bwave && M > 0 && ti < ntiles && s + hoff >= 0 && !ablate(P, 2))
+  {
+    const float cc = -a1;
+    const float c2 = cc * cc;
+    const uint2 *p2 = reinterpret_cast<const uint2 *>(lds + (s + hoff));
+    float pa = 0.0f, pb = 0.0f;
+#pragma unroll 7
+    for (int j = 0; j < T / 2; j++)
+    {
+      const uint2 w = p2[j];
+      pa = __builtin_fmaf(pa, c2, u2f(w.x));
+      pb = __builtin_fmaf(pb, c2, u2f(w.y));
+    }
+    float p = __builtin_fmaf(pa, cc, pb);
+    if (first && ti == j0)
+    {
+      p += deemph_pow(s + T) * st->wb_y;                 // the stream's past, as seen from the end of this tile
+    }
+    R.parr[ti] = p;
+  }
+  sync();                                                // partial sums visible; every read of the v tail is done
+  const bool active = bwave && ti >= fa && ti < ntiles && !ablate(P, 2);   // (flag 2: TIMING EXPERIMENT ONLY, skip phase B)
+  if (active)
+  {
+    // the recurrence is a long dependent chain that needs few issue slots: in k_rx_wbfm let it
+    // win arbitration against the streaming waves of the neighbouring workgroup
+    if (PERBLOCK)
+    {
+      __builtin_amdgcn_s_setprio(3);
+    }
+    if (M > 0)
+    {
+      // y at the end of tile ti - wt - 1:  sum_{m < M} (c^T)^m P[ti - wt - 1 - m], oldest first
+      float acc = 0.0f;
+      for (int m = M; m >= 1; m--)
+      {
+        acc = __builtin_fmaf(acc, P.seed_ct, R.parr[ti - wt - m]);
+      }
+      y = acc;
+    }
+    int kskip = 0;
+    if (first)
+    {
+      if (s <= W)
+      {
+        // the start lies at or before the stream start: carried y, steps at n < 0 skipped
+        y = st->wb_y;
+        kskip = W - s;
+      }
+    }
+    else if (cont && ti == j0)
+    {
+      y = *R.yanchor;                                    // true y[s - W - 1], saved by the previous block
+    }
+    const uint32_t *vp = lds + (s - W + hoff);           // lane stride T = 2 (mod 4): 64-bit accesses, no bank conflicts
+    if (first && wave == 0)
+    {
+      y = iir_run<false, true>(vp, nullptr, W, kskip, y);
+    }
+    else
+    {
+      y = iir_run<false, false>(vp, nullptr, W, 0, y);
+    }
+    y_spec = y;
+    kskip_tile = kskip - W;
+    if (PERBLOCK)
+    {
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  // The first lanes of a wave warm up over tiles of the wave before it: nobody may overwrite v
+  // with y before every warm-up has read it (without this barrier a wave that runs 70 steps ahead
+  // spoils its neighbour's speculated start -- caught by the check, but a repair each time).
+  sync();
+  if (active)
+  {
+    if (PERBLOCK)
+    {
+      __builtin_amdgcn_s_setprio(3);
+    }
+    uint32_t *yp = lds + (s + hoff);
+    if (first && wave == 0)
+    {
+      y = iir_run<true, true>(yp, yp, T, kskip_tile, y);
+    }
+    else
+    {
+      y = iir_run<true, false>(yp, yp, T, 0, y);
+    }
+    if (PERBLOCK)
+    {
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (lane == 63)
+    {
+      R.wfin[wave] = y;
+      if (PERBLOCK && P.dbg != nullptr)
+      {
+        P.dbg[(size_t)blockIdx.x * kDbgSlots + 24 + wave] = __builtin_readcyclecounter();
+      }
+    }
+  }
+  sync();                                                // all chains done
+  // B3: every lane but the anchored one checks its speculated start against its left neighbour's end
+  if (bwave)
+  {
+    float y_left = u2f(shr1(f2u(y), f2u(y)));
+    if (lane == 0 && wave > 0)
+    {
+      y_left = R.wfin[wave - 1];
+    }
+    const bool bad = active && ti > fa && !same_trajectory(y_left, y_spec);
+    const unsigned long long bm = __ballot(bad);
+    if (lane == 0)
+    {
+      R.badmask[wave] = bm;
+      if (bm != 0ull)
+      {
+        *R.anybad = 1u;
+      }
+    }
+  }
+  sync();
+  if (*R.anybad != 0u)
+  {
+    // rare: repair in ascending order.  A tile's true start is the y in front of it in the
+    // buffer (its left neighbour is final by then); the speculated starts go to parr[].
+    if (bwave && ti < ntiles)
+    {
+      R.parr[ti] = y_spec;
+    }
+    sync();
+    if (wave == 0)
+    {
+      unsigned long long bm[kBWaves];
+#pragma unroll
+      for (int w = 0; w < kBWaves; w++)
+      {
+        bm[w] = R.badmask[w];
+      }
+      uint32_t repairs = 0;
+#pragma unroll
+      for (int w = 0; w < kBWaves; w++)
+      {
+        while (bm[w] != 0ull)
+        {
+          const int l = __ffsll((long long)bm[w]) - 1;   // wave-uniform
+          bm[w] &= ~(1ull << l);
+          repairs++;
+          const int j = w * 64 + l;
+          const int sj = origin + j * T;
+          // re-derive v over tile j (it was overwritten by the mis-started y)
+          const int rc0 = (sj - X.vstart) >> 6;
+          const int rc1 = (sj + T - X.vstart + 63) >> 6;
+          uint32_t dummy_mag = 0, dummy_e[4];
+          produce_stream<MODE, true, false, S256, ARITH>(X, rc0, rc1, sj, sj + T, dummy_mag, dummy_e);
+          if (lane == 0)
+          {
+            uint32_t *rp = lds + (sj + hoff);
+            const float y_true = u2f(rp[-1]);
+            iir_run<true, false>(rp, rp, T, 0, y_true);
+          }
+          // the right neighbour's speculation must now match the corrected final y
+          if (j + 1 < ntiles)
+          {
+            const float yj = u2f(lds[sj + T - 1 + hoff]);
+            const float sp = R.parr[j + 1];
+            if (!same_trajectory(yj, sp))
+            {
+              if (l == 63)
+              {
+                if (w + 1 < kBWaves)
+                {
+                  bm[w + 1 < kBWaves ? w + 1 : w] |= 1ull;
+                }
+              }
+              else
+              {
+                bm[w] |= 1ull << (l + 1);
+              }
+            }
+          }
+        }
+      }
+      if (lane == 0)
+      {
+        atomicAdd(&P.counters[kCntRepair], repairs);
+      }
+    }
+    sync();
+  }
+}
+
+
 template <int MODE, bool S256, bool ARITH>
 __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 {
@@ -1256,9 +1484,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   //   other blocks (b > 0, first of a run): history re-derived from the raw input; the first
   //     wt + M lanes cannot be seeded and do not run; lane wt + M is checked across blocks by
   //     k_rx_epilogue (y at -645 as computed here vs. by the predecessor).
-  const int ntiles = P.ntiles, origin = P.origin;
+  const int origin = P.origin;
   const int j0 = (-origin) / T;                          // the tile that contains (or begins at) position 0
-  const int fa = (first || cont) ? j0 : (wt + M);        // first lane that runs; it is anchored
   HRFD_STAMP(2)
   if (wave == 0)
   {
@@ -1303,19 +1530,13 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
     // behind the next barrier, overwrite it with y)
     keep0 = (tid < nkeep) ? lds[n256 - nkeep + tid + hal] : 0u;
   }
-  const float a1 = DEEMPH_A1;
-  const int ti = wave * 64 + lane;                       // this lane's tile (waves >= kBWaves have none)
-  const int s = origin + ti * T;
-  const bool bwave = wave < kBWaves;
-  float y = 0.0f, y_spec = 0.0f;
-  int kskip_tile = 0;
-  bool active = false;
   if (P.serial)
   {
     // exact replay path (n_blocks == 1): one lane, the whole block in order
     __syncthreads();
     if (tid == 0)
     {
+      const float a1 = DEEMPH_A1;
       float ys = st->wb_y;
       for (int n = 0; n < n256; n++)
       {
@@ -1328,185 +1549,8 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
   }
   else
   {
-    // B1: partial sums  P_i = sum_k c^k v[s + T-1 - k], c = -a1, as two interleaved Horner chains in c^2
-    if (bwave && M > 0 && ti < ntiles && !ablate(P, 2))
-    {
-      const float cc = -a1;
-      const float c2 = cc * cc;
-      const uint2 *p2 = reinterpret_cast<const uint2 *>(lds + (s + hal));
-      float pa = 0.0f, pb = 0.0f;
-#pragma unroll 7
-      for (int j = 0; j < T / 2; j++)
-      {
-        const uint2 w = p2[j];
-        pa = __builtin_fmaf(pa, c2, u2f(w.x));
-        pb = __builtin_fmaf(pb, c2, u2f(w.y));
-      }
-      float p = __builtin_fmaf(pa, cc, pb);
-      if (first && ti == j0)
-      {
-        p += deemph_pow(s + T) * st->wb_y;               // the stream's past, as seen from the end of this tile
-      }
-      parr[ti] = p;
-    }
-    __syncthreads();                                     // partial sums visible; every keep0 read is done
-    active = bwave && ti >= fa && ti < ntiles && !ablate(P, 2);   // (flag 2: TIMING EXPERIMENT ONLY, skip phase B)
-    if (active)
-    {
-      // the recurrence is a long dependent chain that needs few issue slots: let it
-      // win arbitration against the streaming waves of the neighbouring workgroup
-      __builtin_amdgcn_s_setprio(3);
-      if (M > 0)
-      {
-        // y at the end of tile ti - wt - 1:  sum_{m < M} (c^T)^m P[ti - wt - 1 - m], oldest first
-        float acc = 0.0f;
-        for (int m = M; m >= 1; m--)
-        {
-          acc = __builtin_fmaf(acc, P.seed_ct, parr[ti - wt - m]);
-        }
-        y = acc;
-      }
-      int kskip = 0;
-      if (first)
-      {
-        if (s <= W)
-        {
-          // the start lies at or before the stream start: carried y, steps at n < 0 skipped
-          y = st->wb_y;
-          kskip = W - s;
-        }
-      }
-      else if (cont && ti == j0)
-      {
-        y = yanchor;                                     // true y[s - W - 1], saved by the previous block
-      }
-      const uint32_t *vp = lds + (s - W + hal);          // lane stride T = 2 (mod 4): 64-bit accesses, no bank conflicts
-      if (first && wave == 0)
-      {
-        y = iir_run<false, true>(vp, nullptr, W, kskip, y);
-      }
-      else
-      {
-        y = iir_run<false, false>(vp, nullptr, W, 0, y);
-      }
-      y_spec = y;
-      kskip_tile = kskip - W;
-      __builtin_amdgcn_s_setprio(0);
-    }
-    // The first lanes of a wave warm up over tiles of the wave before it: nobody may overwrite v
-    // with y before every warm-up has read it.
-    __syncthreads();
-    if (active)
-    {
-      __builtin_amdgcn_s_setprio(3);
-      uint32_t *yp = lds + (s + hal);
-      if (first && wave == 0)
-      {
-        y = iir_run<true, true>(yp, yp, T, kskip_tile, y);
-      }
-      else
-      {
-        y = iir_run<true, false>(yp, yp, T, 0, y);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (lane == 63)
-      {
-        wfin[wave] = y;
-        if (P.dbg != nullptr)
-        {
-          P.dbg[(size_t)blockIdx.x * kDbgSlots + 24 + wave] = __builtin_readcyclecounter();
-        }
-      }
-    }
-    __syncthreads();                                     // all chains done
-    // B3: every lane but the anchored one checks its speculated start against its left neighbour's end
-    if (bwave)
-    {
-      float y_left = u2f(shr1(f2u(y), f2u(y)));
-      if (lane == 0 && wave > 0)
-      {
-        y_left = wfin[wave - 1];
-      }
-      const bool bad = active && ti > fa && !same_trajectory(y_left, y_spec);
-      const unsigned long long bm = __ballot(bad);
-      if (lane == 0)
-      {
-        badmask[wave] = bm;
-        if (bm != 0ull)
-        {
-          anybad = 1u;
-        }
-      }
-    }
-    __syncthreads();
-    if (anybad != 0u)
-    {
-      // rare: repair in ascending order.  A tile's true start is the y in front of it in the
-      // buffer (its left neighbour is final by then); the speculated starts go to parr[].
-      if (bwave && ti < ntiles)
-      {
-        parr[ti] = y_spec;
-      }
-      __syncthreads();
-      if (wave == 0)
-      {
-        unsigned long long bm[kBWaves];
-#pragma unroll
-        for (int w = 0; w < kBWaves; w++)
-        {
-          bm[w] = badmask[w];
-        }
-        uint32_t repairs = 0;
-#pragma unroll
-        for (int w = 0; w < kBWaves; w++)
-        {
-          while (bm[w] != 0ull)
-          {
-            const int l = __ffsll((long long)bm[w]) - 1;   // wave-uniform
-            bm[w] &= ~(1ull << l);
-            repairs++;
-            const int j = w * 64 + l;
-            const int sj = origin + j * T;
-            // re-derive v over tile j (it was overwritten by the mis-started y)
-            const int rc0 = (sj - X.vstart) >> 6;
-            const int rc1 = (sj + T - X.vstart + 63) >> 6;
-            uint32_t dummy_mag = 0, dummy_e[4];
-            produce_stream<MODE, true, false, S256, ARITH>(X, rc0, rc1, sj, sj + T, dummy_mag, dummy_e);
-            if (lane == 0)
-            {
-              uint32_t *rp = lds + (sj + hal);
-              const float y_true = u2f(rp[-1]);
-              iir_run<true, false>(rp, rp, T, 0, y_true);
-            }
-            // the right neighbour's speculation must now match the corrected final y
-            if (j + 1 < ntiles)
-            {
-              const float yj = u2f(lds[sj + T - 1 + hal]);
-              const float sp = parr[j + 1];
-              if (!same_trajectory(yj, sp))
-              {
-                if (l == 63)
-                {
-                  if (w + 1 < kBWaves)
-                  {
-                    bm[w + 1 < kBWaves ? w + 1 : w] |= 1ull;
-                  }
-                }
-                else
-                {
-                  bm[w] |= 1ull << (l + 1);
-                }
-              }
-            }
-          }
-        }
-        if (lane == 0)
-        {
-          atomicAdd(&P.counters[kCntRepair], repairs);
-        }
-      }
-      __syncthreads();
-    }
+    const RecurShared R = {parr, wfin, badmask, &anybad, &yanchor};
+    recurrence_phase<MODE, S256, ARITH, true>(P, X, lds, hal, R, first, cont, wave, lane, [] { __syncthreads(); });
   }
   HRFD_STAMP(3)
   HRFD_STAMP(4)
@@ -2013,14 +2057,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
   const int wt = P.warm_tiles, M = P.seed_terms;
   const int W = wt * T;
   const int nkeep = (wt + M + 1) * T;
-  const int ntiles = P.ntiles, origin = P.origin;
+  const int origin = P.origin;
   const int j0 = (-origin) / T;
   const ChanState *st = P.state + c;
   ChanState *so = P.state_out + c;
   const ChanCfg cfg = P.cfg[c];
   float kgain = cfg.gain_wbfm / 75000.0f;                // K = (gain/75000)*32767 in float, that order
   kgain = kgain * 32767.0f;
-  const float a1 = DEEMPH_A1;
   const bool small_y = fabsf(kgain) * 3.3f < 2147483000.0f;   // NaN gain: false
   uint32_t svc_target = 0;
   // the quad layout of phase A needs whole 4 KiB pieces everywhere and has no iq-dump variant
@@ -2081,7 +2124,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
       const bool last = (b + 1 == P.n_blocks);
       const size_t unit = (size_t)c * P.n_blocks + b;
       const StreamCtx X = make_ctx(b, lds, hoff);
-      const int fa = (first || cont) ? j0 : (wt + M);
       const int nch = (n256 - X.vstart) >> 6;
       if (wave == 0)
       {
@@ -2128,172 +2170,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P
           nl[nh - nkeep + i] = lds[n256 - nkeep + i + hoff];
         }
       }
-      const int ti = tid;                                // this lane's tile
-      const int s = origin + ti * T;
-      float y = 0.0f, y_spec = 0.0f;
-      int kskip_tile = 0;
-      bool active = false;
-      // B1: partial sums (k_rx_wbfm); tiles that lie in front of this buffer's history slot are never needed
-      if (M > 0 && ti < ntiles && s + hoff >= 0)
       {
-        const float cc = -a1;
-        const float c2 = cc * cc;
-        const uint2 *p2 = reinterpret_cast<const uint2 *>(lds + (s + hoff));
-        float pa = 0.0f, pb = 0.0f;
-#pragma unroll 7
-        for (int j = 0; j < T / 2; j++)
-        {
-          const uint2 w = p2[j];
-          pa = __builtin_fmaf(pa, c2, u2f(w.x));
-          pb = __builtin_fmaf(pb, c2, u2f(w.y));
-        }
-        float p = __builtin_fmaf(pa, cc, pb);
-        if (first && ti == j0)
-        {
-          p += deemph_pow(s + T) * st->wb_y;
-        }
-        parr[ti] = p;
-      }
-      svc_barrier(&svc_ctr, svc_target, lane);           // partial sums visible; the tail copy has read v
-      active = ti >= fa && ti < ntiles;
-      if (active)
-      {
-        if (M > 0)
-        {
-          float acc = 0.0f;
-          for (int m = M; m >= 1; m--)
-          {
-            acc = __builtin_fmaf(acc, P.seed_ct, parr[ti - wt - m]);
-          }
-          y = acc;
-        }
-        int kskip = 0;
-        if (first)
-        {
-          if (s <= W)
-          {
-            y = st->wb_y;
-            kskip = W - s;
-          }
-        }
-        else if (cont && ti == j0)
-        {
-          y = yanchor;
-        }
-        const uint32_t *vp = lds + (s - W + hoff);
-        if (first && wave == 0)
-        {
-          y = iir_run<false, true>(vp, nullptr, W, kskip, y);
-        }
-        else
-        {
-          y = iir_run<false, false>(vp, nullptr, W, 0, y);
-        }
-        y_spec = y;
-        kskip_tile = kskip - W;
-      }
-      // The first lanes of a wave warm up over tiles of the wave before it: nobody may overwrite v
-      // with y before every warm-up has read it (without this barrier a wave that runs 70 steps ahead
-      // spoils its neighbour's speculated start -- caught by the check, but a repair each time).
-      svc_barrier(&svc_ctr, svc_target, lane);
-      if (active)
-      {
-        uint32_t *yp = lds + (s + hoff);
-        if (first && wave == 0)
-        {
-          y = iir_run<true, true>(yp, yp, T, kskip_tile, y);
-        }
-        else
-        {
-          y = iir_run<true, false>(yp, yp, T, 0, y);
-        }
-        if (lane == 63)
-        {
-          wfin[wave] = y;
-        }
-      }
-      svc_barrier(&svc_ctr, svc_target, lane);           // all chains done
-      {
-        float y_left = u2f(shr1(f2u(y), f2u(y)));
-        if (lane == 0 && wave > 0)
-        {
-          y_left = wfin[wave - 1];
-        }
-        const bool bad = active && ti > fa && !same_trajectory(y_left, y_spec);
-        const unsigned long long bm = __ballot(bad);
-        if (lane == 0)
-        {
-          badmask[wave] = bm;
-          if (bm != 0ull)
-          {
-            anybad = 1u;
-          }
-        }
-      }
-      svc_barrier(&svc_ctr, svc_target, lane);
-      if (anybad != 0u)
-      {
-        if (ti < ntiles)
-        {
-          parr[ti] = y_spec;
-        }
-        svc_barrier(&svc_ctr, svc_target, lane);
-        if (wave == 0)
-        {
-          unsigned long long bm[kBWaves];
-#pragma unroll
-          for (int w = 0; w < kBWaves; w++)
-          {
-            bm[w] = badmask[w];
-          }
-          uint32_t repairs = 0;
-#pragma unroll
-          for (int w = 0; w < kBWaves; w++)
-          {
-            while (bm[w] != 0ull)
-            {
-              const int l = __ffsll((long long)bm[w]) - 1;
-              bm[w] &= ~(1ull << l);
-              repairs++;
-              const int j = w * 64 + l;
-              const int sj = origin + j * T;
-              const int rc0 = (sj - X.vstart) >> 6;
-              const int rc1 = (sj + T - X.vstart + 63) >> 6;
-              uint32_t dummy_mag = 0, dummy_e[4];
-              produce_stream<3, true, false, false, ARITH>(X, rc0, rc1, sj, sj + T, dummy_mag, dummy_e);
-              if (lane == 0)
-              {
-                uint32_t *rp = lds + (sj + hoff);
-                const float y_true = u2f(rp[-1]);
-                iir_run<true, false>(rp, rp, T, 0, y_true);
-              }
-              if (j + 1 < ntiles)
-              {
-                const float yj = u2f(lds[sj + T - 1 + hoff]);
-                const float sp = parr[j + 1];
-                if (!same_trajectory(yj, sp))
-                {
-                  if (l == 63)
-                  {
-                    if (w + 1 < kBWaves)
-                    {
-                      bm[w + 1 < kBWaves ? w + 1 : w] |= 1ull;
-                    }
-                  }
-                  else
-                  {
-                    bm[w] |= 1ull << (l + 1);
-                  }
-                }
-              }
-            }
-          }
-          if (lane == 0)
-          {
-            atomicAdd(&P.counters[kCntRepair], repairs);
-          }
-        }
-        svc_barrier(&svc_ctr, svc_target, lane);
+        const RecurShared R = {parr, wfin, badmask, &anybad, &yanchor};
+        recurrence_phase<3, false, ARITH, false>(P, X, lds, hoff, R, first, cont, wave, lane,
+                                                 [&] { svc_barrier(&svc_ctr, svc_target, lane); });
       }
       if (tid == 0)
       {
