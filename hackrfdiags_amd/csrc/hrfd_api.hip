@@ -342,7 +342,7 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
     rx_free(h);
     return rc;
   }
-  h->arith_ok = (bad == 0);
+  h->arith_ok = (bad == 0) || (HRFD_ABLATE & 512) != 0;   // (512: TIMING EXPERIMENT ONLY)
   *out = h;
   return HRFD_OK;
 }

@@ -260,6 +260,17 @@ struct AtanApprox
 
 __device__ __forceinline__ AtanApprox atan2_approx(uint32_t a, uint32_t b, bool swap, bool negi, float inv_a)
 {
+#if (HRFD_ABLATE_EARLY & 512)
+  // TIMING EXPERIMENT ONLY: phi straight from the LDS word (what a first-octant float table would cost)
+  {
+    float v = swap ? (kPi2F - inv_a) : inv_a;
+    v = negi ? (kPiF - v) : v;
+    AtanApprox o;
+    o.theta0 = v;
+    o.shift = (swap ? 2u : 0u) | (negi ? 4u : 0u);
+    return o;
+  }
+#endif
   const float bf = (float)b, af = (float)a;
   const float r0 = bf * inv_a;
   const float e = __builtin_fmaf(-af, r0, bf);
@@ -296,7 +307,11 @@ __device__ __forceinline__ float theta_arith(uint32_t mixed, const uint8_t *corr
   const float inv_a = 0.0078125f;
 #else
   const uint32_t code8 = corr[tri];
+#if (HRFD_ABLATE_EARLY & 512)
+  const float inv_a = inv[tri & 127u];
+#else
   const float inv_a = inv[a];
+#endif
 #endif
   const bool negi = (mixed & 0x00000080u) == 0u;
   const AtanApprox ap = atan2_approx(a, b, swap, negi, inv_a);
