@@ -110,17 +110,18 @@ class Rx:
         return float(ms.value)
 
     def debug_stamps(self, groups: int, read: bool = False):
-        """groups > 0, read=False: allocate stamp storage; read=True: fetch [groups, 32] uint64 (kDbgSlots)."""
+        """groups > 0, read=False: allocate stamp storage; read=True: fetch [groups, 48] uint64 (kDbgSlots)."""
         if not read:
             check(self.L.hrfd_rx_debug_stamps(self.h, groups, None), "hrfd_rx_debug_stamps")
             return None
-        out = np.zeros((groups, 32), dtype=np.uint64)
+        out = np.zeros((groups, 48), dtype=np.uint64)
         check(self.L.hrfd_rx_debug_stamps(self.h, groups, _ptr(out)), "hrfd_rx_debug_stamps")
         return out
 
-    def debug_set_stream(self, on: bool):
-        """test hook: False = WBFM batches on k_rx_wbfm instead of k_rx_wbfm_stream"""
-        check(self.L.hrfd_rx_debug_set_stream(self.h, 1 if on else 0), "hrfd_rx_debug_set_stream")
+    def debug_set_stream(self, kernel):
+        """test hook: WBFM batches on 0 / False = k_rx_wbfm, 1 / True = k_rx_wbfm_stream,
+        2 = k_rx_wbfm_flow where it applies (the default)"""
+        check(self.L.hrfd_rx_debug_set_stream(self.h, int(kernel)), "hrfd_rx_debug_set_stream")
 
     def debug_set_stagger(self, units: int):
         check(self.L.hrfd_rx_debug_set_stagger(self.h, units), "hrfd_rx_debug_set_stagger")

@@ -195,7 +195,7 @@ struct hrfd_rx
   int warm = kWarm;
   int stagger = 4;
   int run_len = 0;                     // test hook: blocks per workgroup run of k_rx_wbfm (0 = automatic)
-  int use_stream = 1;                  // test hook: 0 = batches use k_rx_wbfm instead of k_rx_wbfm_stream
+  int use_stream = 2;                  // test hook: WBFM batches on 0 = k_rx_wbfm, 1 = k_rx_wbfm_stream, 2 = k_rx_wbfm_flow (where it applies)
   uint32_t last_counters[kNumCounters] = {0};
 };
 
@@ -555,7 +555,7 @@ extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
   {
     return fail(HRFD_EINVAL, "NULL");
   }
-  h->use_stream = on ? 1 : 0;
+  h->use_stream = (on < 0 || on > 2) ? 2 : on;
   return HRFD_OK;
 }
 
@@ -797,6 +797,8 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.chk_pub = h->d_chk_pub;
   P.chk_spec = h->d_chk_spec;
   P.counters = local;
+  P.flow_hal = 1536;           // >= 768 + 64 * (warm_tiles + seed_terms + 1), whole units
+  P.flow_seed_ct = (float)pow(-(double)DEEMPH_A1, 64.0);
   P.dbg = nullptr;
 
   const size_t ev_slots = h->ev.size() / 2;
@@ -886,6 +888,9 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     // k_rx_wbfm_stream holds one workgroup per CU (256), k_rx_wbfm two (512)
     const uint32_t groups = 8u * ((n + 7u) / 8u);
     const bool streaming = (m == HRFD_MODE_WBFM) && h->use_stream && n_blocks > 1 && !opt.serial && !opt.src256;
+    // k_rx_wbfm_flow: whole units of two 4 KiB pieces, no iq dump, the arithmetic atan2
+    const bool flow = streaming && h->use_stream == 2 && h->arith_ok && h->atan_mode != 0 && d_iq256 == nullptr &&
+                      (n256 % 512u) == 0 && n256 >= 2048u;
     const uint32_t fill = streaming ? 256u : 512u;
     uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : (streaming ? 16u : 8u);
     run_len = std::min(run_len, n_blocks);
@@ -910,6 +915,10 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       if (opt.src256)
       {
         hipLaunchKernelGGL((k_rx_wbfm<3, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      }
+      else if (flow)
+      {
+        hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       else if (streaming)
       {

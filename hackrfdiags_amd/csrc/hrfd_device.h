@@ -137,6 +137,8 @@ struct RxParams
   float *chk_pub;              // [C][n_blocks] y at (n256 - kHist + 59) of this block
   float *chk_spec;             // [C][n_blocks] y at (-kHist + 59) as speculated by this block
   uint32_t *counters;          // kCnt*
+  int32_t flow_hal;            // k_rx_wbfm_flow: history samples in front of a run that does not start the call (multiple of 512)
+  float flow_seed_ct;          // k_rx_wbfm_flow: (-a1)^64
   unsigned long long *dbg;     // optional [grid][kDbgSlots] s_memtime stamps at phase boundaries (diagnostic builds of bench only)
 };
 
@@ -172,7 +174,7 @@ constexpr int kNumCounters = 8;   // counters visible through hrfd_rx_debug_coun
 constexpr int kCntPoison = 8;     // sticky: a launch was not committed and the host has not repaired it yet --
                                   // later launches must not commit either (pipelined submission, hrfd_ingest_*)
 constexpr int kNumDevCounters = 10;
-constexpr int kDbgSlots = 32;      // RxParams::dbg: per workgroup 0..5 phase stamps of thread 0, 6 placement, 8..23 end of phase A per wave, 24..27 end of the recurrence per wave
+constexpr int kDbgSlots = 48;      // RxParams::dbg: per workgroup 0..5 phase stamps of thread 0, 6 placement, 8..23 per wave, 24..31 recurrence / stream-loop probes, 32..47 service-loop probes (k_rx_wbfm_flow)
 
 } // namespace hrfd
 

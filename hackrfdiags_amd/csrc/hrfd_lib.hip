@@ -2,6 +2,7 @@
 // Kernels and their launchers live in one TU so that no relocatable device code
 // / device link step is needed (plain `hipcc -c` + host link).
 #include "hrfd_rx_kernels.hip"
+#include "hrfd_rx_flow.hip"
 #include "hrfd_rx_fir_kernels.hip"
 #include "../../include/hrfd.h"
 #include "hrfd_tx_kernels.hip"

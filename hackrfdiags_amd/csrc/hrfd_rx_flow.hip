@@ -1,0 +1,767 @@
+// hackrfdiags_amd/csrc/hrfd_rx_flow.hip -- k_rx_wbfm_flow: the WBFM chain of a batch as ONE continuous
+// stream per workgroup, without workgroup barriers (gfx950).
+//
+// k_rx_wbfm_stream (hrfd_rx_kernels.hip) keeps two whole blocks in LDS and meets at a workgroup
+// barrier once per block.  Measured on MI355X (gpurun_out/r2_ab*.log): its phases B and C are
+// hidden already (removing them buys 3 %) and so is HBM; what costs is phase A running at ~60 % of
+// its issue-bound rate -- every wave starts a run right behind the barrier (two dependent memory
+// latencies each, all at the same time), and waves that finish early leave their SIMD to a lone
+// wave, which issues at half the rate of four.  Here nothing ever meets:
+//
+//   waves SVC..15 ("stream")   take UNITS of two 4 KiB pieces from an LDS counter, in stream order,
+//        and turn raw IQ into v (quad_piece, the phase A of hrfd_rx_kernels.hip) in a RING of
+//        kFRingTiles 64-sample tiles.  The next unit's loads are issued while the current unit
+//        is computed, across unit boundaries: a stream wave only ever waits when the ring is full.
+//   waves 0..SVC-1 ("service") follow in GENERATIONS of 64 tiles (one per lane): geometric partial
+//        sums, seed, warm-up over the three tiles in front (reads only: v is never overwritten),
+//        then the tile itself, where the lane also narrows y to int16 and runs D(8,4) in registers
+//        (WbFmDemodulator.cc:468-476).  Neither y nor its int16 form ever goes to LDS; a lane keeps
+//        16 U samples.  Generations complete in order (b_done): verification against the left
+//        neighbour's final y, repair of a tile that has not merged (re-run from the true value;
+//        v is intact), first U of every tile from the LEFT lane's true last samples, D(12,4),
+//        D(40,2), PCM.
+//
+// A run (consecutive blocks of one channel) is one stream: positions count from the run's first
+// sample, blocks only matter for the squelch magnitude and the cross-block check values.  A run
+// that does not start the call re-derives kFHal samples of history like the other kernels do and
+// is checked by k_rx_epilogue (y at block-relative position -705).
+//
+// Mirrors IqDataProcessor::reduceSampleRate (IqDataProcessor.cc:429-500), upconvertByFsOver4
+// (:771-815), SignalDetector::detectSignal (SignalDetector.cc:205-274),
+// WbFmDemodulator::demodulateSignal / createPcmData (WbFmDemodulator.cc:381-500),
+// IirFilter::filterData (IirFilter.cc:161-176), Decimator_int16::filterData (Decimator_int16.cc:176-249).
+#ifndef HRFD_FLOW_RING
+#define HRFD_FLOW_RING 320
+#endif
+#ifndef HRFD_FLOW_SVC
+#define HRFD_FLOW_SVC 4
+#endif
+#ifndef HRFD_FLOW_SVC_PRIO
+#define HRFD_FLOW_SVC_PRIO 2
+#endif
+// diagnostic build: -DHRFD_FLOW_PROBE accumulates, per stream wave, the cycles between the marks of its unit loop
+// (slots 24..31 of its workgroup's stamp row are summed over the waves; read with tools/gpu_flow_times.py)
+#ifdef HRFD_FLOW_PROBE
+#define FLOW_MARK(i) { const unsigned long long tm_ = __builtin_readcyclecounter(); probe[i] += tm_ - tprev; tprev = tm_; }
+#define SVC_MARK(i) { const unsigned long long tm_ = __builtin_readcyclecounter(); sprobe[i] += tm_ - sprev; sprev = tm_; }
+#else
+#define FLOW_MARK(i)
+#define SVC_MARK(i)
+#endif
+
+namespace hrfd {
+
+constexpr int kFT = 64;                         // samples per tile
+constexpr int kFStride = 66;                    // dwords per tile slot: 64-bit accesses of 32 lanes fall into 32 different bank pairs
+constexpr int kFRingTiles = HRFD_FLOW_RING;     // tiles of v in the ring
+constexpr int kFUnitTiles = 8;                  // a unit = two 4 KiB pieces = 512 samples
+constexpr int kFUDw = 2048;                     // U ring: 4096 int16 = four generations
+constexpr int kFVDw = 512;                      // V ring: 1024 int16 = four generations
+constexpr int kFEdges = 64;                     // per-unit records kept (>= kFRingTiles / kFUnitTiles + slack)
+constexpr int kFPRing = 512;                    // per-tile partial sums kept (eight generations)
+static_assert(kFRingTiles == 256 || kFRingTiles == 320 || kFRingTiles == 384, "ring_slot knows these sizes");
+static_assert(kFRingTiles / kFUnitTiles + 16 <= kFEdges, "unit records must outlive the ring");
+
+__device__ __forceinline__ int ring_slot(const int t)
+{
+  if (kFRingTiles == 256)
+  {
+    return t & 255;
+  }
+  const uint32_t h = (uint32_t)t >> 6;                   // t / 64 < 2^15
+  const uint32_t q = (kFRingTiles == 320) ? (h * 0xCCCDu) >> 18 : (h * 0xAAABu) >> 18;   // h / 5, h / 6
+  return t - (int)q * kFRingTiles;
+}
+
+// Hand-offs between the waves of the workgroup go through LDS only.  LDS executes a wave's operations in order
+// and has no cache, so "my LDS accesses so far are done" is all a hand-off needs.  A workgroup-scope fence
+// would also wait for vmcnt(0): for a stream wave that is the NEXT unit's prefetch -- a full memory latency per
+// unit (measured: half of the kernel's time).
+__device__ __forceinline__ void lds_order()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t *p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// 64 steps of y <- v - a1*y over one tile of the ring, nothing stored (warm-up)
+__device__ __forceinline__ float flow_warm_tile(const uint32_t *tp, float y)
+{
+  const float a1 = DEEMPH_A1;
+  const uint2 *p2 = reinterpret_cast<const uint2 *>(tp);
+  uint2 g[32];
+#pragma unroll
+  for (int j = 0; j < 32; j++)
+  {
+    g[j] = p2[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 32; j++)
+  {
+    float r = a1 * y;
+    y = u2f(g[j].x) - r;
+    r = a1 * y;
+    y = u2f(g[j].y) - r;
+  }
+  return y;
+}
+
+// What a lane knows about its tile after running it
+struct FlowTile
+{
+  float y;                       // y of the tile's last sample
+  uint32_t sfirst0, sfirst1;     // (int16) y of its first four samples, packed pairs
+  uint32_t slast0, slast1;       // ... of its last four samples
+  uint32_t ud[8];                // U[0..15] = D(8,4) outputs of the tile, packed pairs; U[0] (low half of ud[0]) is
+                                 // filled in later: it needs the left neighbour's last four samples
+};
+
+// The tile proper: the recurrence, the (int16_t) narrowing with x86 semantics and D(8,4) in registers.
+template <bool FIX>
+__device__ __forceinline__ void flow_tile_u(const uint32_t *tp, float y, FlowTile &o)
+{
+  const float a1 = DEEMPH_A1;
+  const uint2 *p2 = reinterpret_cast<const uint2 *>(tp);
+  uint2 g[32];
+#pragma unroll
+  for (int j = 0; j < 32; j++)
+  {
+    g[j] = p2[j];
+  }
+  uint32_t pa = 0, pb = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+  {
+    float r = a1 * y;
+    const float y0 = u2f(g[2 * i].x) - r;
+    r = a1 * y0;
+    const float y1 = u2f(g[2 * i].y) - r;
+    r = a1 * y1;
+    const float y2 = u2f(g[2 * i + 1].x) - r;
+    r = a1 * y2;
+    y = u2f(g[2 * i + 1].y) - r;
+    const uint32_t sa = pack_s16<FIX>(y0, y1), sb = pack_s16<FIX>(y2, y);
+    if (i == 0)
+    {
+      o.sfirst0 = sa;
+      o.sfirst1 = sb;
+      o.ud[0] = 0u;
+    }
+    else
+    {
+      int acc = 1 << 14;
+      acc = dot2(pa, kRevWbD1.p[0], acc);
+      acc = dot2(pb, kRevWbD1.p[1], acc);
+      acc = dot2(sa, kRevWbD1.p[2], acc);
+      acc = dot2(sb, kRevWbD1.p[3], acc);
+      const uint32_t u16 = (uint32_t)q15_out(acc) & 0xffffu;
+      if (i & 1)
+      {
+        o.ud[i >> 1] = (i == 1) ? (u16 << 16) : (o.ud[i >> 1] | (u16 << 16));
+      }
+      else
+      {
+        o.ud[i >> 1] = u16;
+      }
+    }
+    pa = sa;
+    pb = sb;
+  }
+  o.slast0 = pa;
+  o.slast1 = pb;
+  o.y = y;
+}
+
+template <int SVC>
+__global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t ring[kFRingTiles * kFStride];
+  __shared__ __attribute__((aligned(16))) uint8_t atcorr[kCorrBytes];
+  __shared__ __attribute__((aligned(16))) float atinv[kInvEntries];
+  __shared__ __attribute__((aligned(16))) uint32_t uring[kFUDw];
+  __shared__ __attribute__((aligned(16))) uint32_t vring[kFVDw];
+  __shared__ uint32_t edges[kFEdges][4];   // per unit: theta of its first two and last two samples
+  __shared__ uint32_t uflag[kFEdges];      // unit u is complete in the ring: u + 1
+  __shared__ float parr[kFPRing];          // per tile: geometric partial sum of v
+  __shared__ uint32_t pflag[8];            // partial sums of generation g are in parr: g + 1
+  __shared__ uint32_t ctl[24];             // 0 next unit, 1 generations done, 8..23 units done (per block, mod 16)
+  __shared__ uint32_t magl[16][64];        // per block (mod 16: more blocks than the ring can span) and lane: sum of the sample
+                                           // magnitudes.  One word per lane: a
+                                           // same-address atomic from 64 lanes becomes a 64-step scalar loop (LLVM's atomic
+                                           // optimizer), measured at half of the kernel's time
+  __shared__ uint32_t wfin[4];             // the last finished generation's last lane: y, its last two S pairs
+  static_assert(sizeof(uint32_t) * (kFRingTiles * kFStride + kFUDw + kFVDw + 5 * kFEdges + kFPRing + 24) + kCorrBytes +
+                        sizeof(float) * kInvEntries <= 163840, "LDS");
+
+  uint32_t ci, run;
+  if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
+  {
+    return;
+  }
+  const uint32_t c = P.chan_list[ci];
+  const int n256 = (int)P.n256;
+  const uint32_t b_first = run * P.run_len;
+  const uint32_t b_end = min(P.n_blocks, b_first + P.run_len);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool first = (b_first == 0);                     // the stream continues from the carried state: exact start
+  const int hal = first ? 0 : P.flow_hal;                // history re-derived in front of the run (samples)
+  const int L = hal + (int)(b_end - b_first) * n256;     // samples of the stream
+  const int n_units = L >> 9, n_tiles = L >> 6, n_gens = (n_tiles + 63) >> 6;
+  const int upb = n256 >> 9;                             // units per block
+  const int wt = P.warm_tiles, M = P.seed_terms;
+  const ChanState *st = P.state + c;
+  ChanState *so = P.state_out + c;
+  const ChanCfg cfg = P.cfg[c];
+  float kgain = cfg.gain_wbfm / 75000.0f;                // K = (gain/75000)*32767 in float, that order (WbFmDemodulator.cc:392-395)
+  kgain = kgain * 32767.0f;
+  const bool small_y = fabsf(kgain) * 3.3f < 2147483000.0f;   // |y| <= |K| pi: the int32 cast cannot overflow
+  const unsigned long long t_kernel = __builtin_readcyclecounter();
+  unsigned long long waited = 0;
+
+  // tables and control words
+  magl[0][tid] = 0u;
+  if (tid < kCorrBytes / 16)
+  {
+    reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr)[tid];
+  }
+  else if (tid < kCorrBytes / 16 + kInvEntries / 4)
+  {
+    reinterpret_cast<uint4 *>(atinv)[tid - kCorrBytes / 16] = reinterpret_cast<const uint4 *>(P.at_inv)[tid - kCorrBytes / 16];
+  }
+  else if (tid >= 640 && tid < 640 + kFEdges)
+  {
+    uflag[tid - 640] = 0u;
+  }
+  else if (tid >= 768 && tid < 792)
+  {
+    ctl[tid - 768] = 0u;
+  }
+
+  else if (tid >= 800 && tid < 808)
+  {
+    pflag[tid - 800] = 0u;
+  }
+  else if (tid >= 832 && tid < 836 && first)
+  {
+    // what the lane in front of tile 0 would have left: the carried y and the last four S samples
+    wfin[tid - 832] = (tid == 832) ? f2u(st->wb_y) : (tid == 833) ? reinterpret_cast<const uint32_t *>(st->wb_s)[0]
+                                                   : (tid == 834) ? reinterpret_cast<const uint32_t *>(st->wb_s)[1] : 0u;
+  }
+  else if (tid >= 896 && tid < 900 && first)
+  {
+    uring[kFUDw - 4 + (tid - 896)] = reinterpret_cast<const uint32_t *>(st->wb_u)[tid - 896];     // U[-8 .. -1]
+  }
+  else if (tid >= 960 && tid < 979 && first)
+  {
+    vring[kFVDw - 19 + (tid - 960)] = reinterpret_cast<const uint32_t *>(st->wb_v)[tid - 960];    // V[-38 .. -1]
+  }
+  __syncthreads();                                       // the only workgroup barrier of the kernel
+
+  if (wave >= SVC)
+  {
+    // =================================================================== stream waves: raw IQ -> v
+    StreamCtx X;
+    X.P = &P;
+    X.kgain = kgain;
+    X.atc = atcorr;
+    X.ati = atinv;
+    X.lane = lane;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int8_t *>(P.iq + (uint64_t)c * P.ch_stride), 0, (int)(P.n_blocks * P.block_bytes), 0x00020000);
+    const uint32_t base_off = b_first * P.block_bytes - (uint32_t)hal * 16u;   // byte offset of stream sample 0
+    const uint32_t dead = 0xffff0000u;                   // outside the descriptor: zeros, no memory traffic
+    auto grab = [&]() -> int {
+      uint32_t g = 0;
+      if (lane == 0)
+      {
+        g = atomicAdd(&ctl[0], 1u);
+      }
+      return __builtin_amdgcn_readfirstlane((int)g);
+    };
+    auto load_piece = [&](uint4 (&q)[4], const int piece, const bool live) {
+      const uint32_t soff = live ? base_off + (uint32_t)piece * 4096u : dead;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+#if (HRFD_ABLATE & 128)
+        q[j] = make_uint4(lane * 0x01010101u + piece, lane * 0x3010501u + j, piece * 0x10101u, lane ^ (piece + soff));   // TIMING EXPERIMENT ONLY: no HBM reads
+        continue;
+#endif
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 64 + 16 * j, soff, HRFD_STREAM_AUX);
+        q[j] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+    };
+    // the 16 bytes in front of a unit: its front-end carries depend on nothing else
+    auto load_c16 = [&](const int u, const bool live) -> u32x4 {
+      const uint32_t soff = (live && !(first && u == 0)) ? base_off + (uint32_t)u * 8192u - 16u : dead;
+      return __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, soff, 0);
+    };
+    // lane constant: where this lane's four samples of a piece go (tile lane / 16 of the piece, 4 (lane % 16) inside)
+    const int lane_dw = kFStride * (lane >> 4) + ((4 * lane) & 63);
+    int bu0 = hal >> 9, blk = 0;                         // first unit and index (in the run) of the block a unit belongs to
+    unsigned long long probe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    (void)probe; (void)tprev;
+    int u = grab();
+    uint4 qa[4], qb[4];
+    u32x4 c16 = load_c16(u, u < n_units);
+    load_piece(qa, 2 * u, u < n_units);
+    while (u < n_units)
+    {
+      FLOW_MARK(0)
+      const uint32_t done_seen = lds_ld(&ctl[1]);
+      load_piece(qb, 2 * u + 1, true);
+      FLOW_MARK(1)
+      QuadCarry cy;
+      if (first && u == 0)
+      {
+        cy.fe = carry_from_16(*reinterpret_cast<const uint4 *>(st->fe_tail));
+        cy.theta = f2u(st->wb_theta);
+        cy.p = f2u(st->wb_p);
+      }
+      else
+      {
+        cy.fe = carry_from_16(make_uint4(c16.x, c16.y, c16.z, c16.w));
+        cy.theta = 0u;                                   // the unit's first two v are provisional: patched by the service wave
+        cy.p = 0u;
+      }
+      FLOW_MARK(2)
+      // ring space: the tiles this unit overwrites must not be anybody's warm-up any more
+      if (8 * u + 8 + wt > 64 * (int)done_seen + kFRingTiles)
+      {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (8 * u + 8 + wt > 64 * (int)lds_ld(&ctl[1]) + kFRingTiles)
+        {
+          __builtin_amdgcn_s_sleep(8);
+        }
+        waited += __builtin_readcyclecounter() - t0;
+      }
+      FLOW_MARK(3)
+      const int slot0 = ring_slot(8 * u);                // NT is a multiple of 8: a unit never wraps
+      uint32_t *dst = ring + slot0 * kFStride + lane_dw;
+      uint32_t v[4], mag4, magsum;
+      float theta[4];
+      quad_piece<true>(qa, cy, X, v, theta, mag4);
+      reinterpret_cast<uint2 *>(dst)[0] = make_uint2(v[0], v[1]);
+      reinterpret_cast<uint2 *>(dst)[1] = make_uint2(v[2], v[3]);
+      magsum = mag4;
+      const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[0]), 0);
+      const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[1]), 0);
+      FLOW_MARK(4)
+      // the next unit: taken only now (a unit that is reserved early keeps the ring's completed frontier back), its loads
+      // go out at once -- a piece of lead, across the unit boundary
+      const int un = grab();
+      c16 = load_c16(un, un < n_units);
+      load_piece(qa, 2 * un, un < n_units);
+      FLOW_MARK(5)
+      quad_piece<true>(qb, cy, X, v, theta, mag4);
+      reinterpret_cast<uint2 *>(dst + 4 * kFStride)[0] = make_uint2(v[0], v[1]);
+      reinterpret_cast<uint2 *>(dst + 4 * kFStride)[1] = make_uint2(v[2], v[3]);
+      magsum += mag4;
+      const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[2]), 63);
+      const uint32_t e3 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[3]), 63);
+      FLOW_MARK(6)
+      if (lane < 4)
+      {
+        edges[u & (kFEdges - 1)][lane] = (lane == 0) ? e0 : (lane == 1) ? e1 : (lane == 2) ? e2 : e3;
+      }
+      const bool counted = u >= (hal >> 9);              // history in front of the run is not in any block's squelch sum
+      int slot = 0;
+      if (counted)
+      {
+        while (u >= bu0 + upb)
+        {
+          bu0 += upb;
+          blk++;
+        }
+        slot = blk & 15;
+        atomicAdd(&magl[slot][lane], magsum);
+      }
+      lds_order();
+      uint32_t nth = 0;
+      if (lane == 0)
+      {
+        lds_st(&uflag[u & (kFEdges - 1)], (uint32_t)u + 1u);
+        if (counted)
+        {
+          nth = atomicAdd(&ctl[8 + slot], 1u);
+        }
+      }
+      if (counted && __builtin_amdgcn_readfirstlane((int)nth) == upb - 1)
+      {
+        // this unit completed its block: block-mean magnitude, detector (SignalDetector.cc:255,
+        // DbfsCalculator.cc:111-147 with a 7-bit full scale).  A batch speculates every gate open;
+        // k_rx_epilogue runs the tracker and checks.
+        uint32_t total = magl[slot][lane];
+        magl[slot][lane] = 0u;
+        for (int off = 32; off > 0; off >>= 1)
+        {
+          total += __shfl_down(total, off);
+        }
+        if (lane == 0)
+        {
+          const uint32_t mean_mag = total / (uint32_t)n256;
+          int32_t dbfs = P.dbfs[min(mean_mag, 127u)] - 42;
+          dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
+          const uint32_t b = b_first + (uint32_t)blk;
+          P.magnitude[(size_t)c * P.out_blocks + P.out_b0 + b] = mean_mag;
+          P.present[(size_t)c * P.n_blocks + b] = (dbfs >= cfg.threshold) ? 1 : 0;
+          lds_st(&ctl[8 + slot], 0u);
+        }
+      }
+      u = un;
+      FLOW_MARK(7)
+    }
+#ifdef HRFD_FLOW_PROBE
+    if (P.dbg != nullptr && lane == 0)
+    {
+      for (int i = 0; i < 8; i++)
+      {
+        atomicAdd(&P.dbg[(size_t)blockIdx.x * kDbgSlots + 24 + i], probe[i]);
+      }
+    }
+#endif
+    if (b_end == P.n_blocks && wave == SVC && lane < 4)
+    {
+      // front-end carry for the next call: the last 16 raw bytes of the channel's input
+      const int8_t *endp = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)P.n_blocks * P.block_bytes;
+      reinterpret_cast<uint32_t *>(so->fe_tail)[lane] = reinterpret_cast<const uint32_t *>(endp - 16)[lane];
+    }
+  }
+  else
+  {
+    // =================================================================== service waves: v -> PCM
+    __builtin_amdgcn_s_setprio(HRFD_FLOW_SVC_PRIO);      // long dependent chains, few issue slots
+    const float a1 = DEEMPH_A1;
+    const int fa_t = first ? 0 : (wt + M);               // first tile that can be started properly
+    const uint32_t pcm_off = (uint32_t)(hal >> 5);       // PCM samples that the history in front would yield
+    uint32_t *pcm32 = reinterpret_cast<uint32_t *>(P.pcm + ((size_t)c * P.out_blocks + P.out_b0 + b_first) * (size_t)(n256 >> 5));
+    uint32_t repairs = 0;
+    unsigned long long sprobe[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_readcyclecounter();
+    (void)sprobe; (void)sprev;
+    for (int g = wave; g < n_gens; g += SVC)
+    {
+      SVC_MARK(0)
+      const int t0 = 64 * g;
+      const int ntl = min(64, n_tiles - t0);             // tiles of this generation (a multiple of 8)
+      const int t = t0 + lane;
+      const bool have = lane < ntl;
+      // 1. the generation's units, and the one in front (its last two thetas), are in the ring
+      {
+        const int ulo = max(8 * g - 1, 0), uhi = 8 * g + (ntl >> 3);
+        const int uu = ulo + lane;
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+        for (;;)
+        {
+          const bool ok = (uu >= uhi) || lds_ld(&uflag[uu & (kFEdges - 1)]) == (uint32_t)uu + 1u;
+          if (__all(ok))
+          {
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        waited += __builtin_readcyclecounter() - tw0;
+        lds_order();
+      }
+      SVC_MARK(1)
+      // 2. the two provisional samples at the start of every unit (they need theta of the two samples in
+      //    front of it, which another wave produced); one lane per unit
+      if (lane < (ntl >> 3))
+      {
+        const int uu = 8 * g + lane;
+        if (uu > 0)
+        {
+          const uint32_t *ep = edges[(uu - 1) & (kFEdges - 1)], *ec = edges[uu & (kFEdges - 1)];
+          const float tm2 = u2f(ep[2]), tm1 = u2f(ep[3]);
+          const float th0 = u2f(ec[0]), th1 = u2f(ec[1]);
+          const float pm1 = numerator_p(tm1, tm2, kgain);
+          const float p0 = numerator_p(th0, tm1, kgain);
+          const float p1 = numerator_p(th1, th0, kgain);
+          uint32_t *vp = ring + ring_slot(8 * uu) * kFStride;
+          vp[0] = f2u(p0 + pm1);
+          vp[1] = f2u(p1 + p0);
+        }
+      }
+      const uint32_t *tp = ring + ring_slot(t) * kFStride;
+      SVC_MARK(2)
+      // 3. geometric partial sum of v over the own tile: P = sum_k c^k v[63 - k], c = -a1 (approximate on purpose)
+      if (have && M > 0)
+      {
+        const float cc = -a1, c2 = cc * cc;
+        const uint2 *p2 = reinterpret_cast<const uint2 *>(tp);
+        float pa = 0.0f, pb = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < kFT / 2; j++)
+        {
+          const uint2 w = p2[j];
+          pa = __builtin_fmaf(pa, c2, u2f(w.x));
+          pb = __builtin_fmaf(pb, c2, u2f(w.y));
+        }
+        float p = __builtin_fmaf(pa, cc, pb);
+        if (first && t == 0)
+        {
+          p += deemph_pow(kFT) * st->wb_y;               // the stream's past, as seen from the end of tile 0
+        }
+        parr[t & (kFPRing - 1)] = p;
+      }
+      lds_order();
+      if (lane == 0)
+      {
+        lds_st(&pflag[g & 7], (uint32_t)g + 1u);
+      }
+      SVC_MARK(3)
+      if (g > 0 && M > 0)
+      {
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+        while (lds_ld(&pflag[(g - 1) & 7]) != (uint32_t)g)
+        {
+          __builtin_amdgcn_s_sleep(4);
+        }
+        waited += __builtin_readcyclecounter() - tw0;
+        lds_order();
+      }
+      SVC_MARK(4)
+      // 4. seed, warm-up, tile
+      const bool active = have && t >= fa_t;
+      FlowTile o;
+      o.y = 0.0f;
+      o.sfirst0 = o.sfirst1 = o.slast0 = o.slast1 = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+      {
+        o.ud[i] = 0u;
+      }
+      float y_spec = 0.0f;
+      if (active)
+      {
+        const int ws = t - wt;                           // the warm-up begins with this tile
+        float y = 0.0f;
+        if (first && ws <= 0)
+        {
+          y = st->wb_y;                                  // exact: the stream starts here
+        }
+        else if (M > 0)
+        {
+          // y at the end of tile ws - 1: sum_m (c^64)^(m-1) P[ws - m], oldest first
+          float acc = 0.0f;
+          for (int m = M; m >= 1; m--)
+          {
+            const int idx = ws - m;
+            const float pv = (idx >= 0) ? parr[idx & (kFPRing - 1)] : 0.0f;
+            acc = __builtin_fmaf(acc, P.flow_seed_ct, pv);
+          }
+          y = acc;
+        }
+        for (int k = wt; k >= 1; k--)
+        {
+          const int tw = t - k;
+          if (tw >= 0)
+          {
+            y = flow_warm_tile(ring + ring_slot(tw) * kFStride, y);
+          }
+        }
+        y_spec = y;
+        if (small_y)
+        {
+          flow_tile_u<false>(tp, y, o);
+        }
+        else
+        {
+          flow_tile_u<true>(tp, y, o);
+        }
+      }
+      SVC_MARK(5)
+      // 5. generations complete in order
+      {
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+        while (lds_ld(&ctl[1]) != (uint32_t)g)
+        {
+          __builtin_amdgcn_s_sleep(4);
+        }
+        waited += __builtin_readcyclecounter() - tw0;
+        lds_order();
+      }
+      SVC_MARK(6)
+      const uint32_t left_y = wfin[0], left_s0 = wfin[1], left_s1 = wfin[2];
+      // 6. every lane but the first runnable one checks its speculated start against its left neighbour's end;
+      //    a tile that has not merged is re-run from the true value, ascending (rare)
+      {
+        const float y_left = u2f(shr1(f2u(o.y), left_y));
+        const bool bad = active && t > fa_t && !same_trajectory(y_left, y_spec);
+        unsigned long long bm = __ballot(bad);
+        while (bm != 0ull)
+        {
+          const int l = __ffsll((long long)bm) - 1;      // wave-uniform
+          bm &= ~(1ull << l);
+          repairs++;
+          const float y_true = u2f(shr1(f2u(o.y), left_y));
+          if (lane == l)
+          {
+            if (small_y)
+            {
+              flow_tile_u<false>(tp, y_true, o);
+            }
+            else
+            {
+              flow_tile_u<true>(tp, y_true, o);
+            }
+          }
+          // the right neighbour's speculation must now match the corrected final y
+          const float y_new_left = u2f(shr1(f2u(o.y), left_y));
+          const bool bad2 = (lane == l + 1) && active && !same_trajectory(y_new_left, y_spec);
+          bm |= __ballot(bad2);
+        }
+      }
+      // 7. U[0] of every tile: S[-4 .. -1] are the LEFT lane's last four samples (its final ones)
+      {
+        const uint32_t ls0 = shr1(o.slast0, left_s0), ls1 = shr1(o.slast1, left_s1);
+        int acc = 1 << 14;
+        acc = dot2(ls0, kRevWbD1.p[0], acc);
+        acc = dot2(ls1, kRevWbD1.p[1], acc);
+        acc = dot2(o.sfirst0, kRevWbD1.p[2], acc);
+        acc = dot2(o.sfirst1, kRevWbD1.p[3], acc);
+        o.ud[0] = (o.ud[0] & 0xffff0000u) | ((uint32_t)q15_out(acc) & 0xffffu);
+      }
+      if (have)
+      {
+        uint4 *up = reinterpret_cast<uint4 *>(uring + ((8 * t) & (kFUDw - 1)));
+        up[0] = make_uint4(o.ud[0], o.ud[1], o.ud[2], o.ud[3]);
+        up[1] = make_uint4(o.ud[4], o.ud[5], o.ud[6], o.ud[7]);
+      }
+      SVC_MARK(7)
+      // 8. V[k] = D(12,4)(U), two per lane and pass (WbFmDemodulator.cc:478-486)
+      for (int i = lane; i < 2 * ntl; i += 64)
+      {
+        const int k = 256 * g + 2 * i;                   // even
+        const uint4 ua = *reinterpret_cast<const uint4 *>(uring + ((2 * k - 4) & (kFUDw - 1)));
+        const uint4 ub = *reinterpret_cast<const uint4 *>(uring + ((2 * k) & (kFUDw - 1)));
+        const uint32_t uu[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};   // U[4k-8 .. 4k+7]
+        int acc0 = 1 << 14, acc1 = 1 << 14;
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+        {
+          acc0 = dot2(uu[j], kRevD12.p[j], acc0);
+          acc1 = dot2(uu[j + 2], kRevD12.p[j], acc1);
+        }
+        vring[(k >> 1) & (kFVDw - 1)] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+      }
+      // 9. PCM[p] = D(40,2)(V), two per lane (WbFmDemodulator.cc:488-496)
+      if (have)
+      {
+        const int pp = 128 * g + 2 * lane;               // even; V[2pp-38 .. 2pp+3] = dwords pp-19 .. pp+1
+        int acc0 = 1 << 14, acc1 = 1 << 14;
+        uint32_t prev = vring[(pp - 19) & (kFVDw - 1)];
+#pragma unroll
+        for (int j = 0; j < 20; j++)
+        {
+          const uint32_t next = vring[(pp - 18 + j) & (kFVDw - 1)];
+          acc0 = dot2(prev, kRevD40.p[j], acc0);
+          acc1 = dot2(next, kRevD40.p[j], acc1);
+          prev = next;
+        }
+        if ((uint32_t)pp >= pcm_off)
+        {
+          pcm32[((uint32_t)pp - pcm_off) >> 1] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+        }
+      }
+      SVC_MARK(8)
+      // 10. cross-block check values: y at block-relative position -705 = the end of the tile [-768, -704)
+      if (have)
+      {
+        const int x = 64 * t + 768 - hal;                // = (number of blocks completed) * n256 when this is such a tile
+        if (x >= 0)
+        {
+          const int q = x / n256;
+          if (q * n256 == x)
+          {
+            const uint32_t b = b_first + (uint32_t)q;    // the block this value stands in front of
+            if (q == 0)
+            {
+              P.chk_spec[(size_t)c * P.n_blocks + b] = o.y;   // speculated by this run (b_first > 0)
+            }
+            else
+            {
+              P.chk_pub[(size_t)c * P.n_blocks + b - 1] = o.y;
+              if (b < b_end)
+              {
+                P.chk_spec[(size_t)c * P.n_blocks + b] = o.y;
+              }
+            }
+          }
+        }
+      }
+      // 11. hand over to the next generation
+      {
+        const uint32_t fy = (uint32_t)__builtin_amdgcn_readlane((int)f2u(o.y), ntl - 1);
+        const uint32_t fs0 = (uint32_t)__builtin_amdgcn_readlane((int)o.slast0, ntl - 1);
+        const uint32_t fs1 = (uint32_t)__builtin_amdgcn_readlane((int)o.slast1, ntl - 1);
+        if (g + 1 == n_gens && b_end == P.n_blocks)
+        {
+          // the carried state for the next call (pending: k_rx_commit copies it when the launch verified clean)
+          const uint32_t *el = edges[(n_units - 1) & (kFEdges - 1)];
+          if (lane == 0)
+          {
+            so->wb_y = u2f(fy);
+            so->wb_theta = u2f(el[3]);
+            so->wb_p = numerator_p(u2f(el[3]), u2f(el[2]), kgain);
+            reinterpret_cast<uint32_t *>(so->wb_s)[0] = fs0;
+            reinterpret_cast<uint32_t *>(so->wb_s)[1] = fs1;
+          }
+          if (lane < 4)
+          {
+            reinterpret_cast<uint32_t *>(so->wb_u)[lane] = uring[(8 * n_tiles - 4 + lane) & (kFUDw - 1)];
+          }
+          if (lane < 19)
+          {
+            reinterpret_cast<uint32_t *>(so->wb_v)[lane] = vring[(2 * n_tiles - 19 + lane) & (kFVDw - 1)];
+          }
+        }
+        if (lane == 0)
+        {
+          wfin[0] = fy;
+          wfin[1] = fs0;
+          wfin[2] = fs1;
+        }
+        lds_order();
+        if (lane == 0)
+        {
+          lds_st(&ctl[1], (uint32_t)g + 1u);
+        }
+      }
+      SVC_MARK(9)
+    }
+#ifdef HRFD_FLOW_PROBE
+    if (P.dbg != nullptr && lane == 0)
+    {
+      for (int i = 0; i < 10; i++)
+      {
+        atomicAdd(&P.dbg[(size_t)blockIdx.x * kDbgSlots + 32 + i], sprobe[i]);
+      }
+    }
+#endif
+    if (repairs != 0u && lane == 0)
+    {
+      atomicAdd(&P.counters[kCntRepair], repairs);
+    }
+  }
+  if (P.dbg != nullptr && lane == 0)
+  {
+    // per wave: cycles spent waiting (ring full / units not there yet / generation order); slot 0: the workgroup's cycles
+    P.dbg[(size_t)blockIdx.x * kDbgSlots + 8 + wave] = waited;
+    if (tid == 0)
+    {
+      P.dbg[(size_t)blockIdx.x * kDbgSlots + 0] = __builtin_readcyclecounter() - t_kernel;
+    }
+  }
+}
+
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC>(const RxParams);
+
+} // namespace hrfd
