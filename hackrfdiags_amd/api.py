@@ -87,10 +87,12 @@ class Rx:
         """-1 automatic, 0 force the atan2 table gather, 1 require the arithmetic atan2 kernel."""
         check(self.L.hrfd_rx_debug_set_atan(self.h, int(mode)), "hrfd_rx_debug_set_atan")
 
-    def debug_atan_eval(self):
-        """The arithmetic atan2 of the WBFM kernel over all (q, i): float32 [256][256]."""
+    def debug_atan_eval(self, tab: bool = False):
+        """The arithmetic atan2 of the WBFM kernels over all (q, i): float32 [256][256]; tab: the
+        first-octant-table variant of k_rx_wbfm_flow instead of the polynomial one."""
         out = np.zeros((256, 256), dtype=np.float32)
-        check(self.L.hrfd_rx_debug_atan_eval(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "hrfd_rx_debug_atan_eval")
+        fn = self.L.hrfd_rx_debug_atan_eval_tab if tab else self.L.hrfd_rx_debug_atan_eval
+        check(fn(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "hrfd_rx_debug_atan_eval")
         return out
 
     def debug_set_run_len(self, blocks: int):

@@ -20,7 +20,7 @@
 namespace hrfd {
 template <int MODE, bool S256, bool ARITH> __global__ void k_rx_wbfm(const RxParams);
 __global__ void k_build_atan_corr(const float *, const float *, uint8_t *, uint32_t *);
-__global__ void k_atan_eval(const uint8_t *, const float *, float *);
+template <bool TAB> __global__ void k_atan_eval(const uint8_t *, const float *, float *);
 template <int MODE, bool S256, bool ARITH> __global__ void k_rx_fir(const RxParams);
 template <int MODE> __global__ void k_rx_post(const RxParams);
 __global__ void k_rx_epilogue(const EpilogueParams);
@@ -153,6 +153,9 @@ struct hrfd_rx
   float *d_lut = nullptr;
   uint8_t *d_atcorr = nullptr;         // arithmetic atan2 (theta_arith): correction bytes, 1/a
   float *d_atinv = nullptr;
+  uint8_t *d_atcorr2 = nullptr;        // first-octant table atan2 (theta_tab): correction bytes, T0
+  float *d_att0 = nullptr;
+  bool tab_ok = false;                 // its corrections fit: k_rx_wbfm_flow may run
   bool arith_ok = false;               // corrections fit: k_rx_wbfm computes theta instead of gathering it
   int atan_mode = -1;                  // test hook: -1 auto, 0 force the table gather, 1 require arithmetic
   int32_t *d_dbfs = nullptr;
@@ -208,7 +211,7 @@ static int rx_free(hrfd_rx *h)
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->side) (void)hipStreamSynchronize(h->side);
-  void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_dbfs, h->d_counters,
+  void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_atcorr2, h->d_att0, h->d_dbfs, h->d_counters,
                   h->d_lists, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
                   h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq};
   for (void *p : ptrs)
@@ -287,6 +290,8 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && alloc((void **)&h->d_lut, sizeof(float) * 65536);
   ok = ok && alloc((void **)&h->d_atcorr, kCorrBytes);
   ok = ok && alloc((void **)&h->d_atinv, sizeof(float) * kInvEntries);
+  ok = ok && alloc((void **)&h->d_atcorr2, kCorrBytes);
+  ok = ok && alloc((void **)&h->d_att0, sizeof(float) * kCorrBytes);
   ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
   ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * (kNumDevCounters + kCntSticky));
   ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 6 * n_channels);
@@ -330,11 +335,33 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   if (e == hipSuccess) e = hipMemcpy(h->d_atinv, inv, sizeof(inv), hipMemcpyHostToDevice);
   if (e == hipSuccess)
   {
-    hipLaunchKernelGGL(k_build_atan_corr, dim3((kCorrBytes + 255) / 256), dim3(256), 0, 0, h->d_lut, h->d_atinv,
+    hipLaunchKernelGGL(k_build_atan_corr<false>, dim3((kCorrBytes + 255) / 256), dim3(256), 0, 0, h->d_lut, h->d_atinv,
                        h->d_atcorr, h->d_counters + kCntScratch);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(&bad, h->d_counters + kCntScratch, sizeof(bad), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemset(h->d_counters + kCntScratch, 0, sizeof(uint32_t));
+  // first-octant table T0[a(a+1)/2 + b] = (float)atan2((double)b, (double)a): the host's libm, the formula of
+  // WbFmDemodulator.cc:137-148; its corrections for the other octants are derived the same way
+  uint32_t bad2 = 0;
+  {
+    std::vector<float> t0(kCorrBytes, 0.0f);
+    for (int a = 0; a <= 128; a++)
+    {
+      for (int b = 0; b <= a; b++)
+      {
+        t0[(size_t)a * (a + 1) / 2 + b] = (float)atan2((double)b, (double)a);
+      }
+    }
+    if (e == hipSuccess) e = hipMemcpy(h->d_att0, t0.data(), sizeof(float) * kCorrBytes, hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess)
+  {
+    hipLaunchKernelGGL(k_build_atan_corr<true>, dim3((kCorrBytes + 255) / 256), dim3(256), 0, 0, h->d_lut, h->d_att0,
+                       h->d_atcorr2, h->d_counters + kCntScratch);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(&bad2, h->d_counters + kCntScratch, sizeof(bad2), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemset(h->d_counters + kCntScratch, 0, sizeof(uint32_t));
   if (e != hipSuccess)
   {
@@ -343,26 +370,44 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
     return rc;
   }
   h->arith_ok = (bad == 0) || (HRFD_ABLATE & 512) != 0;   // (512: TIMING EXPERIMENT ONLY)
+  h->tab_ok = (bad2 == 0);
   *out = h;
   return HRFD_OK;
 }
 
 // test hook: the arithmetic atan2 evaluated on the device for all 65536 (q, i) pairs, in the
 // layout of hrfd_atan2_table(); must equal that table bit for bit when the corrections fit
+static int atan_eval(hrfd_rx *h, float *out65536, bool tab);
 extern "C" int hrfd_rx_debug_atan_eval(hrfd_rx *h, float *out65536)
+{
+  return atan_eval(h, out65536, false);
+}
+// ... and the first-octant-table variant (theta_tab, k_rx_wbfm_flow)
+extern "C" int hrfd_rx_debug_atan_eval_tab(hrfd_rx *h, float *out65536)
+{
+  return atan_eval(h, out65536, true);
+}
+static int atan_eval(hrfd_rx *h, float *out65536, bool tab)
 {
   if (h == nullptr || out65536 == nullptr)
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_atan_eval: NULL");
   }
-  if (!h->arith_ok)
+  if (tab ? !h->tab_ok : !h->arith_ok)
   {
     return fail(HRFD_ESTATE, "hrfd_rx_debug_atan_eval: the atan2 corrections do not fit 2 bits on this device");
   }
   HIP_TRY(hipSetDevice(h->device));
   float *d = nullptr;
   HIP_TRY(hipMalloc((void **)&d, sizeof(float) * 65536));
-  hipLaunchKernelGGL(k_atan_eval, dim3(256), dim3(256), 0, 0, h->d_atcorr, h->d_atinv, d);
+  if (tab)
+  {
+    hipLaunchKernelGGL(k_atan_eval<true>, dim3(256), dim3(256), 0, 0, h->d_atcorr2, h->d_att0, d);
+  }
+  else
+  {
+    hipLaunchKernelGGL(k_atan_eval<false>, dim3(256), dim3(256), 0, 0, h->d_atcorr, h->d_atinv, d);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(out65536, d, sizeof(float) * 65536, hipMemcpyDeviceToHost);
   (void)hipFree(d);
@@ -793,6 +838,8 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.atan2_lut = h->d_lut;
   P.at_corr = h->d_atcorr;
   P.at_inv = h->d_atinv;
+  P.at_corr2 = h->d_atcorr2;
+  P.at_t0 = h->d_att0;
   P.dbfs = h->d_dbfs;
   P.chk_pub = h->d_chk_pub;
   P.chk_spec = h->d_chk_spec;
@@ -889,7 +936,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     const uint32_t groups = 8u * ((n + 7u) / 8u);
     const bool streaming = (m == HRFD_MODE_WBFM) && h->use_stream && n_blocks > 1 && !opt.serial && !opt.src256;
     // k_rx_wbfm_flow: whole units of two 4 KiB pieces, no iq dump, the arithmetic atan2
-    const bool flow = streaming && h->use_stream == 2 && h->arith_ok && h->atan_mode != 0 && d_iq256 == nullptr &&
+    const bool flow = streaming && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 && d_iq256 == nullptr &&
                       (n256 % 512u) == 0 && n256 >= 2048u;
     const uint32_t fill = streaming ? 256u : 512u;
     uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : (streaming ? 16u : 8u);

@@ -133,6 +133,8 @@ struct RxParams
   const float *atan2_lut;      // [256][256]
   const uint8_t *at_corr;      // arithmetic atan2: correction bytes [kCorrBytes] and 1/a [kInvEntries]
   const float *at_inv;
+  const uint8_t *at_corr2;     // first-octant table atan2 (theta_tab, k_rx_wbfm_flow): correction bytes [kCorrBytes]
+  const float *at_t0;          //   and T0 [kCorrBytes floats]
   const int32_t *dbfs;         // [257]
   float *chk_pub;              // [C][n_blocks] y at (n256 - kHist + 59) of this block
   float *chk_spec;             // [C][n_blocks] y at (-kHist + 59) as speculated by this block

@@ -31,7 +31,7 @@
 // WbFmDemodulator::demodulateSignal / createPcmData (WbFmDemodulator.cc:381-500),
 // IirFilter::filterData (IirFilter.cc:161-176), Decimator_int16::filterData (Decimator_int16.cc:176-249).
 #ifndef HRFD_FLOW_RING
-#define HRFD_FLOW_RING 320
+#define HRFD_FLOW_RING 384
 #endif
 #ifndef HRFD_FLOW_SVC
 #define HRFD_FLOW_SVC 4
@@ -55,8 +55,8 @@ constexpr int kFT = 64;                         // samples per tile
 constexpr int kFStride = 66;                    // dwords per tile slot: 64-bit accesses of 32 lanes fall into 32 different bank pairs
 constexpr int kFRingTiles = HRFD_FLOW_RING;     // tiles of v in the ring
 constexpr int kFUnitTiles = 8;                  // a unit = two 4 KiB pieces = 512 samples
-constexpr int kFUDw = 2048;                     // U ring: 4096 int16 = four generations
-constexpr int kFVDw = 512;                      // V ring: 1024 int16 = four generations
+constexpr int kFUDw = 1024;                     // U ring: 2048 int16 = two generations (generation g + 2 stores after g + 1 is complete)
+constexpr int kFVDw = 256;                      // V ring: 512 int16 = two generations
 constexpr int kFEdges = 64;                     // per-unit records kept (>= kFRingTiles / kFUnitTiles + slack)
 constexpr int kFPRing = 512;                    // per-tile partial sums kept (eight generations)
 static_assert(kFRingTiles == 256 || kFRingTiles == 320 || kFRingTiles == 384, "ring_slot knows these sizes");
@@ -182,8 +182,8 @@ template <int SVC>
 __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
 {
   __shared__ __attribute__((aligned(16))) uint32_t ring[kFRingTiles * kFStride];
-  __shared__ __attribute__((aligned(16))) uint8_t atcorr[kCorrBytes];
-  __shared__ __attribute__((aligned(16))) float atinv[kInvEntries];
+  __shared__ __attribute__((aligned(16))) uint8_t atcorr[kCorrBytes];   // theta_tab: correction bytes ...
+  __shared__ __attribute__((aligned(16))) float att0[kCorrBytes];       // ... and the first-octant table
   __shared__ __attribute__((aligned(16))) uint32_t uring[kFUDw];
   __shared__ __attribute__((aligned(16))) uint32_t vring[kFVDw];
   __shared__ uint32_t edges[kFEdges][4];   // per unit: theta of its first two and last two samples
@@ -196,8 +196,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
                                            // same-address atomic from 64 lanes becomes a 64-step scalar loop (LLVM's atomic
                                            // optimizer), measured at half of the kernel's time
   __shared__ uint32_t wfin[4];             // the last finished generation's last lane: y, its last two S pairs
-  static_assert(sizeof(uint32_t) * (kFRingTiles * kFStride + kFUDw + kFVDw + 5 * kFEdges + kFPRing + 24) + kCorrBytes +
-                        sizeof(float) * kInvEntries <= 163840, "LDS");
+  static_assert(sizeof(uint32_t) * (kFRingTiles * kFStride + kFUDw + kFVDw + 5 * kFEdges + kFPRing + 1024 + 48) + 5 * kCorrBytes <= 163840, "LDS");
 
   uint32_t ci, run;
   if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
@@ -228,13 +227,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
 
   // tables and control words
   magl[0][tid] = 0u;
+  for (int i = tid; i < kCorrBytes / 4; i += kThreads)
+  {
+    reinterpret_cast<uint4 *>(att0)[i] = reinterpret_cast<const uint4 *>(P.at_t0)[i];
+  }
   if (tid < kCorrBytes / 16)
   {
-    reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr)[tid];
-  }
-  else if (tid < kCorrBytes / 16 + kInvEntries / 4)
-  {
-    reinterpret_cast<uint4 *>(atinv)[tid - kCorrBytes / 16] = reinterpret_cast<const uint4 *>(P.at_inv)[tid - kCorrBytes / 16];
+    reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr2)[tid];
   }
   else if (tid >= 640 && tid < 640 + kFEdges)
   {
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     X.P = &P;
     X.kgain = kgain;
     X.atc = atcorr;
-    X.ati = atinv;
+    X.ati = att0;
     X.lane = lane;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<int8_t *>(P.iq + (uint64_t)c * P.ch_stride), 0, (int)(P.n_blocks * P.block_bytes), 0x00020000);
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       uint32_t *dst = ring + slot0 * kFStride + lane_dw;
       uint32_t v[4], mag4, magsum;
       float theta[4];
-      quad_piece<true>(qa, cy, X, v, theta, mag4);
+      quad_piece<2>(qa, cy, X, v, theta, mag4);
       reinterpret_cast<uint2 *>(dst)[0] = make_uint2(v[0], v[1]);
       reinterpret_cast<uint2 *>(dst)[1] = make_uint2(v[2], v[3]);
       magsum = mag4;
@@ -361,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       c16 = load_c16(un, un < n_units);
       load_piece(qa, 2 * un, un < n_units);
       FLOW_MARK(5)
-      quad_piece<true>(qb, cy, X, v, theta, mag4);
+      quad_piece<2>(qb, cy, X, v, theta, mag4);
       reinterpret_cast<uint2 *>(dst + 4 * kFStride)[0] = make_uint2(v[0], v[1]);
       reinterpret_cast<uint2 *>(dst + 4 * kFStride)[1] = make_uint2(v[2], v[3]);
       magsum += mag4;

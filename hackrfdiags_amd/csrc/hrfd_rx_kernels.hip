@@ -323,6 +323,41 @@ __device__ __forceinline__ float theta_arith(uint32_t mixed, const uint8_t *corr
   return u2f(__builtin_amdgcn_bitop3_b32(bits, mixed << 8, 0x80000000u, 0xF2));
 }
 
+// ---- atan2 from a first-octant table -------------------------------------------
+// k_rx_wbfm_flow has the LDS for one more table: T0[a(a+1)/2 + b] = (float)atan2((double)b, (double)a),
+// 0 <= b <= a <= 128, built by the host's libm exactly like the reference's own table
+// (WbFmDemodulator.cc:137-148) -- for |q| <= |i|, i > 0 it IS the reference's entry.  The other
+// octants are pi/2 - t, pi - t, pi - (pi/2 - t) in float plus the same kind of 2-bit correction
+// (-1, 0 or +1 ulp here), derived on the device from the reference table with this very function
+// (k_build_atan_corr<true>).  33 vector instructions of theta_arith become two subtractions.
+__device__ __forceinline__ AtanApprox atan2_from_t0(float t0, bool swap, bool negi)
+{
+  float v = swap ? (kPi2F - t0) : t0;
+  v = negi ? (kPiF - v) : v;
+  AtanApprox o;
+  o.theta0 = v;
+  o.shift = (swap ? 2u : 0u) | (negi ? 4u : 0u);
+  return o;
+}
+
+__device__ __forceinline__ float theta_tab(uint32_t mixed, const uint8_t *corr, const float *t0tab)
+{
+  const s2 d = as_s2(mixed) - as_s2(0x00800080u);
+  const s2 nd = as_s2(0u) - d;
+  const s2 ad = __builtin_elementwise_max(d, nd);
+  const uint32_t ai = (uint32_t)(uint16_t)ad.x, aq = (uint32_t)(uint16_t)ad.y;
+  const bool swap = aq > ai;
+  const uint32_t a = max(ai, aq), b = min(ai, aq);
+  const uint32_t tri = ((a * a + a) >> 1) + b;
+  const uint32_t code8 = corr[tri];
+  const float t0 = t0tab[tri];
+  const bool negi = (mixed & 0x00000080u) == 0u;
+  const AtanApprox ap = atan2_from_t0(t0, swap, negi);
+  const int32_t fix = __builtin_amdgcn_sbfe((int32_t)code8, ap.shift, 2u);
+  const uint32_t bits = f2u(ap.theta0) + (uint32_t)fix;
+  return u2f(__builtin_amdgcn_bitop3_b32(bits, mixed << 8, 0x80000000u, 0xF2));
+}
+
 // deltaTheta wrap (WbFmDemodulator.cc:417-425).  The reference compares the
 // float against the double M_PI: (double)d > M_PI  <=>  d >= 0x1.921fb6p+1f,
 // and subtracts 2*M_PI in double before rounding back to float.  |d| <= 2*pi,
@@ -588,7 +623,7 @@ struct StreamCtx
   int lane;
   int qoff;                      // FIR modes: int16 index of the Q rail inside lds (I rail at 0)
   const uint8_t *atc;            // arithmetic atan2: LDS copies of the correction bytes and of 1/a
-  const float *ati;
+  const float *ati;              //   (quad_piece<2>: of the first-octant table T0)
   uint4 tab;                     // this thread's 16 bytes of them, loaded at kernel entry (in flight)
   bool publish;                  // ... and still to be published to LDS by this produce_stream call
   int prio_phase;                // produce_quads: wave id / 4, the phase of the rotating issue priority
@@ -954,6 +989,8 @@ __device__ __forceinline__ void produce_stream(const StreamCtx &X, const int c0,
 // One thread per (a, b): for each of the four octant classes that exist for it,
 // fix = table - approx (in ulps) must lie in -2..1 (a 2-bit two's complement field); the mirrored entry (q < 0) must be
 // the exact negation.  bad[0] counts violations (then the gather kernel is used).
+// TAB: `inv` is the first-octant table T0 and the approximation is atan2_from_t0 (theta_tab)
+template <bool TAB>
 __global__ void k_build_atan_corr(const float *lut, const float *inv, uint8_t *corr, uint32_t *bad)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -985,7 +1022,7 @@ __global__ void k_build_atan_corr(const float *lut, const float *inv, uint8_t *c
     {
       continue;                                          // i = -0 / i = +128 do not exist
     }
-    const AtanApprox ap = atan2_approx((uint32_t)a, (uint32_t)b, swap, negi, inv[a]);
+    const AtanApprox ap = TAB ? atan2_from_t0(inv[t], swap, negi) : atan2_approx((uint32_t)a, (uint32_t)b, swap, negi, inv[a]);
     bool have = false;
     for (int sgn = 0; sgn < 2; sgn++)
     {
@@ -1022,12 +1059,14 @@ __global__ void k_build_atan_corr(const float *lut, const float *inv, uint8_t *c
 }
 
 // test hook (hrfd_rx_debug_atan_eval): theta_arith over the whole (q, i) domain, table layout
+template <bool TAB>
 __global__ void k_atan_eval(const uint8_t *corr, const float *inv, float *out)
 {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;       // (q_idx << 8) | i_idx
   if (t < 65536u)
   {
-    out[t] = theta_arith(((t >> 8) << 16) | (t & 0xffu), corr, inv);
+    const uint32_t mixed = ((t >> 8) << 16) | (t & 0xffu);
+    out[t] = TAB ? theta_tab(mixed, corr, inv) : theta_arith(mixed, corr, inv);
   }
 }
 
@@ -1757,7 +1796,8 @@ struct QuadCarry
 };
 
 // one 4 KiB piece: raw[j] = the lane's group j (16 bytes) -> v[4]; returns the four thetas
-template <bool ARITH>
+// ARITH: 0 table gather from global memory, 1 theta_arith, 2 theta_tab (X.ati is then T0)
+template <int ARITH>
 __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, const StreamCtx &X,
                                            uint32_t (&vout)[4], float (&theta)[4], uint32_t &mag4)
 {
@@ -1821,7 +1861,11 @@ __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, 
   for (int j = 0; j < 4; j++)
   {
     mag4 += magnitude(mixed[j]);
-    if (ARITH)
+    if (ARITH == 2)
+    {
+      theta[j] = theta_tab(mixed[j], X.atc, X.ati);
+    }
+    else if (ARITH == 1)
     {
       theta[j] = theta_arith(mixed[j], X.atc, X.ati);
     }
