@@ -614,6 +614,19 @@ extern "C" int hrfd_rx_debug_set_stagger(hrfd_rx *h, int units)
   return HRFD_OK;
 }
 
+// diagnostic hook: the cross-block check values of the latest launch ([n_channels][n_blocks] each)
+extern "C" int hrfd_rx_debug_chk(hrfd_rx *h, float *pub, float *spec, uint32_t n)
+{
+  if (h == nullptr || pub == nullptr || spec == nullptr || n > h->cap_units)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_chk: bad arguments");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpy(pub, h->d_chk_pub, n * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(spec, h->d_chk_spec, n * sizeof(float), hipMemcpyDeviceToHost));
+  return HRFD_OK;
+}
+
 extern "C" int hrfd_rx_debug_counters(hrfd_rx *h, uint32_t *out8)
 {
   if (h == nullptr || out8 == nullptr)

@@ -36,6 +36,9 @@
 #ifndef HRFD_FLOW_SVC
 #define HRFD_FLOW_SVC 4
 #endif
+#ifndef HRFD_FLOW_EARLY_GRAB
+#define HRFD_FLOW_EARLY_GRAB 1      /* take the next unit before piece 0 (its LDS round trip hides behind the piece) instead of behind it */
+#endif
 #ifndef HRFD_FLOW_SVC_PRIO
 #define HRFD_FLOW_SVC_PRIO 2
 #endif
@@ -81,6 +84,27 @@ __device__ __forceinline__ void lds_order()
 {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
+// Every wait of this kernel is bounded: a wave that has spun for ~0.1 s (a protocol error -- the normal waits are
+// microseconds) reports it as a speculation failure, which makes the host replay the call on the exact path, and
+// goes on; the grid always drains.  `where` identifies the wait in the diagnostics.
+constexpr uint32_t kFSpinLimit = 1u << 20;
+struct FlowSpin
+{
+  uint32_t n = 0;
+  __device__ __forceinline__ bool expired(const RxParams &P, uint32_t &fail_code, uint32_t where)
+  {
+    if (++n < kFSpinLimit)
+    {
+      return false;
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+      atomicAdd(&P.counters[kCntSpec], 1u);
+    }
+    fail_code = where;
+    return true;
+  }
+};
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *p)
 {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -190,11 +214,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   __shared__ uint32_t uflag[kFEdges];      // unit u is complete in the ring: u + 1
   __shared__ float parr[kFPRing];          // per tile: geometric partial sum of v
   __shared__ uint32_t pflag[8];            // partial sums of generation g are in parr: g + 1
-  __shared__ uint32_t ctl[24];             // 0 next unit, 1 generations done, 8..23 units done (per block, mod 16)
+  __shared__ uint32_t ctl[24];             // 0 next unit, 1 generations verified (their v is released), 2 generations complete (U, V, PCM),
+                                           // 8..23 units done (per block, mod 16)
   __shared__ uint32_t magl[16][64];        // per block (mod 16: more blocks than the ring can span) and lane: sum of the sample
                                            // magnitudes.  One word per lane: a
                                            // same-address atomic from 64 lanes becomes a 64-step scalar loop (LLVM's atomic
                                            // optimizer), measured at half of the kernel's time
+  __shared__ int8_t dbfs8[128];            // the reachable part of the dBFS table
+  __shared__ uint32_t blkout[64];          // per block of the run: mean magnitude | present << 31 (written out at the end:
+                                           // a global store inside the unit loop costs the loop its counted vmcnt waits)
   __shared__ uint32_t wfin[4];             // the last finished generation's last lane: y, its last two S pairs
   static_assert(sizeof(uint32_t) * (kFRingTiles * kFStride + kFUDw + kFVDw + 5 * kFEdges + kFPRing + 1024 + 48) + 5 * kCorrBytes <= 163840, "LDS");
 
@@ -224,6 +252,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   const bool small_y = fabsf(kgain) * 3.3f < 2147483000.0f;   // |y| <= |K| pi: the int32 cast cannot overflow
   const unsigned long long t_kernel = __builtin_readcyclecounter();
   unsigned long long waited = 0;
+  uint32_t fail_code = 0;                                // which wait expired, if any (diagnostics)
 
   // tables and control words
   magl[0][tid] = 0u;
@@ -248,6 +277,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   {
     pflag[tid - 800] = 0u;
   }
+  else if (tid >= 840 && tid < 872)
+  {
+    reinterpret_cast<uint32_t *>(dbfs8)[tid - 840] = 0u;
+  }
   else if (tid >= 832 && tid < 836 && first)
   {
     // what the lane in front of tile 0 would have left: the carried y and the last four S samples
@@ -262,7 +295,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   {
     vring[kFVDw - 19 + (tid - 960)] = reinterpret_cast<const uint32_t *>(st->wb_v)[tid - 960];    // V[-38 .. -1]
   }
-  __syncthreads();                                       // the only workgroup barrier of the kernel
+  __syncthreads();
+  if (tid < 128)
+  {
+    dbfs8[tid] = (int8_t)P.dbfs[tid];
+  }
+  __syncthreads();                                       // the only workgroup barriers of the kernel
 
   if (wave >= SVC)
   {
@@ -273,8 +311,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     X.atc = atcorr;
     X.ati = att0;
     X.lane = lane;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int8_t *>(P.iq + (uint64_t)c * P.ch_stride), 0, (int)(P.n_blocks * P.block_bytes), 0x00020000);
     const uint32_t base_off = b_first * P.block_bytes - (uint32_t)hal * 16u;   // byte offset of stream sample 0
     const uint32_t dead = 0xffff0000u;                   // outside the descriptor: zeros, no memory traffic
     auto grab = [&]() -> int {
@@ -285,82 +321,179 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       }
       return __builtin_amdgcn_readfirstlane((int)g);
     };
-    auto load_piece = [&](uint4 (&q)[4], const int piece, const bool live) {
+    // The raw loads of the unit loop are hand-placed: inline asm with the destination tied to the registers the loop
+    // already owns ("+v"), so that an in-flight load never needs a copy at the back edge (a copy reads the register:
+    // s_waitcnt vmcnt(0) once per unit, which is what the compiler made of builtin loads here), and counted waits
+    // (vm_wait).  The compiler sees no vector memory operation in the loop and adds no waits of its own.
+    // In flight, oldest first, at the top of every iteration: c16 (1), qa (4), qb (4).
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t basep = (uint64_t)(P.iq + (uint64_t)c * P.ch_stride);
+    i32x4 desc;
+    desc.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)basep);
+    desc.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(basep >> 32) & 0xffffu));
+    desc.z = __builtin_amdgcn_readfirstlane((int)(P.n_blocks * P.block_bytes));
+    desc.w = 0x00020000;
+    const int lane_off = lane * 64;
+    // `dep`: stage-1 outputs that between them have read every raw register of the piece being refilled -- the asm
+    // names them as inputs, so no read of the old contents can be scheduled behind the load
+    auto load_piece = [&](u32x4 (&q)[4], const int piece, const bool live, const uint32_t (&dep)[4][4]) {
       const uint32_t soff = live ? base_off + (uint32_t)piece * 4096u : dead;
-#pragma unroll
+#if (HRFD_ABLATE & 128)
       for (int j = 0; j < 4; j++)
       {
-#if (HRFD_ABLATE & 128)
-        q[j] = make_uint4(lane * 0x01010101u + piece, lane * 0x3010501u + j, piece * 0x10101u, lane ^ (piece + soff));   // TIMING EXPERIMENT ONLY: no HBM reads
-        continue;
-#endif
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 64 + 16 * j, soff, HRFD_STREAM_AUX);
-        q[j] = make_uint4(v.x, v.y, v.z, v.w);
+        q[j] = u32x4{lane * 0x01010101u + piece, lane * 0x3010501u + j, piece * 0x10101u, lane ^ (piece + soff)};   // TIMING EXPERIMENT ONLY: no HBM reads
       }
+      return;
+#endif
+      asm volatile("buffer_load_dwordx4 %0, %4, %5, %6 offen\n\t"
+                   "buffer_load_dwordx4 %1, %4, %5, %6 offen offset:16\n\t"
+                   "buffer_load_dwordx4 %2, %4, %5, %6 offen offset:32\n\t"
+                   "buffer_load_dwordx4 %3, %4, %5, %6 offen offset:48"
+                   : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3])
+                   : "v"(lane_off), "s"(desc), "s"(soff), "v"(dep[0][1]), "v"(dep[0][3]), "v"(dep[1][1]), "v"(dep[1][3]),
+                     "v"(dep[2][1]), "v"(dep[2][3]), "v"(dep[3][1]), "v"(dep[3][3])
+                   : "memory");
     };
     // the 16 bytes in front of a unit: its front-end carries depend on nothing else
-    auto load_c16 = [&](const int u, const bool live) -> u32x4 {
+    auto load_c16 = [&](u32x4 &q, const int u, const bool live) {
       const uint32_t soff = (live && !(first && u == 0)) ? base_off + (uint32_t)u * 8192u - 16u : dead;
-      return __builtin_amdgcn_raw_buffer_load_b128(rsrc, 0, soff, 0);
+#if (HRFD_ABLATE & 128)
+      q = u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+      return;
+#endif
+      asm volatile("buffer_load_dwordx4 %0, off, %1, %2" : "+v"(q) : "s"(desc), "s"(soff) : "memory");
     };
+#if (HRFD_ABLATE & 128)
+#define VM_WAIT(n, ...)
+#else
+#define VM_WAIT(n, ...) asm volatile("s_waitcnt vmcnt(" #n ")" : __VA_ARGS__ : : "memory")
+#endif
+    // the carried state of a stream that continues the previous call, read once, long before the loop
+    const uint32_t theta_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(st->wb_theta));
+    const uint32_t p_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(st->wb_p));
+    uint32_t tail_in[4];
+    for (int i = 0; i < 4; i++)
+    {
+      tail_in[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t *>(st->fe_tail)[i]);
+    }
     // lane constant: where this lane's four samples of a piece go (tile lane / 16 of the piece, 4 (lane % 16) inside)
     const int lane_dw = kFStride * (lane >> 4) + ((4 * lane) & 63);
     int bu0 = hal >> 9, blk = 0;                         // first unit and index (in the run) of the block a unit belongs to
     unsigned long long probe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
     (void)probe; (void)tprev;
+    // the unit that completes a block (its count came back as upb - 1) finishes the block: block-mean magnitude,
+    // detector (SignalDetector.cc:255, DbfsCalculator.cc:111-147 with a 7-bit full scale).  A batch speculates
+    // every gate open; k_rx_epilogue runs the tracker and checks.
+    uint32_t pend_nth = 0u;
+    bool pend = false;
+    int pend_slot = 0, pend_blk = 0;
+    auto finish_block = [&]() {
+      if (pend && __builtin_amdgcn_readfirstlane((int)pend_nth) == upb - 1)
+      {
+        uint32_t total = magl[pend_slot][lane];
+        magl[pend_slot][lane] = 0u;
+        for (int off = 32; off > 0; off >>= 1)
+        {
+          total += __shfl_down(total, off);
+        }
+        if (lane == 0)
+        {
+          const uint32_t mean_mag = total / (uint32_t)n256;
+          int32_t dbfs = (int32_t)dbfs8[min(mean_mag, 127u)] - 42;
+          dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
+          blkout[pend_blk & 63] = mean_mag | ((dbfs >= cfg.threshold) ? 0x80000000u : 0u);
+          lds_st(&ctl[8 + pend_slot], 0u);
+          atomicAdd(&ctl[3], 1u);                        // blocks finished
+        }
+      }
+      pend = false;
+    };
     int u = grab();
-    uint4 qa[4], qb[4];
-    u32x4 c16 = load_c16(u, u < n_units);
-    load_piece(qa, 2 * u, u < n_units);
+    u32x4 qa[4], qb[4], c16;
+    for (int j = 0; j < 4; j++)
+    {
+      qa[j] = u32x4{0u, 0u, 0u, 0u};
+      qb[j] = u32x4{0u, 0u, 0u, 0u};
+    }
+    c16 = u32x4{0u, 0u, 0u, 0u};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing of the prologue's is in flight: the counts below are exact
+    load_c16(c16, u, u < n_units);
+    {
+      const uint32_t nodep[4][4] = {};
+      load_piece(qa, 2 * u, u < n_units, nodep);
+      load_piece(qb, 2 * u + 1, u < n_units, nodep);
+    }
     while (u < n_units)
     {
       FLOW_MARK(0)
       const uint32_t done_seen = lds_ld(&ctl[1]);
-      load_piece(qb, 2 * u + 1, true);
       FLOW_MARK(1)
       QuadCarry cy;
-      if (first && u == 0)
+      VM_WAIT(8, "+v"(c16));
       {
-        cy.fe = carry_from_16(*reinterpret_cast<const uint4 *>(st->fe_tail));
-        cy.theta = f2u(st->wb_theta);
-        cy.p = f2u(st->wb_p);
+        const bool st0 = first && u == 0;                // "the 16 bytes in front" of a continued stream are the carried ones
+        cy.fe = carry_from_16(make_uint4(st0 ? tail_in[0] : c16.x, st0 ? tail_in[1] : c16.y, st0 ? tail_in[2] : c16.z,
+                                         st0 ? tail_in[3] : c16.w));
       }
-      else
-      {
-        cy.fe = carry_from_16(make_uint4(c16.x, c16.y, c16.z, c16.w));
-        cy.theta = 0u;                                   // the unit's first two v are provisional: patched by the service wave
-        cy.p = 0u;
-      }
+      // a unit's first two v are provisional (theta and b0*x of the sample in front are another wave's): patched by
+      // the service wave -- except at the very start of a stream that continues the previous call
+      cy.theta = (first && u == 0) ? theta_in : 0u;
+      cy.p = (first && u == 0) ? p_in : 0u;
       FLOW_MARK(2)
       // ring space: the tiles this unit overwrites must not be anybody's warm-up any more
       if (8 * u + 8 + wt > 64 * (int)done_seen + kFRingTiles)
       {
         const unsigned long long t0 = __builtin_readcyclecounter();
-        while (8 * u + 8 + wt > 64 * (int)lds_ld(&ctl[1]) + kFRingTiles)
+        FlowSpin sp;
+        while (8 * u + 8 + wt > 64 * (int)lds_ld(&ctl[1]) + kFRingTiles && !sp.expired(P, fail_code, 1))
         {
           __builtin_amdgcn_s_sleep(8);
         }
         waited += __builtin_readcyclecounter() - t0;
       }
+      finish_block();                                    // of the previous unit
       FLOW_MARK(3)
       const int slot0 = ring_slot(8 * u);                // NT is a multiple of 8: a unit never wraps
       uint32_t *dst = ring + slot0 * kFStride + lane_dw;
       uint32_t v[4], mag4, magsum;
       float theta[4];
-      quad_piece<2>(qa, cy, X, v, theta, mag4);
+#if HRFD_FLOW_EARLY_GRAB
+      uint32_t un_v = 0;
+      if (lane == 0)
+      {
+        un_v = atomicAdd(&ctl[0], 1u);
+      }
+#endif
+      // (the next unit's loads go out from inside the pieces, as soon as a piece's raw registers are free:
+      //  almost two pieces of lead without a register more)
+      int un = 0;
+      VM_WAIT(4, "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]));
+      {
+        const uint4 ra[4] = {make_uint4(qa[0].x, qa[0].y, qa[0].z, qa[0].w), make_uint4(qa[1].x, qa[1].y, qa[1].z, qa[1].w),
+                             make_uint4(qa[2].x, qa[2].y, qa[2].z, qa[2].w), make_uint4(qa[3].x, qa[3].y, qa[3].z, qa[3].w)};
+        quad_piece<2>(ra, cy, X, v, theta, mag4, [&](const uint32_t (&y1)[4][4]) {
+#if HRFD_FLOW_EARLY_GRAB
+          un = __builtin_amdgcn_readfirstlane((int)un_v);
+#else
+          un = grab();
+#endif
+          load_c16(c16, un, un < n_units);
+          load_piece(qa, 2 * un, un < n_units, y1);
+        });
+      }
       reinterpret_cast<uint2 *>(dst)[0] = make_uint2(v[0], v[1]);
       reinterpret_cast<uint2 *>(dst)[1] = make_uint2(v[2], v[3]);
       magsum = mag4;
       const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[0]), 0);
       const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[1]), 0);
       FLOW_MARK(4)
-      // the next unit: taken only now (a unit that is reserved early keeps the ring's completed frontier back), its loads
-      // go out at once -- a piece of lead, across the unit boundary
-      const int un = grab();
-      c16 = load_c16(un, un < n_units);
-      load_piece(qa, 2 * un, un < n_units);
       FLOW_MARK(5)
-      quad_piece<2>(qb, cy, X, v, theta, mag4);
+      VM_WAIT(5, "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+      {
+        const uint4 rb[4] = {make_uint4(qb[0].x, qb[0].y, qb[0].z, qb[0].w), make_uint4(qb[1].x, qb[1].y, qb[1].z, qb[1].w),
+                             make_uint4(qb[2].x, qb[2].y, qb[2].z, qb[2].w), make_uint4(qb[3].x, qb[3].y, qb[3].z, qb[3].w)};
+        quad_piece<2>(rb, cy, X, v, theta, mag4, [&](const uint32_t (&y1)[4][4]) { load_piece(qb, 2 * un + 1, un < n_units, y1); });
+      }
       reinterpret_cast<uint2 *>(dst + 4 * kFStride)[0] = make_uint2(v[0], v[1]);
       reinterpret_cast<uint2 *>(dst + 4 * kFStride)[1] = make_uint2(v[2], v[3]);
       magsum += mag4;
@@ -383,40 +516,49 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
         slot = blk & 15;
         atomicAdd(&magl[slot][lane], magsum);
       }
-      lds_order();
-      uint32_t nth = 0;
+      // LDS executes a wave's operations in order: the flag and the block's unit count go out behind the data
+      // without waiting for anything; the count's old value is looked at one unit later (pend_*)
+      asm volatile("" ::: "memory");
+      pend_nth = 0u;
       if (lane == 0)
       {
         lds_st(&uflag[u & (kFEdges - 1)], (uint32_t)u + 1u);
         if (counted)
         {
-          nth = atomicAdd(&ctl[8 + slot], 1u);
+          pend_nth = atomicAdd(&ctl[8 + slot], 1u);
         }
       }
-      if (counted && __builtin_amdgcn_readfirstlane((int)nth) == upb - 1)
-      {
-        // this unit completed its block: block-mean magnitude, detector (SignalDetector.cc:255,
-        // DbfsCalculator.cc:111-147 with a 7-bit full scale).  A batch speculates every gate open;
-        // k_rx_epilogue runs the tracker and checks.
-        uint32_t total = magl[slot][lane];
-        magl[slot][lane] = 0u;
-        for (int off = 32; off > 0; off >>= 1)
-        {
-          total += __shfl_down(total, off);
-        }
-        if (lane == 0)
-        {
-          const uint32_t mean_mag = total / (uint32_t)n256;
-          int32_t dbfs = P.dbfs[min(mean_mag, 127u)] - 42;
-          dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
-          const uint32_t b = b_first + (uint32_t)blk;
-          P.magnitude[(size_t)c * P.out_blocks + P.out_b0 + b] = mean_mag;
-          P.present[(size_t)c * P.n_blocks + b] = (dbfs >= cfg.threshold) ? 1 : 0;
-          lds_st(&ctl[8 + slot], 0u);
-        }
-      }
+      pend = counted;
+      pend_slot = slot;
+      pend_blk = blk;
       u = un;
       FLOW_MARK(7)
+    }
+    // The last prefetches (pointed outside the buffer) are still in flight, and the compiler does not know: their
+    // registers must stay reserved until they have landed, or whatever reuses them is overwritten with zeros.
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(c16), "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]), "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3])
+                 :
+                 : "memory");
+    finish_block();
+    if (wave == SVC)
+    {
+      // every stream wave is through its units by now or about to be: wait for the last blocks, then the
+      // squelch inputs of the whole run go out
+      const uint32_t nb = b_end - b_first;
+      FlowSpin sp;
+      while (lds_ld(&ctl[3]) != nb && !sp.expired(P, fail_code, 2))
+      {
+        __builtin_amdgcn_s_sleep(2);
+      }
+      lds_order();
+      for (uint32_t i = lane; i < nb; i += 64)
+      {
+        const uint32_t w = blkout[i & 63];
+        const uint32_t b = b_first + i;
+        P.magnitude[(size_t)c * P.out_blocks + P.out_b0 + b] = w & 0x7fffffffu;
+        P.present[(size_t)c * P.n_blocks + b] = (uint8_t)(w >> 31);
+      }
     }
 #ifdef HRFD_FLOW_PROBE
     if (P.dbg != nullptr && lane == 0)
@@ -457,14 +599,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
         const int ulo = max(8 * g - 1, 0), uhi = 8 * g + (ntl >> 3);
         const int uu = ulo + lane;
         const unsigned long long tw0 = __builtin_readcyclecounter();
+        FlowSpin sp;
         for (;;)
         {
           const bool ok = (uu >= uhi) || lds_ld(&uflag[uu & (kFEdges - 1)]) == (uint32_t)uu + 1u;
-          if (__all(ok))
+          if (__all(ok) || sp.expired(P, fail_code, 3))
           {
             break;
           }
-          __builtin_amdgcn_s_sleep(8);
+          __builtin_amdgcn_s_sleep(2);
         }
         waited += __builtin_readcyclecounter() - tw0;
         lds_order();
@@ -519,7 +662,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       if (g > 0 && M > 0)
       {
         const unsigned long long tw0 = __builtin_readcyclecounter();
-        while (lds_ld(&pflag[(g - 1) & 7]) != (uint32_t)g)
+        FlowSpin sp;
+        while (lds_ld(&pflag[(g - 1) & 7]) != (uint32_t)g && !sp.expired(P, fail_code, 4))
         {
           __builtin_amdgcn_s_sleep(4);
         }
@@ -577,12 +721,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
         }
       }
       SVC_MARK(5)
-      // 5. generations complete in order
+      // 5. generations are verified in order ...
       {
         const unsigned long long tw0 = __builtin_readcyclecounter();
-        while (lds_ld(&ctl[1]) != (uint32_t)g)
+        FlowSpin sp;
+        while (lds_ld(&ctl[1]) != (uint32_t)g && !sp.expired(P, fail_code, 5))
         {
-          __builtin_amdgcn_s_sleep(4);
+          __builtin_amdgcn_s_sleep(2);
         }
         waited += __builtin_readcyclecounter() - tw0;
         lds_order();
@@ -617,6 +762,33 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
           const bool bad2 = (lane == l + 1) && active && !same_trajectory(y_new_left, y_spec);
           bm |= __ballot(bad2);
         }
+      }
+      // ... and hand their last lane's end to the next one at once: from here on nobody reads this generation's v
+      // (but for the next one's warm-up over its last tiles, which the ring check of the stream waves allows for)
+      const uint32_t fy = (uint32_t)__builtin_amdgcn_readlane((int)f2u(o.y), ntl - 1);
+      const uint32_t fs0 = (uint32_t)__builtin_amdgcn_readlane((int)o.slast0, ntl - 1);
+      const uint32_t fs1 = (uint32_t)__builtin_amdgcn_readlane((int)o.slast1, ntl - 1);
+      if (lane == 0)
+      {
+        wfin[0] = fy;
+        wfin[1] = fs0;
+        wfin[2] = fs1;
+      }
+      asm volatile("" ::: "memory");
+      if (lane == 0)
+      {
+        lds_st(&ctl[1], (uint32_t)g + 1u);
+      }
+      // the integer stages follow in a chain of their own
+      {
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+        FlowSpin sp;
+        while (lds_ld(&ctl[2]) != (uint32_t)g && !sp.expired(P, fail_code, 6))
+        {
+          __builtin_amdgcn_s_sleep(2);
+        }
+        waited += __builtin_readcyclecounter() - tw0;
+        lds_order();
       }
       // 7. U[0] of every tile: S[-4 .. -1] are the LEFT lane's last four samples (its final ones)
       {
@@ -698,9 +870,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       }
       // 11. hand over to the next generation
       {
-        const uint32_t fy = (uint32_t)__builtin_amdgcn_readlane((int)f2u(o.y), ntl - 1);
-        const uint32_t fs0 = (uint32_t)__builtin_amdgcn_readlane((int)o.slast0, ntl - 1);
-        const uint32_t fs1 = (uint32_t)__builtin_amdgcn_readlane((int)o.slast1, ntl - 1);
         if (g + 1 == n_gens && b_end == P.n_blocks)
         {
           // the carried state for the next call (pending: k_rx_commit copies it when the launch verified clean)
@@ -722,16 +891,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
             reinterpret_cast<uint32_t *>(so->wb_v)[lane] = vring[(2 * n_tiles - 19 + lane) & (kFVDw - 1)];
           }
         }
+        asm volatile("" ::: "memory");
         if (lane == 0)
         {
-          wfin[0] = fy;
-          wfin[1] = fs0;
-          wfin[2] = fs1;
-        }
-        lds_order();
-        if (lane == 0)
-        {
-          lds_st(&ctl[1], (uint32_t)g + 1u);
+          lds_st(&ctl[2], (uint32_t)g + 1u);
         }
       }
       SVC_MARK(9)
@@ -754,6 +917,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   {
     // per wave: cycles spent waiting (ring full / units not there yet / generation order); slot 0: the workgroup's cycles
     P.dbg[(size_t)blockIdx.x * kDbgSlots + 8 + wave] = waited;
+    if (fail_code != 0u)
+    {
+      P.dbg[(size_t)blockIdx.x * kDbgSlots + 7] = 0x100000000ull * fail_code + (unsigned)wave + 1u;
+    }
     if (tid == 0)
     {
       P.dbg[(size_t)blockIdx.x * kDbgSlots + 0] = __builtin_readcyclecounter() - t_kernel;

@@ -1797,9 +1797,15 @@ struct QuadCarry
 
 // one 4 KiB piece: raw[j] = the lane's group j (16 bytes) -> v[4]; returns the four thetas
 // ARITH: 0 table gather from global memory, 1 theta_arith, 2 theta_tab (X.ati is then T0)
-template <int ARITH>
+struct NoHook
+{
+  __device__ __forceinline__ void operator()(const uint32_t (&)[4][4]) const {}
+};
+// `raw_free` is called once the raw registers are dead (behind stage 1, whose outputs it gets so that it can make
+// whatever it does depend on them): the caller may refill the registers there
+template <int ARITH, class Hook = NoHook>
 __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, const StreamCtx &X,
-                                           uint32_t (&vout)[4], float (&theta)[4], uint32_t &mag4)
+                                           uint32_t (&vout)[4], float (&theta)[4], uint32_t &mag4, Hook &&raw_free = NoHook())
 {
   uint32_t r[4][4];
 #pragma unroll
@@ -1831,6 +1837,7 @@ __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, 
     y1[j][2] = __builtin_amdgcn_perm(0u, y23, 0x0c010c00u);
     y1[j][3] = __builtin_amdgcn_perm(0u, y23, 0x0c030c02u);
   }
+  raw_free(y1);
   // stage 2
   uint32_t y20b[4], y21[4];
   const uint32_t y1m1_0 = shr1(y1[3][3], c.fe.y13);

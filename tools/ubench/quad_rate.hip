@@ -5,14 +5,14 @@
 #include <stdio.h>
 using namespace hrfd;
 
-template <int LDSREAD>
+template <int ATAN>
 __global__ __launch_bounds__(1024, 4) void k_quad(unsigned long long *out, int iters, const uint8_t *gcorr, const float *ginv, float kgain)
 {
   __shared__ __attribute__((aligned(16))) uint8_t atcorr[kCorrBytes];
-  __shared__ __attribute__((aligned(16))) float atinv[kInvEntries];
+  __shared__ __attribute__((aligned(16))) float atinv[ATAN == 2 ? kCorrBytes : kInvEntries];
   __shared__ uint32_t sink[1024 * 4];
   for (int i = threadIdx.x; i < kCorrBytes; i += blockDim.x) atcorr[i] = gcorr[i];
-  for (int i = threadIdx.x; i < kInvEntries; i += blockDim.x) atinv[i] = ginv[i];
+  for (int i = threadIdx.x; i < (ATAN == 2 ? kCorrBytes : kInvEntries); i += blockDim.x) atinv[i] = ginv[i % kInvEntries];
   __syncthreads();
   StreamCtx X;
   X.kgain = kgain;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(1024, 4) void k_quad(unsigned long long *out, int i
   {
     uint32_t v[4], mag4;
     float theta[4];
-    quad_piece<true>(raw, c, X, v, theta, mag4);
+    quad_piece<ATAN>(raw, c, X, v, theta, mag4);
     // feed the outputs back so that nothing is hoisted or dropped; one LDS store like the kernel's
     *reinterpret_cast<uint4 *>(sink + 4 * threadIdx.x) = make_uint4(v[0], v[1], v[2], v[3]);
     acc += mag4;
@@ -63,14 +63,16 @@ int main()
   float inv[kInvEntries] = {0};
   for (int a = 1; a <= 128; a++) inv[a] = 1.0f / (float)a;
   hipMemcpy(di, inv, sizeof(inv), hipMemcpyHostToDevice);
-  const int iters = 400;
+  const int iters = 2000;
+  for (int atan = 1; atan <= 2; atan++)
   for (int threads : {256, 512, 768, 1024})
   {
+    auto kern = (atan == 1) ? k_quad<1> : k_quad<2>;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_quad<1>, dim3(256), dim3(threads), 0, 0, d, iters, dc, di, 13351.9f);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, d, iters, dc, di, 13351.9f);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_quad<1>, dim3(256), dim3(threads), 0, 0, d, iters, dc, di, 13351.9f);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(threads), 0, 0, d, iters, dc, di, 13351.9f);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
@@ -78,8 +80,8 @@ int main()
     double sum = 0; int n = 256 * (threads / 64);
     for (int i = 0; i < n; i++) sum += (double)h[i];
     const double cyc = sum / n;                      // cycles one wave spent on `iters` pieces
-    printf("%d waves/SIMD: %.0f cycles per piece per wave, %.0f cycles per piece per SIMD (wall %.3f ms)\n",
-           threads / 256, cyc / iters, cyc / iters / (threads / 256), ms);
+    printf("atan %d, %d waves/SIMD: %.0f cycles per piece per wave, %.0f cycles per piece per SIMD (wall %.3f ms)\n",
+           atan, threads / 256, cyc / iters, cyc / iters / (threads / 256), ms);
   }
   return 0;
 }
