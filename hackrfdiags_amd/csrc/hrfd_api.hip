@@ -978,6 +978,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       }
       else if (flow)
       {
+        P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here
         hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       else if (streaming)

@@ -39,6 +39,12 @@
 #ifndef HRFD_FLOW_EARLY_GRAB
 #define HRFD_FLOW_EARLY_GRAB 1      /* take the next unit before piece 0 (its LDS round trip hides behind the piece) instead of behind it */
 #endif
+#ifndef HRFD_FLOW_WARM_TILES
+#define HRFD_FLOW_WARM_TILES 3      /* warm-up of the recurrence tiles, in tiles of 64 samples */
+#endif
+#ifndef HRFD_FLOW_STREAM_PRIO
+#define HRFD_FLOW_STREAM_PRIO 0
+#endif
 #ifndef HRFD_FLOW_SVC_PRIO
 #define HRFD_FLOW_SVC_PRIO 2
 #endif
@@ -214,7 +220,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   __shared__ uint32_t uflag[kFEdges];      // unit u is complete in the ring: u + 1
   __shared__ float parr[kFPRing];          // per tile: geometric partial sum of v
   __shared__ uint32_t pflag[8];            // partial sums of generation g are in parr: g + 1
-  __shared__ uint32_t ctl[24];             // 0 next unit, 1 generations verified (their v is released), 2 generations complete (U, V, PCM),
+  __shared__ uint32_t ctl[24];             // 0 next unit, 1 generations verified (their v is released), 2 generations complete (U, V, PCM), 3 blocks finished,
+                                           // 4 next generation,
                                            // 8..23 units done (per block, mod 16)
   __shared__ uint32_t magl[16][64];        // per block (mod 16: more blocks than the ring can span) and lane: sum of the sample
                                            // magnitudes.  One word per lane: a
@@ -305,6 +312,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   if (wave >= SVC)
   {
     // =================================================================== stream waves: raw IQ -> v
+#if HRFD_FLOW_STREAM_PRIO == 1
+    // the arbiter serves the oldest wave of a SIMD first: the young ones lag, hold the ring's completed frontier back and
+    // the old ones run into the ring limit.  Static priorities the other way round.
+    if (wave >= 12) __builtin_amdgcn_s_setprio(2);
+    else if (wave >= 8) __builtin_amdgcn_s_setprio(1);
+#elif HRFD_FLOW_STREAM_PRIO == 2
+    if (wave >= 12) __builtin_amdgcn_s_setprio(1);
+#endif
     StreamCtx X;
     X.P = &P;
     X.kgain = kgain;
@@ -587,7 +602,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     uint32_t repairs = 0;
     unsigned long long sprobe[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_readcyclecounter();
     (void)sprobe; (void)sprev;
-    for (int g = wave; g < n_gens; g += SVC)
+    // generations are taken in order by whichever service wave is free (a fixed rotation makes generation g wait
+    // behind g - SVC on a wave that is late while the others idle)
+    auto grab_gen = [&]() -> int {
+      uint32_t v = 0;
+      if (lane == 0)
+      {
+        v = atomicAdd(&ctl[4], 1u);
+      }
+      return __builtin_amdgcn_readfirstlane((int)v);
+    };
+    for (int g = grab_gen(); g < n_gens; g = grab_gen())
     {
       SVC_MARK(0)
       const int t0 = 64 * g;

@@ -376,6 +376,21 @@ __device__ __forceinline__ float wrap_pi(float d)
   return (fabsf(d) >= pi_up) ? w : d;
 }
 
+// The same wrap without compare and select: n = rint(d * CM) is 0 or +-1, with CM the float for which the flip
+// falls exactly between the largest float below M_PI and the smallest above it; d - n*C_HI is exact, the second
+// fma rounds once like the second subtraction of wrap_pi.  tools/proofs/wrap_rint.c checks EVERY float d with
+// |d| <= 6.5 against the reference's double arithmetic (d = -0.0, which a difference of table thetas never is,
+// comes out as +0.0).  Four instructions for seven.
+__device__ __forceinline__ float wrap_pi_rint(float d)
+{
+  const float cm = u2f(0x3e22f984u);                     // ~ 1 / (2 pi)
+  const float c_hi = u2f(0x40c90fdbu);                   // (float)(2*M_PI)
+  const float c_lo = u2f(0xb43bbd2eu);                   // (float)(2*M_PI - C_HI)
+  const float n = __builtin_rintf(d * cm);
+  const float u = __builtin_fmaf(-n, c_hi, d);
+  return __builtin_fmaf(-n, c_lo, u);
+}
+
 // (int16_t)f the way x86-64 does it (cvttss2si, then the low 16 bits): NaN and
 // |f| >= 2^31 give 0x80000000 -> 0.  v_cvt_i32_f32 saturates instead, so the
 // positive overflow is patched (INT_MAX can only come from saturation).
@@ -664,10 +679,11 @@ __device__ __forceinline__ uint4 load_chunk(const StreamCtx &X, int chunk, int l
 // phase difference -> de-emphasis numerator, WbFmDemodulator.cc:404-430 and the
 // FIR half of IirFilter::filterData: d = wrap(theta - theta_prev); x = K*d;
 // p = b0*x (b1 == b0, so p is also next sample's b1*x[n-1]); v = p + p_prev.
+template <bool RINT = false>
 __device__ __forceinline__ float numerator_p(float theta, float theta_prev, float kgain)
 {
   float d = theta - theta_prev;
-  d = wrap_pi(d);
+  d = RINT ? wrap_pi_rint(d) : wrap_pi(d);
   const float x = kgain * d;
   return DEEMPH_B0 * x;
 }
@@ -1885,10 +1901,10 @@ __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, 
   const float thp0 = u2f(shr1(f2u(theta[3]), c.theta));
   c.theta = ror1(f2u(theta[3]));
   float p[4];
-  p[0] = numerator_p(theta[0], thp0, X.kgain);
-  p[1] = numerator_p(theta[1], theta[0], X.kgain);
-  p[2] = numerator_p(theta[2], theta[1], X.kgain);
-  p[3] = numerator_p(theta[3], theta[2], X.kgain);
+  p[0] = numerator_p<ARITH == 2>(theta[0], thp0, X.kgain);
+  p[1] = numerator_p<ARITH == 2>(theta[1], theta[0], X.kgain);
+  p[2] = numerator_p<ARITH == 2>(theta[2], theta[1], X.kgain);
+  p[3] = numerator_p<ARITH == 2>(theta[3], theta[2], X.kgain);
   const float pp0 = u2f(shr1(f2u(p[3]), c.p));
   c.p = ror1(f2u(p[3]));
   vout[0] = f2u(p[0] + pp0);
