@@ -40,13 +40,13 @@
 #define HRFD_FLOW_EARLY_GRAB 1      /* take the next unit before piece 0 (its LDS round trip hides behind the piece) instead of behind it */
 #endif
 #ifndef HRFD_FLOW_WARM_TILES
-#define HRFD_FLOW_WARM_TILES 3      /* warm-up of the recurrence tiles, in tiles of 64 samples */
+#define HRFD_FLOW_WARM_TILES 2      /* warm-up of the recurrence tiles, in tiles of 64 samples (2: ~7e-4 of the tiles are repaired in place) */
 #endif
 #ifndef HRFD_FLOW_STREAM_PRIO
-#define HRFD_FLOW_STREAM_PRIO 0
+#define HRFD_FLOW_STREAM_PRIO 3      /* 0 none, 1 / 2 static by wave age, 3 by lag (a wave that has fallen behind gets priority) */
 #endif
 #ifndef HRFD_FLOW_SVC_PRIO
-#define HRFD_FLOW_SVC_PRIO 2
+#define HRFD_FLOW_SVC_PRIO 3
 #endif
 // diagnostic build: -DHRFD_FLOW_PROBE accumulates, per stream wave, the cycles between the marks of its unit loop
 // (slots 24..31 of its workgroup's stamp row are summed over the waves; read with tools/gpu_flow_times.py)
@@ -111,6 +111,19 @@ struct FlowSpin
     return true;
   }
 };
+// A returning LDS atomic whose result is looked at LATER: the compiler would wait for an atomicAdd() at once (and
+// LLVM's atomic optimizer puts a readfirstlane right behind it), i.e. for every LDS operation of the wave that is
+// still queued in front of it -- hundreds of cycles per unit of a stream wave.  `ret` must go through lds_landed()
+// before it is read.  One lane must call this (exec is what the caller's branch left).
+__device__ __forceinline__ void lds_add_async(uint32_t &ret, const uint32_t *p, uint32_t val)
+{
+  const uint32_t off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)p;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(ret) : "v"(off), "v"(val) : "memory");
+}
+__device__ __forceinline__ void lds_landed(uint32_t &ret)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ret) : : "memory");
+}
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t *p)
 {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -403,6 +416,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     bool pend = false;
     int pend_slot = 0, pend_blk = 0;
     auto finish_block = [&]() {
+      if (pend)
+      {
+        lds_landed(pend_nth);
+      }
       if (pend && __builtin_amdgcn_readfirstlane((int)pend_nth) == upb - 1)
       {
         uint32_t total = magl[pend_slot][lane];
@@ -456,7 +473,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       cy.p = (first && u == 0) ? p_in : 0u;
       FLOW_MARK(2)
       // ring space: the tiles this unit overwrites must not be anybody's warm-up any more
-      if (8 * u + 8 + wt > 64 * (int)done_seen + kFRingTiles)
+      if (!(HRFD_ABLATE & (1024 | 2048)) && 8 * u + 8 + wt > 64 * (int)done_seen + kFRingTiles)   // (1024: TIMING EXPERIMENT ONLY, stream waves alone)
       {
         const unsigned long long t0 = __builtin_readcyclecounter();
         FlowSpin sp;
@@ -476,7 +493,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       uint32_t un_v = 0;
       if (lane == 0)
       {
-        un_v = atomicAdd(&ctl[0], 1u);
+        lds_add_async(un_v, &ctl[0], 1u);
       }
 #endif
       // (the next unit's loads go out from inside the pieces, as soon as a piece's raw registers are free:
@@ -488,7 +505,28 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
                              make_uint4(qa[2].x, qa[2].y, qa[2].z, qa[2].w), make_uint4(qa[3].x, qa[3].y, qa[3].z, qa[3].w)};
         quad_piece<2>(ra, cy, X, v, theta, mag4, [&](const uint32_t (&y1)[4][4]) {
 #if HRFD_FLOW_EARLY_GRAB
+          lds_landed(un_v);
           un = __builtin_amdgcn_readfirstlane((int)un_v);
+#if HRFD_FLOW_STREAM_PRIO == 3
+          // fairness: the arbiter serves the oldest wave of a SIMD first, so the young ones fall behind, hold the
+          // ring's completed frontier back and the old ones run into the ring limit.  A wave that sees more units
+          // taken since its own than there are stream waves is late: it gets priority until its next unit.
+          {
+            const int lag = un - u;
+            if (lag > 16)
+            {
+              __builtin_amdgcn_s_setprio(2);
+            }
+            else if (lag > 13)
+            {
+              __builtin_amdgcn_s_setprio(1);
+            }
+            else
+            {
+              __builtin_amdgcn_s_setprio(0);
+            }
+          }
+#endif
 #else
           un = grab();
 #endif
@@ -540,7 +578,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
         lds_st(&uflag[u & (kFEdges - 1)], (uint32_t)u + 1u);
         if (counted)
         {
-          pend_nth = atomicAdd(&ctl[8 + slot], 1u);
+          lds_add_async(pend_nth, &ctl[8 + slot], 1u);
         }
       }
       pend = counted;
@@ -612,7 +650,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       }
       return __builtin_amdgcn_readfirstlane((int)v);
     };
-    for (int g = grab_gen(); g < n_gens; g = grab_gen())
+    for (int g = grab_gen(); g < n_gens && !(HRFD_ABLATE & 1024); g = grab_gen())
     {
       SVC_MARK(0)
       const int t0 = 64 * g;
@@ -632,7 +670,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
           {
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(6);
         }
         waited += __builtin_readcyclecounter() - tw0;
         lds_order();
@@ -661,17 +699,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       // 3. geometric partial sum of v over the own tile: P = sum_k c^k v[63 - k], c = -a1 (approximate on purpose)
       if (have && M > 0)
       {
+        // (the even and the odd samples as the two halves of one packed fma: a lone wave is bound by its instruction count)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
         const float cc = -a1, c2 = cc * cc;
-        const uint2 *p2 = reinterpret_cast<const uint2 *>(tp);
-        float pa = 0.0f, pb = 0.0f;
+        const f32x2 c22 = {c2, c2};
+        const f32x2 *p2 = reinterpret_cast<const f32x2 *>(tp);
+        f32x2 pab = {0.0f, 0.0f};
 #pragma unroll 8
         for (int j = 0; j < kFT / 2; j++)
         {
-          const uint2 w = p2[j];
-          pa = __builtin_fmaf(pa, c2, u2f(w.x));
-          pb = __builtin_fmaf(pb, c2, u2f(w.y));
+          pab = __builtin_elementwise_fma(pab, c22, p2[j]);
         }
-        float p = __builtin_fmaf(pa, cc, pb);
+        float p = __builtin_fmaf(pab.x, cc, pab.y);
         if (first && t == 0)
         {
           p += deemph_pow(kFT) * st->wb_y;               // the stream's past, as seen from the end of tile 0

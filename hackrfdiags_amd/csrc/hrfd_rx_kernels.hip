@@ -408,8 +408,8 @@ __device__ __forceinline__ uint32_t pack_s16(float lo, float hi)
   {
     return ((uint32_t)f2i16(lo) & 0xffffu) | ((uint32_t)f2i16(hi) << 16);
   }
-  // |y| < 2^31 is known: v_cvt_i32_f32 cannot saturate, the low 16 bits are x86's
-  return ((uint32_t)(int)lo & 0xffffu) | ((uint32_t)(int)hi << 16);
+  // |y| < 2^31 is known: v_cvt_i32_f32 cannot saturate, the low 16 bits are x86's (one v_perm packs the two low halves)
+  return __builtin_amdgcn_perm((uint32_t)(int)hi, (uint32_t)(int)lo, 0x05040100u);
 }
 
 // Have two runs of the de-emphasis recurrence become the same trajectory?
