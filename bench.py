@@ -168,7 +168,8 @@ def bench_ssbmod(args, api, device, rank, world, dist):
             "value": round(value, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int16 PCM -> Q15 int32 -> int8 IQ", "data": "synthetic",
-            "config": {"workload": f"{C} {kname} modulator channels per GPU (BASELINE config 5), {B} blocks of 512 PCM "
+            "config": {"workload": f"{C} {kname} modulator channels per GPU (BASELINE config 5" + ("" if (C, args.workload) == (1024, "ssbmod") else
+                                   " is 1024 SSB channels") + f"), {B} blocks of 512 PCM "
                                    f"samples per step, 8-stage x256 half-band interpolator", "channels_per_gpu": C,
                        "blocks_per_step": B},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -224,10 +225,23 @@ def bench_ingest(args, api, device, rank, world, dist):
                        "blocks_per_step": B},
             "pcie_GBps": round(C * B * BLOCK * args.steps / elapsed / 1e9, 2),
             "replayed_batches": ing.replayed(),
+            **({"invalid": "batches were replayed on the exact path"} if ing.replayed() else {}),
         }), flush=True)
     ing.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def kernel_source_tag():
+    """sha256 (first 16 hex digits) of the kernel sources: ties a committed PMC summary to the code it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hackrfdiags_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic_bytes(args, C, B):
@@ -235,16 +249,81 @@ def pmc_traffic_bytes(args, C, B):
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs of this same command; the summary
     is committed under profiles/).  gfx950: FETCH_SIZE counts 64 B per 128-B request for wide
     coalesced reads, hence the factor 2 (MI355X_MICROARCH.md).  None when the workload differs
-    from the profiled one."""
+    from the profiled one OR when the kernel sources have changed since that profile (the summary
+    carries the source tag it was taken with)."""
     if args.workload != "wbfm" or (C, B) != (256, 16):
-        return None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "latest_pmc_traffic_wbfm256x16.json")
+        return None, None
+    path = os.path.join(ROOT, "profiles", "latest_pmc_traffic_wbfm256x16.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        return int(t["FETCH_SIZE"]["mean"] * 1024 * 2 + t["WRITE_SIZE"]["mean"] * 1024)
+        if t.get("kernel_source_tag") != kernel_source_tag():
+            return None, t.get("kernel_source_tag")
+        return int(t["FETCH_SIZE"]["mean"] * 1024 * 2 + t["WRITE_SIZE"]["mean"] * 1024), t.get("kernel_source_tag")
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+
+
+def stream_copy_gbs(device):
+    """Second denominator: what a plain device-to-device copy of 1 GiB reaches on this GPU in this
+    run, read + write bytes over the time of the copy kernel (HIP events, 10 copies after 3 warm-ups)."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.int8, device=device)
+    b = torch.empty(n, dtype=torch.int8, device=device)
+    a.random_(0, 127)
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    del a, b
+    return 2 * n / (ms * 1e-3) / 1e9
+
+
+def end_to_end(api, device, C):
+    """Host to host: pinned batches of [C][4][262144] through hrfd_ingest_* -- H2D, the kernels and
+    the D2H of the PCM on three streams, two batches in flight.  Never the headline value."""
+    rx = api.Rx(C, device=device.index)
+    rx.set_mode(api.WBFM)
+    B = 4
+    ing = api.Ingest(rx, BLOCK, B, 2)
+    x = make_fm_batch(C, B, device).cpu().numpy()
+    for _ in range(2):
+        ing.acquire()[...] = x
+        ing.submit(0)
+    for _ in range(2):
+        ing.collect()
+    steps = 6
+    t0 = time.perf_counter()
+    ing.acquire(); ing.submit(0)
+    for i in range(steps):
+        if i + 1 < steps:
+            ing.acquire(); ing.submit(0)
+        ing.collect()
+    dt = time.perf_counter() - t0
+    out = {"MSamples/s": round(C * B * (BLOCK // 2) * steps / dt / 1e6, 1), "pcie_GBps": round(C * B * BLOCK * steps / dt / 1e9, 2),
+           "batch": f"{C} channels x {B} blocks from pinned host memory, 2 batches in flight", "replayed_batches": ing.replayed()}
+    ing.close()
+    return out
+
+
+def single_block_latency_ms(api, device):
+    """The reference's real cadence: ONE channel, ONE 262144-byte block (64 ms of signal) per call, host buffer in,
+    PCM out, through hrfd_rx_process_block (what the IqDataProcessor shim's acceptIqData does).  Median of 30."""
+    from hackrfdiags_amd import synth
+    rx = api.Rx(1, device=device.index)
+    rx.set_mode(api.WBFM)
+    x = synth.make_input("fmtone", 0, 4).reshape(1, 4, BLOCK)
+    ts = []
+    for i in range(34):
+        t0 = time.perf_counter()
+        rx.process_block(x[:, i % 4:i % 4 + 1], 1)
+        ts.append(time.perf_counter() - t0)
+    return round(1e3 * float(np.median(ts[4:])), 3)
 
 
 def main():
@@ -253,7 +332,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100,
                     help="untimed steps; the clock governor needs ~25 ms of this load to settle (DESIGN.md 5)")
-    ap.add_argument("--channels", type=int, default=256, help="channels per GPU (BASELINE config 2)")
+    ap.add_argument("--channels", type=int, default=0,
+                    help="channels per GPU; default: 256 on one GPU (BASELINE config 2), 512 per GPU on several "
+                         "(config 4: 4096 channels over 8 GPUs), 1024 for the modulator workloads (config 5)")
     ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
     ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")
     ap.add_argument("--workload", choices=["wbfm", "mixed", "ssbmod", "ammod", "fmmod", "wbfmmod", "ingest"], default="wbfm",
@@ -266,6 +347,8 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.channels <= 0:
+        args.channels = 1024 if args.workload in ("ssbmod", "ammod", "fmmod", "wbfmmod") else (256 if world == 1 else 512)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -339,6 +422,8 @@ def main():
     produced = int(n_pcm.sum().item())
     assert produced == C * B * 512, f"PCM samples produced {produced} != {C * B * 512}"
 
+    traffic, ptag = pmc_traffic_bytes(args, C, B)
+    copy_gbs = stream_copy_gbs(device)
     samples_per_step = C * B * (BLOCK // 2)
     value = world * samples_per_step * args.steps / elapsed / 1e6            # MSamples/s, whole job
     algo_bytes = C * B * (BLOCK + 1024 + 4)                                   # 2.0078 B / IQ sample
@@ -365,6 +450,8 @@ def main():
                              if args.workload == "wbfm" else
                              f"mixed-mode bank {C // 4} AM + {C // 4} FM + {C // 4} WBFM + {C // 4} SSB per GPU "
                              f"(BASELINE config 3), ") +
+                            (f"= {world * C} channels over {world} GPUs (BASELINE config 4 asks for 4096 over 8), "
+                             if world > 1 and args.workload == "wbfm" else "") +
                             f"{B} blocks of 262144 B per channel per step, input resident in HBM"
                             + (", IQ scattered from rank 0 over RCCL each step" if args.scatter and world > 1 else ""),
                 "channels_per_gpu": C, "blocks_per_step": B, "signal": args.signal,
@@ -378,9 +465,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic_bytes(args, C, B),
-                "kernel": ("hrfd::k_rx_wbfm_stream<true> (one workgroup per CU, arithmetic atan2)" if args.workload == "wbfm"
-                           else "all demodulator kernels of a step"),
+                "traffic": traffic,
+                "traffic_source": (f"profiles/latest_pmc_traffic_wbfm256x16.json, kernel sources {ptag}" if traffic is not None else
+                                   ("no PMC summary for this workload" if ptag is None else
+                                    f"PMC summary is of kernel sources {ptag}, this run is {kernel_source_tag()}: not reported")),
+                "measured_stream_copy_GBps": round(copy_gbs, 1),
+                "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+                "kernel": ("hrfd::k_rx_wbfm_flow<4> (one persistent workgroup per CU, LDS ring, first-octant-table atan2)"
+                           if args.workload == "wbfm" else "all demodulator kernels of a step"),
                 "kernel_ms_mean": round(mean_ms, 4),
                 "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "kernel_ms_median": round(float(np.median(kernel_ms)), 4),
@@ -389,6 +481,13 @@ def main():
             "verification": {"uncommitted_launches": counters[5], "tiles_repaired_in_place": counters[4],
                              "launches": counters[6]},
         }
+        if counters[5] != 0:
+            # a launch that did not commit means later launches started from a stale state and the batch path was
+            # not what ran: the number is not a measurement of it
+            line["invalid"] = f"{counters[5]} launch(es) were not committed"
+        if world == 1 and args.workload == "wbfm":
+            line["end_to_end"] = end_to_end(api, device, C)
+            line["single_block_latency_ms"] = single_block_latency_ms(api, device)
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, os.cpu_count() or 1)
             # also the reference on ONE host thread (config 1's shape), a short sample

@@ -1,0 +1,119 @@
+"""The configurations of BASELINE.json at their full sizes, through the C ABI on the GPU:
+
+  config 2 / 4 / north star   256, 512 (config 4's per-GPU shard) and 1024 (>= 1000, the stated target)
+                              concurrent WBFM channels x 16 blocks in ONE launch
+  config 3                    64 AM + 64 FM + 64 WBFM + 64 SSB x 16 blocks, per-mode dispatch
+  config 5                    1024 SSB modulators
+
+Each against the sequential CPU oracle on a spread of channels, plus size-independent properties over
+ALL channels: channels fed identical input give identical output, every launch committed (nothing was
+replayed), and the two batch kernels (k_rx_wbfm_flow, k_rx_wbfm_stream) agree."""
+import zlib
+
+import numpy as np
+import pytest
+
+from hackrfdiags_amd import api, synth
+from tests.reflib import AM, FM, LSB, WBFM
+
+pytestmark = pytest.mark.gpu
+BLK = synth.BLOCK_BYTES
+NBASE = 8
+
+
+def _oracle_pcm(oracle, mode, x):
+    o = oracle.rx()
+    o.set_mode(mode)
+    outs = [o.process(x[b]) for b in range(x.shape[0])]
+    return np.stack([w[0] for w in outs]), [w[1] for w in outs]
+
+
+@pytest.mark.parametrize("C", [512, 1024])
+def test_wbfm_512_and_1024_channels(oracle, C):
+    """C x 16 blocks of 262144 B per launch (2 and 4 GiB of IQ): the persistent grid is 2 and 4 workgroups
+    per CU deep here.  Two launches (the second continues every stream)."""
+    import torch
+    B = 16
+    dev = torch.device("cuda:0")
+    base = [synth.make_input("fmtone" if k % 2 else "lcg", 500 + k, 2 * B).reshape(2 * B, BLK) for k in range(NBASE)]
+    x = torch.empty((C, B, BLK), dtype=torch.int8, device=dev)
+    want = [_oracle_pcm(oracle, WBFM, base[k]) for k in range(NBASE)]
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    ref_other = api.Rx(C)
+    ref_other.set_mode(api.WBFM)
+    ref_other.debug_set_stream(1)                        # k_rx_wbfm_stream
+    for half in range(2):
+        for c in range(C):
+            x[c] = torch.from_numpy(base[c % NBASE][half * B:(half + 1) * B]).to(dev)
+        out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+        mag = torch.zeros((C, B), dtype=torch.int32, device=dev)
+        npcm = torch.zeros((C, B), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        rx.process_device(x.data_ptr(), B * BLK, BLK, B, out.data_ptr(), d_n_pcm=npcm.data_ptr(), d_magnitude=mag.data_ptr())
+        assert rx.sync() == 0
+        got, gmag = out.cpu().numpy(), mag.cpu().numpy()
+        assert int(npcm.sum().item()) == C * B * 512
+        for k in range(NBASE):
+            assert (got[k] == want[k][0][half * B:(half + 1) * B]).all(), (half, k)
+            assert gmag[k].tolist() == want[k][1][half * B:(half + 1) * B], (half, k)
+            for c in range(k, C, NBASE):                  # every channel with this input
+                assert (got[c] == got[k]).all() and (gmag[c] == gmag[k]).all(), (half, c, k)
+        out2 = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        ref_other.process_device(x.data_ptr(), B * BLK, BLK, B, out2.data_ptr())
+        assert ref_other.sync() == 0
+        assert zlib.crc32(out2.cpu().numpy().tobytes()) == zlib.crc32(got.tobytes())
+    assert rx.debug_counters()[5] == 0 and ref_other.debug_counters()[5] == 0, "a launch was replayed"
+
+
+def test_mixed_bank_full_size(oracle):
+    """config 3: 64 AM + 64 FM + 64 WBFM + 64 SSB channels x 16 blocks, two launches"""
+    import torch
+    C, B = 256, 16
+    modes = [AM, FM, WBFM, LSB]
+    amodes = [api.AM, api.FM, api.WBFM, api.LSB]
+    dev = torch.device("cuda:0")
+    base = [synth.make_input(("fmtone", "lcg")[k], 600 + k, 2 * B).reshape(2 * B, BLK) for k in range(2)]
+    rx = api.Rx(C)
+    for c in range(C):
+        rx.set_mode(amodes[(4 * c) // C], channel=c)
+    want = {(q, k): _oracle_pcm(oracle, modes[q], base[k]) for q in range(4) for k in range(2)}
+    x = torch.empty((C, B, BLK), dtype=torch.int8, device=dev)
+    for half in range(2):
+        for c in range(C):
+            x[c] = torch.from_numpy(base[c % 2][half * B:(half + 1) * B]).to(dev)
+        out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        rx.process_device(x.data_ptr(), B * BLK, BLK, B, out.data_ptr())
+        assert rx.sync() == 0
+        got = out.cpu().numpy()
+        for q in range(4):
+            c0 = q * (C // 4)
+            for k in range(2):
+                assert (got[c0 + k] == want[(q, k)][0][half * B:(half + 1) * B]).all(), (half, q, k)
+                for c in range(c0 + k, c0 + C // 4, 2):
+                    assert (got[c] == got[c0 + k]).all(), (half, q, c)
+    assert rx.debug_counters()[5] == 0
+
+
+def test_ssb_modulator_1024_channels(oracle):
+    """config 5: 1024 SSB modulators, 16 blocks of 512 PCM samples each, two calls"""
+    C, B = 1024, 16
+    base = [synth.lcg_pcm(7 + k, 2 * B * 512) for k in range(NBASE)]
+    pcm = np.stack([base[c % NBASE] for c in range(C)])
+    m = api.Mod(api.MOD_SSB, C)
+    for c in range(C):
+        m.set_sideband(c % 16 < 8, channel=c)            # channels k and k + 8 differ in sideband only
+    os_ = {}
+    for k in range(2 * NBASE):
+        o = oracle.ssbmod(k < NBASE)
+        os_[k] = o
+    for half in range(2):
+        seg = pcm[:, half * B * 512:(half + 1) * B * 512]
+        got = m.process(seg)
+        for k in range(2 * NBASE):
+            want = np.concatenate([os_[k].process(base[k % NBASE][half * B * 512 + s:half * B * 512 + s + 512]) for s in range(0, B * 512, 512)])
+            assert (got[k] == want).all(), (half, k)
+            for c in range(k, C, 16):
+                assert (got[c] == got[k]).all(), (half, c, k)
