@@ -78,9 +78,16 @@ class Rx:
               "hrfd_rx_process_device")
 
     def sync(self) -> int:
+        """waits for the last process_device; returns the number of channels that did not commit"""
         v = C.c_uint32(0)
         check(self.L.hrfd_rx_sync(self.h, C.byref(v)), "hrfd_rx_sync")
         return int(v.value)
+
+    def failed_channels(self) -> np.ndarray:
+        """uint8 [n_channels]: != 0 where the channel did not commit in the launch sync() last waited for"""
+        out = np.zeros(self.n, dtype=np.uint8)
+        check(self.L.hrfd_rx_failed_channels(self.h, out.ctypes.data, self.n), "hrfd_rx_failed_channels")
+        return out
 
     # test hooks
     def debug_set_atan(self, mode: int):

@@ -23,8 +23,7 @@ __global__ void k_build_atan_corr(const float *, const float *, uint8_t *, uint3
 template <bool TAB> __global__ void k_atan_eval(const uint8_t *, const float *, float *);
 template <int MODE, bool S256, bool ARITH> __global__ void k_rx_fir(const RxParams);
 template <int MODE> __global__ void k_rx_post(const RxParams);
-__global__ void k_rx_epilogue(const EpilogueParams);
-__global__ void k_rx_commit(const EpilogueParams);
+__global__ void k_rx_finish(const EpilogueParams);
 } // namespace hrfd
 
 using namespace hrfd;
@@ -162,8 +161,12 @@ struct hrfd_rx
   uint32_t *d_counters = nullptr;       // [kNumDevCounters] + a second set of the per-launch counters [kCntSticky]
   uint32_t *d_local = nullptr;          // the per-launch counters of the latest launch (set 0 = d_counters, set 1 behind it)
   int parity = 0;
-  uint32_t *d_lists = nullptr;         // [6][n_channels] channel ids grouped by mode
-  uint32_t list_count[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t *d_lists = nullptr;         // [7][n_channels] channel ids grouped by mode; list 6: every channel that is not WBFM
+  uint32_t list_count[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t *d_sub_lists = nullptr;     // the same for a launch over a subset of the channels (replay of failed channels);
+                                       // list 6 there: the subset itself
+  uint32_t *d_chan = nullptr;          // [4][n_channels]: chan_fail, chan_poison, chan_expired, chan_arrived (EpilogueParams)
+  std::vector<uint32_t> h_fail;        // chan_fail of the latest synchronised launch
 
   // per-call scratch, grown on demand (units = channels * blocks)
   size_t cap_units = 0;
@@ -212,7 +215,7 @@ static int rx_free(hrfd_rx *h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->side) (void)hipStreamSynchronize(h->side);
   void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_atcorr2, h->d_att0, h->d_dbfs, h->d_counters,
-                  h->d_lists, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
+                  h->d_lists, h->d_sub_lists, h->d_chan, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
                   h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq};
   for (void *p : ptrs)
   {
@@ -294,7 +297,9 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && alloc((void **)&h->d_att0, sizeof(float) * kCorrBytes);
   ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
   ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * (kNumDevCounters + kCntSticky));
-  ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 6 * n_channels);
+  ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 7 * n_channels);
+  ok = ok && alloc((void **)&h->d_sub_lists, sizeof(uint32_t) * 7 * n_channels);
+  ok = ok && alloc((void **)&h->d_chan, sizeof(uint32_t) * 4 * n_channels);
   if (!ok)
   {
     if (rc == HRFD_OK) rc = fail(HRFD_ENODEV, "hrfd_rx_create: stream creation failed");
@@ -322,6 +327,8 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   if (e == hipSuccess) e = hipMemcpy(h->d_lut, lut.data(), sizeof(float) * 65536, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_dbfs, dbfs, sizeof(dbfs), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemset(h->d_counters, 0, sizeof(uint32_t) * (kNumDevCounters + kCntSticky));
+  if (e == hipSuccess) e = hipMemset(h->d_chan, 0, sizeof(uint32_t) * 4 * n_channels);
+  h->h_fail.assign(n_channels, 0u);
   h->d_local = h->d_counters;
   // arithmetic atan2: reciprocals from the host (correctly rounded), correction bytes derived on
   // the device from the table just uploaded, with the kernel's own arithmetic (k_build_atan_corr)
@@ -694,6 +701,7 @@ struct LaunchOpts
   uint32_t out_b0;         // first block of that layout this launch fills
   int serial;              // exact one-lane de-emphasis (replay path)
   int src256;              // input is the 256 kS/s mixed stream (hrfd_demod_*)
+  const std::vector<uint32_t> *subset = nullptr;   // launch for these channels only (ascending ids), nullptr = all
 };
 
 static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, uint32_t block_bytes,
@@ -759,18 +767,23 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   }
 
   // configuration snapshot
+  uint32_t sub_count[7] = {0, 0, 0, 0, 0, 0, 0};
   std::vector<std::pair<uint32_t, int>> resets;
   {
     std::lock_guard<std::mutex> g(h->mu);
     resets.swap(h->pending_resets);
     if (h->cfg_dirty)
     {
-      std::vector<uint32_t> lists((size_t)6 * h->n_channels);
-      uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
+      std::vector<uint32_t> lists((size_t)7 * h->n_channels);
+      uint32_t cnt[7] = {0, 0, 0, 0, 0, 0, 0};
       for (uint32_t c = 0; c < h->n_channels; c++)
       {
         const int m = h->h_cfg[c].mode;
         lists[(size_t)m * h->n_channels + cnt[m]++] = c;
+        if (m != HRFD_MODE_WBFM)
+        {
+          lists[(size_t)6 * h->n_channels + cnt[6]++] = c;
+        }
       }
       memcpy(h->list_count, cnt, sizeof(cnt));
       // synchronous uploads: the host vectors are only valid under the lock
@@ -779,6 +792,25 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       HIP_TRY(hipMemcpy(h->d_lists, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice));
       h->cfg_dirty = false;
     }
+    if (opt.subset != nullptr)
+    {
+      // per-mode lists of the subset (list 6: the subset itself)
+      std::vector<uint32_t> lists((size_t)7 * h->n_channels);
+      for (uint32_t c : *opt.subset)
+      {
+        const int m = h->h_cfg[c].mode;
+        lists[(size_t)m * h->n_channels + sub_count[m]++] = c;
+        lists[(size_t)6 * h->n_channels + sub_count[6]++] = c;
+      }
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipMemcpy(h->d_sub_lists, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice));
+    }
+  }
+  const uint32_t *const list_count = (opt.subset != nullptr) ? sub_count : h->list_count;
+  const uint32_t *const d_lists = (opt.subset != nullptr) ? h->d_sub_lists : h->d_lists;
+  if (opt.subset != nullptr && opt.subset->empty())
+  {
+    return HRFD_OK;
   }
   int rc = apply_resets(h, s, resets);
   if (rc != HRFD_OK)
@@ -803,7 +835,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     h->cap_units = need;
   }
 
-  if (h->list_count[HRFD_MODE_LSB] + h->list_count[HRFD_MODE_USB] != 0)
+  if (list_count[HRFD_MODE_LSB] + list_count[HRFD_MODE_USB] != 0)
   {
     const size_t need = units * (size_t)(n256 / 32) * 2 * sizeof(int16_t);
     if (need > h->cap_ssb)
@@ -861,6 +893,35 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.flow_seed_ct = (float)pow(-(double)DEEMPH_A1, 64.0);
   P.dbg = nullptr;
 
+  EpilogueParams E;
+  memset(&E, 0, sizeof(E));
+  E.n_channels = h->n_channels;
+  E.n_blocks = n_blocks;
+  E.n_pcm_per_block = n256 / 32;
+  E.out_blocks = opt.out_blocks;
+  E.out_b0 = opt.out_b0;
+  E.cfg = h->d_cfg;
+  E.state = h->d_state;
+  E.state_out = h->d_state_out;
+  E.present = h->d_present;
+  E.allowed = d_allowed;
+  E.n_pcm = d_n_pcm;
+  E.chk_pub = h->d_chk_pub;
+  E.chk_spec = h->d_chk_spec;
+  E.counters = local;
+  E.sticky = h->d_counters;
+  E.next_local = other;
+  E.chan_list = nullptr;
+  E.first_channel = (opt.subset != nullptr) ? opt.subset->front() : 0u;
+  E.chan_fail = h->d_chan;
+  E.chan_poison = h->d_chan + h->n_channels;
+  E.chan_expired = h->d_chan + 2 * (size_t)h->n_channels;
+  E.chan_arrived = h->d_chan + 3 * (size_t)h->n_channels;
+  P.fin = E;
+  P.self_finish = 0;
+  P.sticky = h->d_counters;
+  bool flow_ran = false;
+
   const size_t ev_slots = h->ev.size() / 2;
   const size_t ev_slot = ev_slots ? (h->ev_launches % ev_slots) : 0;
   if (ev_slots)
@@ -875,12 +936,12 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   int n_side = 0;
   for (int m : {HRFD_MODE_AM, HRFD_MODE_LSB, HRFD_MODE_USB, HRFD_MODE_FM})
   {
-    const uint32_t n = h->list_count[m];
+    const uint32_t n = list_count[m];
     if (n == 0)
     {
       continue;
     }
-    P.chan_list = h->d_lists + (size_t)m * h->n_channels;
+    P.chan_list = d_lists + (size_t)m * h->n_channels;
     P.n_list = n;
     const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
     if (m == HRFD_MODE_FM)
@@ -936,12 +997,12 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
 
   for (int m : {HRFD_MODE_NONE, HRFD_MODE_WBFM})
   {
-    const uint32_t n = h->list_count[m];
+    const uint32_t n = list_count[m];
     if (n == 0)
     {
       continue;
     }
-    P.chan_list = h->d_lists + (size_t)m * h->n_channels;
+    P.chan_list = d_lists + (size_t)m * h->n_channels;
     P.n_list = n;
     // runs of consecutive blocks per workgroup (only a run's first block re-produces the history
     // in front of it): as long as possible while the launch still fills the chip --
@@ -979,7 +1040,10 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       else if (flow)
       {
         P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here
+        P.self_finish = 1;                                 // the last workgroup of a channel finishes it (finish_channel)
+        flow_ran = true;
         hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC>), dim3(grid), dim3(kThreads), 0, s, P);
+        P.self_finish = 0;
       }
       else if (streaming)
       {
@@ -1016,28 +1080,41 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     h->ev_launches++;
   }
 
-  EpilogueParams E;
-  memset(&E, 0, sizeof(E));
-  E.n_channels = h->n_channels;
-  E.n_blocks = n_blocks;
-  E.n_pcm_per_block = n256 / 32;
-  E.out_blocks = opt.out_blocks;
-  E.out_b0 = opt.out_b0;
-  E.cfg = h->d_cfg;
-  E.state = h->d_state;
-  E.state_out = h->d_state_out;
-  E.present = h->d_present;
-  E.allowed = d_allowed;
-  E.n_pcm = d_n_pcm;
-  E.chk_pub = h->d_chk_pub;
-  E.chk_spec = h->d_chk_spec;
-  E.counters = local;
-  E.sticky = h->d_counters;
-  E.next_local = other;
-  hipLaunchKernelGGL(k_rx_epilogue, dim3(h->n_channels), dim3(64), 0, s, E);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_rx_commit, dim3(h->n_channels), dim3(64), 0, s, E);
-  HIP_TRY(hipGetLastError());
+  // the channels that no kernel finished by itself (finish_channel): everything but the WBFM channels when
+  // k_rx_wbfm_flow ran, else all of them
+  {
+    EpilogueParams F = E;
+    if (flow_ran)
+    {
+      F.chan_list = d_lists + (size_t)6 * h->n_channels;
+      F.n_channels = (opt.subset != nullptr) ? 0u : list_count[6];
+      if (opt.subset != nullptr)
+      {
+        // the subset's list 6 holds all its channels: finish those that are not WBFM through their mode lists
+        for (int m : {HRFD_MODE_NONE, HRFD_MODE_AM, HRFD_MODE_FM, HRFD_MODE_LSB, HRFD_MODE_USB})
+        {
+          if (list_count[m] != 0)
+          {
+            EpilogueParams G = E;
+            G.chan_list = d_lists + (size_t)m * h->n_channels;
+            G.n_channels = list_count[m];
+            hipLaunchKernelGGL(k_rx_finish, dim3(G.n_channels), dim3(64), 0, s, G);
+            HIP_TRY(hipGetLastError());
+          }
+        }
+      }
+    }
+    else if (opt.subset != nullptr)
+    {
+      F.chan_list = d_lists + (size_t)6 * h->n_channels;
+      F.n_channels = list_count[6];
+    }
+    if (F.n_channels != 0)
+    {
+      hipLaunchKernelGGL(k_rx_finish, dim3(F.n_channels), dim3(64), 0, s, F);
+      HIP_TRY(hipGetLastError());
+    }
+  }
   h->last_stream = s;
   return HRFD_OK;
 }
@@ -1069,19 +1146,95 @@ extern "C" int hrfd_rx_sync(hrfd_rx *h, uint32_t *n_violations)
   HIP_TRY(hipMemcpy(h->last_counters, h->d_counters, sizeof(h->last_counters), hipMemcpyDeviceToHost));   // the totals
   HIP_TRY(hipMemcpy(h->last_counters, h->d_local, sizeof(uint32_t) * kCntSticky, hipMemcpyDeviceToHost)); // the latest launch
   h->total_repairs = h->last_counters[kCntTotRepair];
-  uint32_t viol = h->last_counters[kCntGate] + h->last_counters[kCntSpec];
-  if (viol == 0 && h->last_counters[kCntTotLaunch] != 0 && h->last_counters[kCntCommit] == 0)
-  {
-    viol = 1;                                            // clean by itself, but behind an unrepaired failed launch
-  }
+  // channels of the latest launch that did not commit (their own checks failed, or they ran behind an unrepaired failure)
+  const uint32_t viol = (h->last_counters[kCntTotLaunch] != 0) ? h->last_counters[kCntFail] : 0u;
+  h->last_counters[kCntCommit] = (viol == 0) ? 1u : 0u;  // shown as "all committed" by hrfd_rx_debug_counters
   if (viol != 0)
   {
-    // the caller repairs from here (resubmits block by block): later launches may commit again
-    HIP_TRY(hipMemset(h->d_counters + kCntPoison, 0, sizeof(uint32_t)));
+    // the caller repairs those channels from here (resubmits them block by block, hrfd_rx_failed_channels says
+    // which): they may commit again
+    HIP_TRY(hipMemcpy(h->h_fail.data(), h->d_chan, sizeof(uint32_t) * h->n_channels, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(h->d_chan + h->n_channels, 0, sizeof(uint32_t) * h->n_channels));
+  }
+  else
+  {
+    std::fill(h->h_fail.begin(), h->h_fail.end(), 0u);
   }
   if (n_violations != nullptr)
   {
     *n_violations = viol;
+  }
+  return HRFD_OK;
+}
+
+// Which channels of the launch that hrfd_rx_sync last waited for did not commit: out[c] != 0 (kFail* bits:
+// 1 closed gate in a batch, 2 failed time-parallel speculation, 4 behind an unrepaired failure, 8 internal wait expired).
+extern "C" int hrfd_rx_failed_channels(hrfd_rx *h, uint8_t *out, uint32_t n)
+{
+  if (h == nullptr || out == nullptr || n != h->n_channels)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_failed_channels: need a handle and room for n_channels flags");
+  }
+  for (uint32_t c = 0; c < n; c++)
+  {
+    out[c] = (uint8_t)h->h_fail[c];
+  }
+  return HRFD_OK;
+}
+
+// Replays `subset` (ascending channel ids) through the exact path: one block per launch (state advances in
+// order); a channel whose de-emphasis tiles did not re-synchronise is redone on the one-lane path.  Inputs and
+// outputs are the full [n_channels][n_blocks][...] device buffers of the call being repaired.
+static int rx_replay(hrfd_rx *h, const std::vector<uint32_t> &subset, const int8_t *d_iq, uint64_t stride,
+                     uint32_t block_bytes, uint32_t n_blocks, uint32_t gain_db, int16_t *d_pcm, uint32_t *d_npcm,
+                     uint32_t *d_mag, uint8_t *d_allowed, int8_t *d_iq256, hipStream_t s)
+{
+  if (subset.empty())
+  {
+    return HRFD_OK;
+  }
+  // squelched units write no PCM: they must read as zeros, not as what a failed batch left there
+  const size_t row = (size_t)n_blocks * (block_bytes / 512) * sizeof(int16_t);
+  if (subset.size() == h->n_channels)
+  {
+    HIP_TRY(hipMemsetAsync(d_pcm, 0, row * h->n_channels, s));
+  }
+  else
+  {
+    for (uint32_t c : subset)
+    {
+      HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(d_pcm) + row * c, 0, row, s));
+    }
+  }
+  for (uint32_t b = 0; b < n_blocks; b++)
+  {
+    std::vector<uint32_t> todo = subset;
+    for (int attempt = 0; attempt < 2 && !todo.empty(); attempt++)
+    {
+      LaunchOpts opt = {n_blocks, b, attempt, 0};
+      opt.subset = &todo;
+      int rc = rx_launch(h, d_iq + (size_t)b * block_bytes, stride, block_bytes, 1, gain_db, d_pcm, d_npcm, d_mag,
+                         d_allowed, d_iq256, s, opt);
+      if (rc != HRFD_OK) return rc;
+      uint32_t viol = 0;
+      if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
+      if (viol == 0)
+      {
+        todo.clear();
+        break;
+      }
+      h->replays++;
+      std::vector<uint32_t> again;
+      for (uint32_t c : todo)
+      {
+        if (h->h_fail[c] != 0) again.push_back(c);
+      }
+      todo.swap(again);
+    }
+    if (!todo.empty())
+    {
+      return fail(HRFD_ESTATE, "internal: exact replay still reports %zu failed channel(s)", todo.size());
+    }
   }
   return HRFD_OK;
 }
@@ -1125,7 +1278,7 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
   const uint64_t stride = (uint64_t)block_bytes * n_blocks;
   int8_t *d_iq256 = iq256k_opt ? h->d_iq256 : nullptr;
   uint32_t viol = 0;
-  bool done = false;
+  std::vector<uint32_t> redo;                              // channels to run on the exact per-block path
   if (n_blocks > 1 && (uint32_t)(kMaxHal + 64) * 16u <= block_bytes)
   {
     // whole batch in one launch, blocks of a channel in parallel (speculative)
@@ -1134,29 +1287,19 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
                    h->d_mag_out, h->d_allowed, d_iq256, s, opt);
     if (rc != HRFD_OK) return rc;
     if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
-    done = (viol == 0);
-  }
-  if (!done)
-  {
-    // exact path: one block per launch (state advances in order); a launch whose
-    // de-emphasis tiles did not re-synchronise is redone on the one-lane path.
-    for (uint32_t b = 0; b < n_blocks; b++)
+    for (uint32_t c = 0; c < C && viol != 0; c++)
     {
-      for (int attempt = 0; attempt < 2; attempt++)
-      {
-        const LaunchOpts opt = {n_blocks, b, attempt, 0};
-        rc = rx_launch(h, h->d_iq + (size_t)b * block_bytes, stride, block_bytes, 1, gain_db,
-                       h->d_pcm, h->d_npcm, h->d_mag_out, h->d_allowed, d_iq256, s, opt);
-        if (rc != HRFD_OK) return rc;
-        if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
-        if (viol == 0) break;
-        h->replays++;
-      }
-      if (viol != 0)
-      {
-        return fail(HRFD_ESTATE, "internal: exact replay still reports %u violations", viol);
-      }
+      if (h->h_fail[c] != 0) redo.push_back(c);
     }
+  }
+  else
+  {
+    for (uint32_t c = 0; c < C; c++) redo.push_back(c);
+  }
+  if ((rc = rx_replay(h, redo, h->d_iq, stride, block_bytes, n_blocks, gain_db, h->d_pcm, h->d_npcm, h->d_mag_out,
+                      h->d_allowed, d_iq256, s)) != HRFD_OK)
+  {
+    return rc;
   }
   HIP_TRY(hipMemcpyAsync(pcm, h->d_pcm, pcm_bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(n_pcm, h->d_npcm, units * 4, hipMemcpyDeviceToHost, s));

@@ -98,6 +98,33 @@ struct alignas(16) ChanCfg
 };
 
 // ---- launch parameters -------------------------------------------------------
+struct EpilogueParams
+{
+  uint32_t n_channels;         // channels this launch finishes: all of them, or chan_list[0 .. n_channels)
+  uint32_t n_blocks;
+  uint32_t n_pcm_per_block;
+  uint32_t out_blocks, out_b0; // layout of allowed / n_pcm (see RxParams)
+  const ChanCfg *cfg;
+  ChanState *state;
+  const ChanState *state_out;
+  const uint8_t *present;
+  uint8_t *allowed;            // optional out
+  uint32_t *n_pcm;             // optional out
+  const float *chk_pub;
+  const float *chk_spec;
+  uint32_t *counters;          // kCnt* of THIS launch (kCntRepair .. kCntFail): one of two sets, used alternately
+  uint32_t *sticky;            // the handle's counter block: kCntSticky.. (totals) live here
+  uint32_t *next_local;        // the other set: the launch's first channel clears it for the next launch (no memset between launches)
+  const uint32_t *chan_list;   // nullptr: channels 0 .. n_channels - 1
+  uint32_t first_channel;      // the channel whose finisher does the launch's bookkeeping
+  uint32_t *chan_fail;         // [channels] verdict of the latest launch per channel: 0 = committed, else kFail* bits
+  uint32_t *chan_poison;       // [channels] sticky: the channel failed and the host has not repaired it yet -- it must not
+                               //   commit in launches submitted behind the failed one either (pipelined submission)
+  uint32_t *chan_expired;      // [channels] set by a kernel whose wait expired (k_rx_wbfm_flow), cleared by the finisher
+  uint32_t *chan_arrived;      // [channels] workgroups of the channel that are through (k_rx_wbfm_flow finishes its own
+                               //   channels: the last workgroup of a channel does); zero between launches
+};
+
 struct RxParams
 {
   const int8_t *iq;            // [C][n_blocks][block_bytes]
@@ -138,43 +165,28 @@ struct RxParams
   const int32_t *dbfs;         // [257]
   float *chk_pub;              // [C][n_blocks] y at (n256 - kHist + 59) of this block
   float *chk_spec;             // [C][n_blocks] y at (-kHist + 59) as speculated by this block
-  uint32_t *counters;          // kCnt*
+  uint32_t *counters;          // kCnt* of this launch
+  uint32_t *sticky;            // the handle's totals (kCntTotRepair ...)
+  EpilogueParams fin;          // k_rx_wbfm_flow finishes its own channels (the launch's finish parameters) ...
+  int32_t self_finish;         // ... when this is set
   int32_t flow_hal;            // k_rx_wbfm_flow: history samples in front of a run that does not start the call (multiple of 512)
   float flow_seed_ct;          // k_rx_wbfm_flow: (-a1)^64
   unsigned long long *dbg;     // optional [grid][kDbgSlots] s_memtime stamps at phase boundaries (diagnostic builds of bench only)
 };
 
-struct EpilogueParams
-{
-  uint32_t n_channels;
-  uint32_t n_blocks;
-  uint32_t n_pcm_per_block;
-  uint32_t out_blocks, out_b0; // layout of allowed / n_pcm (see RxParams)
-  const ChanCfg *cfg;
-  ChanState *state;
-  const ChanState *state_out;
-  const uint8_t *present;
-  uint8_t *allowed;            // optional out
-  uint32_t *n_pcm;             // optional out
-  const float *chk_pub;
-  const float *chk_spec;
-  uint32_t *counters;          // kCnt* of THIS launch (kCntRepair .. kCntCommit): one of two sets, used alternately
-  uint32_t *sticky;            // the handle's counter block: kCntSticky.. (totals, kCntPoison) live here
-  uint32_t *next_local;        // the other set: k_rx_commit clears it for the next launch (no memset between launches)
-};
+constexpr uint32_t kFailGate = 1u, kFailSpec = 2u, kFailPoison = 4u, kFailExpired = 8u;
 
 constexpr int kCntRepair = 0;  // de-emphasis tiles re-run in place because their warm-up had not re-synchronised
 constexpr int kCntGate = 1;    // blocks b > 0 whose squelch gate turned out closed
 constexpr int kCntSpec = 2;    // blocks b > 0 whose first tile disagrees with the predecessor
-constexpr int kCntCommit = 3;  // 1 when the epilogue committed the pending state
+constexpr int kCntFail = 3;    // channels of this launch whose state was NOT committed (hrfd_rx_debug_counters shows 1 = all committed here)
+constexpr int kCntCommit = 3;
 constexpr int kCntSticky = 4;  // counters from here on are never reset (totals since creation):
 constexpr int kCntTotRepair = 4;
-constexpr int kCntTotViol = 5; // launches whose state was NOT committed
+constexpr int kCntTotViol = 5; // channel-launches whose state was NOT committed
 constexpr int kCntTotLaunch = 6;
 constexpr int kCntScratch = 7;  // k_build_atan_corr's violation count (hrfd_rx_create only)
 constexpr int kNumCounters = 8;   // counters visible through hrfd_rx_debug_counters
-constexpr int kCntPoison = 8;     // sticky: a launch was not committed and the host has not repaired it yet --
-                                  // later launches must not commit either (pipelined submission, hrfd_ingest_*)
 constexpr int kNumDevCounters = 10;
 constexpr int kDbgSlots = 48;      // RxParams::dbg: per workgroup 0..5 phase stamps of thread 0, 6 placement, 8..23 per wave, 24..31 recurrence / stream-loop probes, 32..47 service-loop probes (k_rx_wbfm_flow)
 

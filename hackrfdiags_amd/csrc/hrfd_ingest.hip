@@ -13,11 +13,11 @@
 //   producer:  hrfd_ingest_acquire -> fill the slot -> hrfd_ingest_submit
 //   consumer:  hrfd_ingest_collect  (oldest submitted batch, blocks until it is there)
 //
-// A multi-block batch is speculative (hrfd.h: hrfd_rx_process_device).  When one fails its
-// checks it does not commit its state, and neither does any batch launched behind it (the
-// device keeps a sticky flag, kCntPoison); collect() then replays that batch and the ones
-// already in flight behind it through the exact blocking path, in order, from the pinned
-// inputs.  Results are always the sequential ones.
+// A multi-block batch is speculative (hrfd.h: hrfd_rx_process_device), per channel.  A channel that
+// fails its checks does not commit its state, and neither does it in any batch launched behind that
+// one (the device keeps a sticky flag per channel, chan_poison); collect() then replays THOSE
+// CHANNELS of that batch and of the ones already in flight behind it through the exact path, in
+// order, from the batches' device-resident inputs.  Results are always the sequential ones.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -36,7 +36,8 @@ struct hrfd_ingest
     int16_t *h_pcm = nullptr, *d_pcm = nullptr;
     uint32_t *h_npcm = nullptr, *d_npcm = nullptr, *h_mag = nullptr, *d_mag = nullptr;
     uint8_t *h_allowed = nullptr, *d_allowed = nullptr;
-    uint32_t *h_counters = nullptr;                  // the launch's counters (commit flag)
+    uint32_t *h_counters = nullptr;                  // the launch's counters (kCntFail: channels that did not commit)
+    uint32_t *h_fail = nullptr;                      // ... and which (chan_fail)
     hipEvent_t e_in = nullptr, e_comp = nullptr, e_out = nullptr;
     uint32_t gain_db = 0;
     int state = 0;                                   // 0 free, 1 acquired, 2 submitted, 3 collected (results in use)
@@ -60,7 +61,7 @@ int ingest_free(hrfd_ingest *g)
   (void)hipDeviceSynchronize();
   for (auto &sl : g->slots)
   {
-    void *hostp[] = {sl.h_iq, sl.h_pcm, sl.h_npcm, sl.h_mag, sl.h_allowed, sl.h_counters};
+    void *hostp[] = {sl.h_iq, sl.h_pcm, sl.h_npcm, sl.h_mag, sl.h_allowed, sl.h_counters, sl.h_fail};
     for (void *p : hostp)
     {
       if (p) (void)hipHostFree(p);
@@ -115,6 +116,7 @@ extern "C" int hrfd_ingest_create(hrfd_rx *rx, uint32_t block_bytes, uint32_t n_
     if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_mag, g->units * 4, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_allowed, g->units, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_counters, sizeof(uint32_t) * kNumCounters, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&sl.h_fail, sizeof(uint32_t) * g->C, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&sl.d_iq, g->iq_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&sl.d_pcm, g->pcm_elems * 2);
     if (e == hipSuccess) e = hipMalloc((void **)&sl.d_npcm, g->units * 4);
@@ -186,6 +188,7 @@ extern "C" int hrfd_ingest_submit(hrfd_ingest *g, uint32_t gain_db)
     return rc;
   }
   HIP_TRY(hipMemcpyAsync(sl.h_counters, rx->d_local, sizeof(uint32_t) * kCntSticky, hipMemcpyDeviceToHost, cs));   // this launch's set
+  HIP_TRY(hipMemcpyAsync(sl.h_fail, rx->d_chan, sizeof(uint32_t) * g->C, hipMemcpyDeviceToHost, cs));
   HIP_TRY(hipEventRecord(sl.e_comp, cs));
   HIP_TRY(hipStreamWaitEvent(g->s_out, sl.e_comp, 0));
   HIP_TRY(hipMemcpyAsync(sl.h_pcm, sl.d_pcm, g->pcm_elems * 2, hipMemcpyDeviceToHost, g->s_out));
@@ -216,25 +219,41 @@ extern "C" int hrfd_ingest_collect(hrfd_ingest *g, const int16_t **pcm, const ui
   HIP_TRY(hipSetDevice(rx->device));
   hrfd_ingest::Slot &sl = g->slots[g->tail];
   HIP_TRY(hipEventSynchronize(sl.e_out));
-  if (sl.h_counters[kCntCommit] == 0)
+  if (sl.h_counters[kCntFail] != 0)
   {
-    // This batch did not commit (its own checks failed, or it ran behind one that did): nothing
-    // launched since has committed either.  Drain, then replay it and everything behind it, in
-    // order, through the exact blocking path.
+    // Some channels of this batch did not commit (their own checks failed, or they ran behind a failure of
+    // theirs): they have not committed in anything launched since either.  Drain, then replay those channels of
+    // this batch and of everything behind it, in order, through the exact path.
     HIP_TRY(hipStreamSynchronize(rx->stream));
     HIP_TRY(hipStreamSynchronize(g->s_out));
-    HIP_TRY(hipMemset(rx->d_counters + kCntPoison, 0, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(rx->d_chan + rx->n_channels, 0, sizeof(uint32_t) * rx->n_channels));   // chan_poison
     uint32_t k = g->tail;
     for (uint32_t i = 0; i < g->in_flight; i++, k = (k + 1) % g->n_slots)
     {
       hrfd_ingest::Slot &r = g->slots[k];
-      const int rc = hrfd_rx_process_block(rx, r.h_iq, g->block_bytes, g->n_blocks, r.gain_db, r.h_pcm, r.h_npcm,
-                                           r.h_mag, r.h_allowed, nullptr);
+      std::vector<uint32_t> redo;
+      for (uint32_t c = 0; c < g->C; c++)
+      {
+        if (r.h_fail[c] != 0) redo.push_back(c);
+      }
+      if (redo.empty())
+      {
+        continue;
+      }
+      const int rc = rx_replay(rx, redo, r.d_iq, (uint64_t)g->block_bytes * g->n_blocks, g->block_bytes, g->n_blocks,
+                               r.gain_db, r.d_pcm, r.d_npcm, r.d_mag, r.d_allowed, nullptr, rx->stream);
       if (rc != HRFD_OK)
       {
         return rc;
       }
-      r.h_counters[kCntCommit] = 1;
+      hipStream_t cs = rx->stream;
+      HIP_TRY(hipMemcpyAsync(r.h_pcm, r.d_pcm, g->pcm_elems * 2, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(r.h_npcm, r.d_npcm, g->units * 4, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(r.h_mag, r.d_mag, g->units * 4, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipMemcpyAsync(r.h_allowed, r.d_allowed, g->units, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipStreamSynchronize(cs));
+      r.h_counters[kCntFail] = 0;
+      memset(r.h_fail, 0, sizeof(uint32_t) * g->C);
       HIP_TRY(hipEventRecord(r.e_out, g->s_out));    // already complete
       g->replayed_batches++;
     }

@@ -663,6 +663,7 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
         if (lane == 0)
         {
           atomicAdd(&P.counters[kCntRepair], 1u);
+          atomicAdd(&P.sticky[kCntTotRepair], 1u);
         }
       }
     }

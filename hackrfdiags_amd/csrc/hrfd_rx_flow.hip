@@ -91,8 +91,8 @@ __device__ __forceinline__ void lds_order()
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 // Every wait of this kernel is bounded: a wave that has spun for ~0.1 s (a protocol error -- the normal waits are
-// microseconds) reports it as a speculation failure, which makes the host replay the call on the exact path, and
-// goes on; the grid always drains.  `where` identifies the wait in the diagnostics.
+// microseconds) marks its channel as failed (chan_expired), which makes the host replay that channel on the exact
+// path, and goes on; the grid always drains.  `where` identifies the wait in the diagnostics.
 constexpr uint32_t kFSpinLimit = 1u << 20;
 struct FlowSpin
 {
@@ -103,11 +103,7 @@ struct FlowSpin
     {
       return false;
     }
-    if ((threadIdx.x & 63) == 0)
-    {
-      atomicAdd(&P.counters[kCntSpec], 1u);
-    }
-    fail_code = where;
+    fail_code = where;                                   // reported as chan_expired at the end of the wave
     return true;
   }
 };
@@ -234,7 +230,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   __shared__ float parr[kFPRing];          // per tile: geometric partial sum of v
   __shared__ uint32_t pflag[8];            // partial sums of generation g are in parr: g + 1
   __shared__ uint32_t ctl[24];             // 0 next unit, 1 generations verified (their v is released), 2 generations complete (U, V, PCM), 3 blocks finished,
-                                           // 4 next generation,
+                                           // 4 next generation, 5 waves of the workgroup that are through,
                                            // 8..23 units done (per block, mod 16)
   __shared__ uint32_t magl[16][64];        // per block (mod 16: more blocks than the ring can span) and lane: sum of the sample
                                            // magnitudes.  One word per lane: a
@@ -975,6 +971,40 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     if (repairs != 0u && lane == 0)
     {
       atomicAdd(&P.counters[kCntRepair], repairs);
+      atomicAdd(&P.sticky[kCntTotRepair], repairs);
+    }
+  }
+  // The last wave of the last workgroup of a channel finishes the channel (finish_channel: squelch tracker, checks
+  // of both speculations, n_pcm / allowed outputs, commit of the pending state): no kernel behind this one.
+  // Release / acquire at agent scope around the two counters (MI355X_MICROARCH, "Workgroup dispatch ... visibility").
+  if (P.self_finish)
+  {
+    if (fail_code != 0u && lane == 0)
+    {
+      P.fin.chan_expired[c] = 1u;
+    }
+    __threadfence();
+    uint32_t prev = 0;
+    if (lane == 0)
+    {
+      prev = atomicAdd(&ctl[5], 1u);
+    }
+    if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
+    {
+      uint32_t arrived = 0;
+      if (lane == 0)
+      {
+        arrived = atomicAdd(&P.fin.chan_arrived[c], 1u);
+      }
+      if ((uint32_t)__builtin_amdgcn_readfirstlane((int)arrived) == P.n_runs - 1u)
+      {
+        if (lane == 0)
+        {
+          P.fin.chan_arrived[c] = 0u;                    // zero between launches
+        }
+        __threadfence();
+        finish_channel(P.fin, c, lane);
+      }
     }
   }
   if (P.dbg != nullptr && lane == 0)

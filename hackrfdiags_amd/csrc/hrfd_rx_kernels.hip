@@ -1313,6 +1313,7 @@ __device__ __forceinline__ void recurrence_phase(const RxParams &P, const Stream
       if (lane == 0)
       {
         atomicAdd(&P.counters[kCntRepair], repairs);
+      atomicAdd(&P.sticky[kCntTotRepair], repairs);
       }
     }
     sync();
@@ -2499,19 +2500,20 @@ template __global__ void k_rx_wbfm_stream<false>(const RxParams);
 template __global__ void k_rx_wbfm_stream<true>(const RxParams);
 
 // =============================================================================
-//  epilogue: squelch tracker over the batch, verification of both speculations,
-//  n_pcm / allowed outputs.  One wave per channel, one lane per block.
+//  finish: per channel -- squelch tracker over the batch, verification of both speculations,
+//  n_pcm / allowed outputs, and the commit of the channel's pending state when the channel
+//  verified clean.  One wave per channel (one lane per block for the checks, the lanes copy the
+//  mode's state section in parallel).  The verdict is the CHANNEL's: a closed gate or a failed
+//  speculation in one channel does not keep the others from committing (chan_fail / chan_poison);
+//  the host replays the failed channels only.
+//  Called from k_rx_finish (one workgroup per channel) and from the tail of k_rx_wbfm_flow (the
+//  last workgroup of a channel finishes it).
 // =============================================================================
-__global__ __launch_bounds__(64) void k_rx_epilogue(const EpilogueParams E)
+__device__ __forceinline__ void finish_channel(const EpilogueParams &E, const uint32_t c, const int lane)
 {
-  const uint32_t c = blockIdx.x;
-  const int lane = threadIdx.x;
-  if (c >= E.n_channels)
-  {
-    return;
-  }
   const int mode = E.cfg[c].mode;
-  uint32_t carry = E.state[c].tracking != 0 ? 1u : 0u;    // `present` of the block before
+  ChanState *dst = E.state + c;
+  uint32_t carry = dst->tracking != 0 ? 1u : 0u;          // `present` of the block before
   uint32_t gate_viol = 0, spec_viol = 0;
   for (uint32_t b0 = 0; b0 < E.n_blocks; b0 += 64)
   {
@@ -2547,49 +2549,44 @@ __global__ __launch_bounds__(64) void k_rx_epilogue(const EpilogueParams E)
     gate_viol += __shfl_down(gate_viol, off);
     spec_viol += __shfl_down(spec_viol, off);
   }
+  gate_viol = (uint32_t)__builtin_amdgcn_readfirstlane((int)gate_viol);
+  spec_viol = (uint32_t)__builtin_amdgcn_readfirstlane((int)spec_viol);
+  // a launch behind an unrepaired failed one started this channel from a stale state: it must not commit
+  const uint32_t bits = (gate_viol ? kFailGate : 0u) | (spec_viol ? kFailSpec : 0u) |
+                        (E.chan_poison[c] != 0u ? kFailPoison : 0u) | (E.chan_expired[c] != 0u ? kFailExpired : 0u);
+  const bool clean = bits == 0u;
   if (lane == 0)
   {
-    if (gate_viol)
-    {
-      atomicAdd(&E.counters[kCntGate], gate_viol);
-    }
-    if (spec_viol)
-    {
-      atomicAdd(&E.counters[kCntSpec], spec_viol);
-    }
-  }
-}
-
-// commit the pending per-channel state when the whole call verified clean.
-// One wave per channel; the lanes copy the mode's section in parallel.
-__global__ __launch_bounds__(64) void k_rx_commit(const EpilogueParams E)
-{
-  const uint32_t c = blockIdx.x;
-  const int lane = threadIdx.x;
-  // a launch behind an unrepaired failed one started from a stale state: it must not commit
-  const bool clean = (E.counters[kCntGate] | E.counters[kCntSpec] | E.sticky[kCntPoison]) == 0u;
-  if (c == 0 && lane == 0)
-  {
+    E.chan_fail[c] = bits;
+    E.chan_expired[c] = 0u;
     if (!clean)
     {
-      E.sticky[kCntPoison] = 1u;
+      E.chan_poison[c] = 1u;
+      atomicAdd(&E.counters[kCntFail], 1u);
+      atomicAdd(&E.sticky[kCntTotViol], 1u);
+      if (gate_viol)
+      {
+        atomicAdd(&E.counters[kCntGate], gate_viol);
+      }
+      if (spec_viol)
+      {
+        atomicAdd(&E.counters[kCntSpec], spec_viol);
+      }
     }
-    E.counters[kCntCommit] = clean ? 1u : 0u;
-    E.sticky[kCntTotRepair] += E.counters[kCntRepair];
-    E.sticky[kCntTotViol] += clean ? 0u : 1u;
-    E.sticky[kCntTotLaunch] += 1u;
+    if (c == E.first_channel)
+    {
+      atomicAdd(&E.sticky[kCntTotLaunch], 1u);
+    }
   }
-  if (c == 0 && lane < kCntSticky)
+  if (c == E.first_channel && lane < kCntSticky)
   {
     E.next_local[lane] = 0u;                             // the next launch counts into the other set
   }
-  if (c >= E.n_channels || !clean)
+  if (!clean)
   {
     return;
   }
-  ChanState *dst = E.state + c;
   const ChanState *src = E.state_out + c;
-  const int mode = E.cfg[c].mode;
   // tracker over the batch; was the last block demodulated?
   const uint32_t nb = E.n_blocks;
   const bool p_last = E.present[(size_t)c * nb + nb - 1] != 0;
@@ -2632,6 +2629,17 @@ __global__ __launch_bounds__(64) void k_rx_commit(const EpilogueParams E)
   {
     dst->tracking = p_last ? 1u : 0u;
   }
+}
+
+// the channels that no kernel finishes by itself: one wave per channel of E.chan_list (or 0 .. n_channels - 1)
+__global__ __launch_bounds__(64) void k_rx_finish(const EpilogueParams E)
+{
+  if (blockIdx.x >= E.n_channels)
+  {
+    return;
+  }
+  const uint32_t c = (E.chan_list != nullptr) ? E.chan_list[blockIdx.x] : blockIdx.x;
+  finish_channel(E, c, (int)threadIdx.x);
 }
 
 // explicit instantiations used by the host side

@@ -119,12 +119,17 @@ int hrfd_rx_process_device(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stri
                            uint8_t *d_signal_allowed, int8_t *d_iq256k_opt,
                            void *stream);
 /* Waits for the last hrfd_rx_process_device call.  *n_violations (may be NULL)
- * receives the number of (channel, block) units whose speculation failed in
- * that call (0 = every output is exact); when it is non-zero the per-channel
- * state has NOT been advanced and the caller should resubmit the batch one block
- * per call (n_blocks == 1 is always exact).  hrfd_rx_process_block does this
- * by itself. */
+ * receives the number of CHANNELS whose speculation failed in that call or that
+ * ran behind an unrepaired failure of their own (0 = every output is exact).  The
+ * verdict is per channel: a channel that verified clean has advanced its state and
+ * its outputs are exact; a failed channel has NOT advanced and the caller should
+ * resubmit that channel one block per call (n_blocks == 1 is always exact) --
+ * hrfd_rx_failed_channels says which, hrfd_rx_process_block does all of this by
+ * itself.  With a real squelch threshold a quiet channel fails every batch it is in
+ * (its gate closes) and costs its own replay only. */
 int hrfd_rx_sync(hrfd_rx *h, uint32_t *n_violations);
+/* out[c] != 0 for the channels of that call that did not commit (n = n_channels). */
+int hrfd_rx_failed_channels(hrfd_rx *h, uint8_t *out, uint32_t n);
 
 /* ------------------------------------------------------------------------------
  * Receive, inner boundary: one demodulator class, n_channels instances.

@@ -230,6 +230,57 @@ def test_squelch_in_a_batch_falls_back_to_exact_path(oracle):
     assert rx.debug_counters()[7] == 0          # replays only count de-emphasis redo, none needed
 
 
+def test_one_quiet_channel_does_not_stop_the_bank(oracle):
+    """The verdict of a batch is per channel: with a real squelch threshold, one channel whose gate closes
+    inside the batch fails ITS speculation and is replayed block by block; the other channels commit from
+    the batch launch (device path: sync() reports one failed channel and says which).  Squelched units
+    hand back zeros, not what the failed batch launch left in the buffer."""
+    import torch
+    C, B = 6, 5
+    loud = [synth.make_input("fmtone", 40 + c, B).reshape(B, BLK) for c in range(C)]
+    xs = np.stack(loud)
+    quiet_c = 3
+    xs[quiet_c, 1:4] = 0                                  # the gate of channel 3 closes for blocks 2 and 3 (one tail block)
+    # blocking entry: everything exact, squelched PCM zero
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    rx.set_threshold(-30)
+    pcm, n_pcm, mag, allowed, _ = rx.process_block(xs, B)
+    for c in range(C):
+        want = _oracle_stream(oracle, WBFM, xs[c], B, threshold=-30)
+        for b in range(B):
+            assert n_pcm[c, b] == len(want[b][0]) and bool(allowed[c, b]) == want[b][2], (c, b)
+            assert (pcm[c, b, :n_pcm[c, b]] == want[b][0]).all(), (c, b)
+            assert (pcm[c, b, n_pcm[c, b]:] == 0).all(), (c, b)
+    assert (n_pcm[quiet_c] == 0).sum() == 2
+    # device entry: one launch, per-channel verdict
+    dev = torch.device("cuda:0")
+    rx2 = api.Rx(C)
+    rx2.set_mode(api.WBFM)
+    rx2.set_threshold(-30)
+    x = torch.from_numpy(xs).to(dev)
+    out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    rx2.process_device(x.data_ptr(), B * BLK, BLK, B, out.data_ptr())
+    assert rx2.sync() == 1
+    assert rx2.failed_channels().tolist() == [1 if c == quiet_c else 0 for c in range(C)]
+    got = out.cpu().numpy()
+    for c in range(C):
+        if c != quiet_c:
+            assert (got[c] == pcm[c]).all(), c             # committed from the batch, exact
+    # the clean channels have advanced: a second batch continues them; the failed one has not
+    xs2 = np.stack([synth.make_input("fmtone", 40 + c, 2 * B).reshape(2 * B, BLK)[B:] for c in range(C)])
+    x2 = torch.from_numpy(xs2).to(dev)
+    torch.cuda.synchronize()
+    rx2.process_device(x2.data_ptr(), B * BLK, BLK, B, out.data_ptr())
+    rx2.sync()
+    got2 = out.cpu().numpy()
+    pcm2 = rx.process_block(xs2, B)[0]
+    for c in range(C):
+        if c != quiet_c:
+            assert (got2[c] == pcm2[c]).all(), c
+
+
 @pytest.mark.parametrize("warm", [64, 256, 384])
 def test_short_warmup_is_repaired_exactly(oracle, warm):
     """Shrinking the de-emphasis warm-up makes tiles fail to re-synchronise; the
