@@ -344,6 +344,9 @@ def main():
                     help="N > 1 only: all IQ starts on rank 0 and is scattered over RCCL inside the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="leave out the end-to-end and single-block latency figures (profiling runs: only the headline "
+                         "launches in the kernel statistics)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -485,7 +488,7 @@ def main():
             # a launch that did not commit means later launches started from a stale state and the batch path was
             # not what ran: the number is not a measurement of it
             line["invalid"] = f"{counters[5]} launch(es) were not committed"
-        if world == 1 and args.workload == "wbfm":
+        if world == 1 and args.workload == "wbfm" and not args.no_extras:
             line["end_to_end"] = end_to_end(api, device, C)
             line["single_block_latency_ms"] = single_block_latency_ms(api, device)
         if world == 1 and not args.no_cpu:

@@ -983,7 +983,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     {
       P.fin.chan_expired[c] = 1u;
     }
-    __threadfence();
+    // this wave's global stores are done (they are in the XCD's L2, which every wave of this CU reads through) ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t prev = 0;
     if (lane == 0)
     {
@@ -991,18 +992,33 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     }
     if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
     {
-      uint32_t arrived = 0;
-      if (lane == 0)
+      // ... and this is the last wave of the workgroup.  A channel cut into several runs is finished by the workgroup
+      // that arrives last; what the others wrote comes from other CUs, possibly other XCDs: one agent-scope release
+      // per workgroup in front of the arrival count, one acquire behind it (MI355X_MICROARCH, "Workgroup dispatch,
+      // XCD placement & inter-workgroup visibility").  One run per channel (the usual case): nothing to fence.
+      bool last = true;
+      if (P.n_runs > 1u)
       {
-        arrived = atomicAdd(&P.fin.chan_arrived[c], 1u);
-      }
-      if ((uint32_t)__builtin_amdgcn_readfirstlane((int)arrived) == P.n_runs - 1u)
-      {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t arrived = 0;
         if (lane == 0)
         {
-          P.fin.chan_arrived[c] = 0u;                    // zero between launches
+          arrived = __hip_atomic_fetch_add(&P.fin.chan_arrived[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __threadfence();
+        last = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived) == P.n_runs - 1u;
+        if (last)
+        {
+          if (lane == 0)
+          {
+            __hip_atomic_store(&P.fin.chan_arrived[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero between launches
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      if (last)
+      {
         finish_channel(P.fin, c, lane);
       }
     }

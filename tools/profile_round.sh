@@ -11,7 +11,7 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 stats() {   # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -- python3 $R/bench.py --no-cpu "$@" > $O/bench_under_rocprof_$name.json 2> $O/trace_$name.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -- python3 $R/bench.py --no-cpu --no-extras "$@" > $O/bench_under_rocprof_$name.json 2> $O/trace_$name.log
   python3 - "$O" "$name" <<'PY'
 import csv, glob, sys
 O, name = sys.argv[1], sys.argv[2]
@@ -35,7 +35,7 @@ if [ "$2" = "all" ]; then
   stats wbfmmod --steps 20 --warmup 10 --workload wbfmmod --channels 256
 fi
 for CNT in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc_$CNT -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu > /dev/null 2> $O/pmc_$CNT.log
+  rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc_$CNT -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extras > /dev/null 2> $O/pmc_$CNT.log
 done
 python3 - "$O" "$R" <<'PY'
 import csv, glob, collections, json, sys
