@@ -10,12 +10,19 @@
 //                  same cascade with that tool's own (asymmetric) stage-1 table.
 //
 // Everything is integer FIR work (bit-exact), so blocks of one channel are
-// independent given enough input history: a workgroup owns a tile of 32 input
-// samples (16 KiB of output), re-derives the few history samples every stage
+// independent given enough input history: a workgroup owns a tile of 64 input
+// samples (32 KiB of output), re-derives the few history samples every stage
 // needs from the PCM just before the tile (from the carried tail at the start
-// of a call), keeps stages 1-5 in LDS and runs the last three x2 stages in
+// of a call), keeps stages 1, 3, 4 and 5 in LDS (stage 2 lives in the registers of
+// the thread that feeds stage 3 with it) and runs the last three x2 stages in
 // registers so that every lane ends with 16 contiguous output bytes
 // (8 IQ pairs): one coalesced 16-byte store per lane, write traffic only.
+// Every tap is a literal (the loops are unrolled over compile-time tap indices: a
+// run-time tap index costs a memory load per multiply), and the half-band stages use
+// what their tables are: phase 1 is one tap of 16384, q15(16384 + 16384 x) = (x + 1) >> 1,
+// and phase 0 is symmetric, h (a + d) + g (b + c).  From stage 2 on no value leaves the
+// int16 range (the phases' sum of |taps| is < 1), so the reference's (int16_t)
+// narrowing is the identity there; stages 0 and 1 narrow through their int16 stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,7 +32,7 @@ constexpr int HRFD_MOD_RAILS = 100;     // internal kind: int16 (I,Q) rails in, 
 constexpr int HRFD_MOD_WB_HEAD = 101;   // WBFM modulator: (pcm, 0) pairs in, rail 0 after stage 5 out (x32)
 constexpr int HRFD_MOD_WB_TAIL = 102;   // WBFM modulator: 256 kS/s (I,Q) rails in, stages 6-8 (x8)
 #ifndef HRFD_MOD_TILE
-#define HRFD_MOD_TILE 32
+#define HRFD_MOD_TILE 64
 #endif
 constexpr int kModTile = HRFD_MOD_TILE;  // input samples per workgroup
 constexpr int kModThreads = 256;
@@ -67,31 +74,34 @@ __constant__ constexpr int16_t kS1Interp[40] = {
 // Q15 output of an interpolator phase: (16384 + sum) >> 15, low 16 bits
 __device__ __forceinline__ int q15(int acc) { return (int)(short)(acc >> 15); }
 
-// x2 stage with the 8-tap half-band prototype {-1445,0,9548,16384,9548,0,-1445,0}
-// (INTERP_HB8): phase 0 taps (h0,h2,h4,h6), phase 1 taps (h1,h3,h5,h7) = (0,16384,0,0).
-__device__ __forceinline__ void hb8(const int16_t *x, int n, int &y0, int &y1)
+// x2 stage with the 8-tap half-band prototype {-1445,0,9548,16384,9548,0,-1445,0} (INTERP_HB8), inputs
+// x[n], x[n-1], x[n-2], x[n-3] = a, b, c, d: phase 0 taps (h0,h2,h4,h6) are symmetric, phase 1 is
+// (0,16384,0,0): y1 = q15(16384 + 16384 b) = (b + 1) >> 1.
+static_assert(Q_INTERP_HB8[0] == Q_INTERP_HB8[6] && Q_INTERP_HB8[2] == Q_INTERP_HB8[4] && Q_INTERP_HB8[3] == 16384 &&
+              Q_INTERP_HB8[1] == 0 && Q_INTERP_HB8[5] == 0 && Q_INTERP_HB8[7] == 0, "hb8 relies on the table's shape");
+__device__ __forceinline__ void hb8(int a, int b, int c, int d, int &y0, int &y1)
 {
-  const int acc = (1 << 14) + (int)Q_INTERP_HB8[0] * x[n] + (int)Q_INTERP_HB8[2] * x[n - 1] +
-                  (int)Q_INTERP_HB8[4] * x[n - 2] + (int)Q_INTERP_HB8[6] * x[n - 3];
-  y0 = q15(acc);
-  y1 = q15((1 << 14) + (int)Q_INTERP_HB8[1] * x[n] + (int)Q_INTERP_HB8[3] * x[n - 1] +
-           (int)Q_INTERP_HB8[5] * x[n - 2] + (int)Q_INTERP_HB8[7] * x[n - 3]);
+  y0 = ((1 << 14) + (int)Q_INTERP_HB8[0] * (a + d) + (int)Q_INTERP_HB8[2] * (b + c)) >> 15;
+  y1 = (b + 1) >> 1;
 }
 
-// x2 stage with a 4-tap prototype {h0, h1, h2, 0}: phase 0 (h0,h2), phase 1 (h1,0)
-__device__ __forceinline__ void hb4(const int16_t (&h)[4], int xn, int xm1, int &y0, int &y1)
+// x2 stage with a 4-tap prototype {h, 16384, h, 0}: phase 0 = h (x[n] + x[n-1]), phase 1 = (x[n] + 1) >> 1
+template <int H>
+__device__ __forceinline__ void hb4(int xn, int xm1, int &y0, int &y1)
 {
-  y0 = q15((1 << 14) + (int)h[0] * xn + (int)h[2] * xm1);
-  y1 = q15((1 << 14) + (int)h[1] * xn + (int)h[3] * xm1);
+  y0 = ((1 << 14) + H * (xn + xm1)) >> 15;
+  y1 = (xn + 1) >> 1;
 }
+static_assert(Q_INTERP_HB3[0] == Q_INTERP_HB3[2] && Q_INTERP_HB3[1] == 16384 && Q_INTERP_HB3[3] == 0, "hb4 relies on the table's shape");
+static_assert(Q_INTERP_HB2[0] == Q_INTERP_HB2[2] && Q_INTERP_HB2[1] == 16384 && Q_INTERP_HB2[3] == 0, "hb4 relies on the table's shape");
+static_assert(Q_INTERP_HB1[0] == Q_INTERP_HB1[2] && Q_INTERP_HB1[1] == 16384 && Q_INTERP_HB1[3] == 0, "hb4 relies on the table's shape");
 
-// LDS layout per rail (int16), each stage with its history in front:
-//   x0 [24 + 32]   s1 [6 + 64]   s2 [4 + 128]   s3 [6 + 256]   s4 [4 + 512]   s5 [2 + 1024]
-constexpr int kH0 = 24, kH1 = 6, kH2 = 4, kH3 = 6, kH4 = 4, kH5 = 2;
+// LDS layout per rail (int16), each stage with its history in front (stage 2 is never stored):
+//   x0 [24 + T]   s1 [6 + 2T]   s3 [8 + 8T]   s4 [4 + 16T]   s5 [2 + 32T]
+constexpr int kH0 = 24, kH1 = 6, kH3 = 8, kH4 = 4, kH5 = 2;
 constexpr int kO0 = 0;
 constexpr int kO1 = kO0 + kH0 + kModTile;
-constexpr int kO2 = kO1 + kH1 + 2 * kModTile;
-constexpr int kO3 = kO2 + kH2 + 4 * kModTile;
+constexpr int kO3 = kO1 + kH1 + 2 * kModTile;
 constexpr int kO4 = kO3 + kH3 + 8 * kModTile;
 constexpr int kO5 = kO4 + kH4 + 16 * kModTile;
 constexpr int kRail = kO5 + kH5 + 32 * kModTile + 6;
@@ -226,11 +236,13 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       {
         // delay line: Q15 tap -32768 at k = 15 (FirFilter_int16.cc:151-224)
         iv = q15((1 << 14) + (-32768) * (int)s0[-15]);
+        // 31-tap Hilbert: the odd taps are zero and h[30 - k] = -h[k] (checked below), int32 wrap-around sum
         int acc = 1 << 14;
   #pragma unroll
-        for (int k = 0; k < N_SSB_HILBERT; k++)
+        for (int k = 0; k < 15; k += 2)
         {
-          acc += (int)kHilbert[k] * (int)s0[-k];
+          static_assert(N_SSB_HILBERT == 31, "");
+          acc += (int)Q_SSB_HILBERT[k] * ((int)s0[-k] - (int)s0[-(30 - k)]);
         }
         qv = q15(acc);
         if (!M.lsb[c])
@@ -254,69 +266,82 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       }
     }
 
-    // ---- stage 1: 40-tap prototype, x2; outputs m in [-kH1, 2*tile)
+    // ---- stage 1: 40-tap prototype, x2: both phases of one input position n per thread and rail,
+    //      outputs m = 2n, 2n + 1 for n in [-kH1/2, tile)
     {
-      const int16_t *h = (KIND == HRFD_MOD_INTERP) ? kS1Interp : kS1Ssb;
-      for (int t = tid; t < 2 * (kH1 + 2 * kModTile); t += kModThreads)
+      constexpr const int16_t (&h)[40] = (KIND == HRFD_MOD_INTERP) ? Q_INTERPSIG_S1 : Q_AUDIO_D40;
+      for (int t = tid; t < 2 * (kH1 / 2 + kModTile); t += kModThreads)
       {
         const int rail = t & 1, u = t >> 1;
-        const int m = u - kH1;                              // output index at 16 kS/s
-        const int nn = m >> 1, ph = m & 1;                  // floor division (m may be negative)
+        const int nn = u - kH1 / 2;
         const int16_t *x = &r[rail][kO0 + kH0 + nn];
-        int acc = 1 << 14;
+        int acc0 = 1 << 14, acc1 = 1 << 14;
   #pragma unroll
         for (int j = 0; j < 20; j++)
         {
-          acc += (int)h[ph + 2 * j] * (int)x[-j];
+          const int xv = (int)x[-j];
+          acc0 += (int)h[2 * j] * xv;
+          acc1 += (int)h[2 * j + 1] * xv;
         }
-        r[rail][kO1 + u] = (int16_t)q15(acc);
+        // (int16 stores narrow: the 40-tap phases can exceed the int16 range for adversarial input, wrap is the contract)
+        r[rail][kO1 + 2 * u] = (int16_t)(acc0 >> 15);
+        r[rail][kO1 + 2 * u + 1] = (int16_t)(acc1 >> 15);
       }
     }
     __syncthreads();
-    // ---- stage 2: HB8, outputs m in [-kH2, 4*tile)
-    // (from here on a thread produces both phases of one input sample of one rail)
-    for (int t = tid; t < 2 * ((kH2 + 4 * kModTile) / 2); t += kModThreads)
-    {
-      const int rail = t & 1, u = t >> 1;                   // u: input sample slot
-      const int nn = u - kH2 / 2;                           // input index (16 kS/s)
-      int y0, y1;
-      hb8(&r[rail][kO1 + kH1], nn, y0, y1);
-      r[rail][kO2 + 2 * u] = (int16_t)y0;
-      r[rail][kO2 + 2 * u + 1] = (int16_t)y1;
-    }
-    __syncthreads();
-    // ---- stage 3: 4-tap HB3, outputs m in [-kH3, 8*tile)
-    for (int t = tid; t < 2 * ((kH3 + 8 * kModTile) / 2); t += kModThreads)
+    // ---- stages 2 (HB8) and 3 (HB3): one stage-1 position p per thread and rail -> s2[2p], s2[2p+1] in
+    //      registers (and s2[2p-1], the cheap phase-1 value of the position before) -> s3[4p .. 4p+3]
+    for (int t = tid; t < 2 * (kH3 / 4 + 2 * kModTile); t += kModThreads)
     {
       const int rail = t & 1, u = t >> 1;
-      const int nn = u - kH3 / 2;
-      const int16_t *x = &r[rail][kO2 + kH2];
-      int y0, y1;
-      hb4(Q_INTERP_HB3, x[nn], x[nn - 1], y0, y1);
-      r[rail][kO3 + 2 * u] = (int16_t)y0;
-      r[rail][kO3 + 2 * u + 1] = (int16_t)y1;
+      const int pp = u - kH3 / 4;                          // stage-1 index, from -2
+      const int16_t *x = &r[rail][kO1 + kH1 + pp];
+      const int xa = x[0], xb = x[-1], xc = x[-2], xd = x[-3];
+      int e0, e1;
+      hb8(xa, xb, xc, xd, e0, e1);                         // s2[2p], s2[2p+1]
+      const int em1 = (xc + 1) >> 1;                       // s2[2p-1]
+      int y0, y1, y2, y3;
+      hb4<Q_INTERP_HB3[0]>(e0, em1, y0, y1);
+      hb4<Q_INTERP_HB3[0]>(e1, e0, y2, y3);
+      // (int16 pairs: 4u is even)
+      uint32_t *o = reinterpret_cast<uint32_t *>(&r[rail][kO3 + 4 * u]);
+      o[0] = ((uint32_t)y0 & 0xffffu) | ((uint32_t)y1 << 16);
+      o[1] = ((uint32_t)y2 & 0xffffu) | ((uint32_t)y3 << 16);
     }
     __syncthreads();
-    // ---- stage 4: HB8, outputs m in [-kH4, 16*tile)
-    for (int t = tid; t < 2 * ((kH4 + 16 * kModTile) / 2); t += kModThreads)
+    // ---- stage 4: HB8, outputs m in [-kH4, 16*tile); two stage-3 positions per thread and rail
+    for (int t = tid; t < 2 * ((kH4 / 2 + 8 * kModTile) / 2); t += kModThreads)
     {
-      const int rail = t & 1, u = t >> 1;
-      const int nn = u - kH4 / 2;
-      int y0, y1;
-      hb8(&r[rail][kO3 + kH3], nn, y0, y1);
-      r[rail][kO4 + 2 * u] = (int16_t)y0;
-      r[rail][kO4 + 2 * u + 1] = (int16_t)y1;
+      const int rail = t & 1, u = t >> 1;                   // u: pair of input positions 2u, 2u+1 (offset by the history)
+      const int nn = 2 * u - kH4 / 2;                       // first input index of the pair (even)
+      const int16_t *x = &r[rail][kO3 + kH3 + nn];
+      const int x1 = x[1], x0 = x[0], xm1 = x[-1], xm2 = x[-2], xm3 = x[-3];
+      int y0, y1, y2, y3;
+      hb8(x0, xm1, xm2, xm3, y0, y1);
+      hb8(x1, x0, xm1, xm2, y2, y3);
+      uint32_t *o = reinterpret_cast<uint32_t *>(&r[rail][kO4 + 4 * u]);
+      o[0] = ((uint32_t)y0 & 0xffffu) | ((uint32_t)y1 << 16);
+      o[1] = ((uint32_t)y2 & 0xffffu) | ((uint32_t)y3 << 16);
     }
     __syncthreads();
     // ---- stage 5: HB8, outputs m in [-kH5, 32*tile)
-    for (int t = tid; t < 2 * ((kH5 + 32 * kModTile) / 2); t += kModThreads)
+    for (int t = tid; t < 2 * ((kH5 / 2 + 16 * kModTile + 1) / 2); t += kModThreads)
     {
       const int rail = t & 1, u = t >> 1;
-      const int nn = u - kH5 / 2;
-      int y0, y1;
-      hb8(&r[rail][kO4 + kH4], nn, y0, y1);
-      r[rail][kO5 + 2 * u] = (int16_t)y0;
-      r[rail][kO5 + 2 * u + 1] = (int16_t)y1;
+      const int nn = 2 * u - kH5 / 2 - 1;                   // odd first index: output dwords stay aligned (kO5 + kH5 + 2 nn even)
+      const int16_t *x = &r[rail][kO4 + kH4 + nn];
+      const int x1 = x[1], x0 = x[0], xm1 = x[-1], xm2 = x[-2], xm3 = x[-3];
+      int y0, y1, y2, y3;
+      hb8(x0, xm1, xm2, xm3, y0, y1);
+      hb8(x1, x0, xm1, xm2, y2, y3);
+      int16_t *o = &r[rail][kO5 + kH5 + 2 * nn];
+      if (nn >= -kH5 / 2)
+      {
+        o[0] = (int16_t)y0;
+        o[1] = (int16_t)y1;
+      }
+      o[2] = (int16_t)y2;
+      o[3] = (int16_t)y3;
     }
     __syncthreads();
 
@@ -347,19 +372,20 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       const int xa = x5[j], xb = x5[j - 1], xc = x5[j - 2];
       // stage 6 (HB3): y6[2j-1] (phase 1 of j-1), y6[2j], y6[2j+1]
       int a0, a1, p0, p1;
-      hb4(Q_INTERP_HB3, xb, xc, p0, p1);                  // p1 = y6[2j-1]
-      hb4(Q_INTERP_HB3, xa, xb, a0, a1);                  // y6[2j], y6[2j+1]
+      hb4<Q_INTERP_HB3[0]>(xb, xc, p0, p1);               // p1 = y6[2j-1]
+      hb4<Q_INTERP_HB3[0]>(xa, xb, a0, a1);               // y6[2j], y6[2j+1]
       // stage 7 (HB2): y7[4j-1] (phase 1 of y6[2j-1]), y7[4j..4j+3]
-      int b0, b1, b2, b3, q0, q1;
-      hb4(Q_INTERP_HB2, p1, p0, q0, q1);                  // q1 = y7[4j-1]
-      hb4(Q_INTERP_HB2, a0, p1, b0, b1);                  // y7[4j], y7[4j+1]
-      hb4(Q_INTERP_HB2, a1, a0, b2, b3);                  // y7[4j+2], y7[4j+3]
+      int b0, b1, b2, b3;
+      const int q1 = (p1 + 1) >> 1;                       // y7[4j-1]
+      (void)p0;
+      hb4<Q_INTERP_HB2[0]>(a0, p1, b0, b1);               // y7[4j], y7[4j+1]
+      hb4<Q_INTERP_HB2[0]>(a1, a0, b2, b3);               // y7[4j+2], y7[4j+3]
       // stage 8 (HB1): y8[8j .. 8j+7], (int8_t) narrowing (:607-610)
       int y[8];
-      hb4(Q_INTERP_HB1, b0, q1, y[0], y[1]);
-      hb4(Q_INTERP_HB1, b1, b0, y[2], y[3]);
-      hb4(Q_INTERP_HB1, b2, b1, y[4], y[5]);
-      hb4(Q_INTERP_HB1, b3, b2, y[6], y[7]);
+      hb4<Q_INTERP_HB1[0]>(b0, q1, y[0], y[1]);
+      hb4<Q_INTERP_HB1[0]>(b1, b0, y[2], y[3]);
+      hb4<Q_INTERP_HB1[0]>(b2, b1, y[4], y[5]);
+      hb4<Q_INTERP_HB1[0]>(b3, b2, y[6], y[7]);
 #pragma unroll
       for (int k = 0; k < 8; k++)
       {
