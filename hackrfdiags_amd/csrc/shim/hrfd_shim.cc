@@ -159,7 +159,7 @@ void SsbDemodulator::displayInternalInformation(void) { display("SSB Demodulator
 IqDataProcessor::IqDataProcessor(char *hostIpAddress,int hostPort)
 {
   // IqDataProcessor.cc:139: the `enable iqdump` stream goes to hostIpAddress:hostPort as
-  // 2048-byte datagrams (UdpClient, hrfd_shim_io.cc) unless a sink is registered instead
+  // 2048-byte datagrams (the application's UdpClient) unless a sink is registered instead
   networkInterfacePtr = new UdpClient(hostIpAddress, hostPort);
   handle = NULL;
   demodulatorMode = None;
@@ -306,8 +306,12 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
   }
 }
 
-// Public in the reference but only meaningful through acceptIqData (decimatedData is
-// private there too): advances the decimators by running the front end alone.
+// Public in the reference (IqDataProcessor.cc:429-500): the three half-band stages per rail over one buffer,
+// result in the private decimatedData, decimator pipelines advanced, NO Fs/4 mix (acceptIqData applies that
+// separately).  Here the front end only exists fused with the mixer, so a mode-NONE block runs (front-end history
+// advanced like the reference's pipelines) and the mix is taken out of decimatedData again -- the int8 rotation is
+// exactly invertible, -(-128) wraps to -128 both ways.  One deviation: the squelch detector and tracker also see
+// this block (the reference's reduceSampleRate does not touch them); the application never calls this directly.
 uint32_t IqDataProcessor::reduceSampleRate(int8_t *bufferPtr,uint32_t bufferLength)
 {
   uint32_t sampleCount = 0;
@@ -321,36 +325,38 @@ uint32_t IqDataProcessor::reduceSampleRate(int8_t *bufferPtr,uint32_t bufferLeng
   if (rc != HRFD_OK) fatal("reduceSampleRate", rc);
   rc = hrfd_rx_set_mode(handle, 0, (int)demodulatorMode);
   if (rc != HRFD_OK) fatal("hrfd_rx_set_mode", rc);
+  downconvertByFsOver4(decimatedData, bufferLength / 8);
   return bufferLength / 8;
 }
 
-// Stand-alone helpers of the reference (IqDataProcessor.cc:700-744, :771-815): a period-4
-// rotation of a caller-owned 256 kS/s buffer.  Not on the per-block path (the fused
-// kernel does its own rotation); stated here directly so that the symbol exists.
+// Stand-alone helpers of the reference's public interface (IqDataProcessor.h:55-56): multiply sample n of a
+// caller-owned interleaved int8 IQ buffer by j^n (up) or (-j)^n (down).  Not on the per-block path (the fused
+// kernels rotate by themselves).  One table-free form for both directions: a quarter turn maps (i, q) to (-q, i),
+// k quarter turns are applied by exchanging and negating according to k & 3; int8 negation wraps.
+namespace {
+inline void quarter_turns(int8_t *iq, uint32_t byteCount, unsigned step)
+{
+  const uint32_t samples = byteCount / 2;
+  for (uint32_t n = 0; n < samples; n++)
+  {
+    const unsigned k = (n * step) & 3u;                  // quarter turns for this sample
+    const int8_t i = iq[2 * n], q = iq[2 * n + 1];
+    const int8_t a = (k & 1u) ? q : i, b = (k & 1u) ? i : q;            // odd k exchanges the rails
+    const bool negFirst = (k == 1u || k == 2u), negSecond = (k == 2u || k == 3u);
+    iq[2 * n] = negFirst ? (int8_t)(0 - a) : a;
+    iq[2 * n + 1] = negSecond ? (int8_t)(0 - b) : b;
+  }
+}
+}  // namespace
+
 void IqDataProcessor::upconvertByFsOver4(int8_t *bufferPtr,uint32_t byteCount)
 {
-  for (uint32_t i = 0; i < byteCount; i += 8)
-  {
-    int8_t x = bufferPtr[i + 2], y = bufferPtr[i + 3];
-    bufferPtr[i + 2] = (int8_t)-y; bufferPtr[i + 3] = x;
-    x = bufferPtr[i + 4]; y = bufferPtr[i + 5];
-    bufferPtr[i + 4] = (int8_t)-x; bufferPtr[i + 5] = (int8_t)-y;
-    x = bufferPtr[i + 6]; y = bufferPtr[i + 7];
-    bufferPtr[i + 6] = y; bufferPtr[i + 7] = (int8_t)-x;
-  }
+  quarter_turns(bufferPtr, byteCount, 1u);               // j^n
 }
 
 void IqDataProcessor::downconvertByFsOver4(int8_t *bufferPtr,uint32_t byteCount)
 {
-  for (uint32_t i = 0; i < byteCount; i += 8)
-  {
-    int8_t x = bufferPtr[i + 2], y = bufferPtr[i + 3];
-    bufferPtr[i + 2] = y; bufferPtr[i + 3] = (int8_t)-x;
-    x = bufferPtr[i + 4]; y = bufferPtr[i + 5];
-    bufferPtr[i + 4] = (int8_t)-x; bufferPtr[i + 5] = (int8_t)-y;
-    x = bufferPtr[i + 6]; y = bufferPtr[i + 7];
-    bufferPtr[i + 6] = (int8_t)-y; bufferPtr[i + 7] = x;
-  }
+  quarter_turns(bufferPtr, byteCount, 3u);               // (-j)^n = j^(3n)
 }
 
 void IqDataProcessor::enableSignalNotification(void) { signalNotificationEnabled = true; }
@@ -719,4 +725,154 @@ void DataProvider::displayInternalInformation(void)
   nprintf(stderr, "--------------------------------------------\n");
   nprintf(stderr, "IQ File Name            : %s\n", iqFileName);
   nprintf(stderr, "IQ Sample Buffer Index  : %u\n", index);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BasebandDataProcessor: the transmit boundary's dispatcher.  libhackrf's transmit callback asks
+// for one transfer buffer of IQ (getIqData, BasebandDataProcessor.cc:381); one 512-sample PCM block comes off the
+// ring (hrfd_txring_read_batch = getNextFilledBuffer, :482-606: drop / repeat pacing, zeros while idle) and goes
+// through the modulator of the current mode (:630-697); mode None fills the buffer with 64 (:641).
+// ---------------------------------------------------------------------------------------------
+#include <sys/select.h>
+
+#include "BasebandDataProcessor.h"
+
+BasebandDataProcessor::BasebandDataProcessor(void)
+    : ring(NULL), streamState(Idle), modulatorMode(None), amModulatorPtr(NULL), fmModulatorPtr(NULL),
+      wbFmModulatorPtr(NULL), ssbModulatorPtr(NULL), timeToStopReaderThread(false), readerThreadStarted(false),
+      basebandReaderThread()
+{
+  const int rc = hrfd_txring_create(1, &ring);
+  if (rc != HRFD_OK) fatal("hrfd_txring_create", rc);
+  memset(pcmBlock, 0, sizeof(pcmBlock));
+}
+
+BasebandDataProcessor::~BasebandDataProcessor(void)
+{
+  stop();
+  hrfd_txring_destroy(ring);
+}
+
+void BasebandDataProcessor::setAmModulator(AmModulator *modulatorPtr) { amModulatorPtr = modulatorPtr; }
+void BasebandDataProcessor::setFmModulator(FmModulator *modulatorPtr) { fmModulatorPtr = modulatorPtr; }
+void BasebandDataProcessor::setWbFmModulator(WbFmModulator *modulatorPtr) { wbFmModulatorPtr = modulatorPtr; }
+void BasebandDataProcessor::setSsbModulator(SsbModulator *modulatorPtr) { ssbModulatorPtr = modulatorPtr; }
+
+void BasebandDataProcessor::setModulatorMode(modulatorType mode)
+{
+  modulatorMode = mode;
+  if (ssbModulatorPtr != NULL)
+  {
+    if (mode == Lsb) ssbModulatorPtr->setLsbModulationMode();
+    if (mode == Usb) ssbModulatorPtr->setUsbModulationMode();
+  }
+}
+
+void BasebandDataProcessor::putPcmBlock(const int16_t *pcm512)
+{
+  const int rc = hrfd_txring_write(ring, 0, pcm512);
+  if (rc != HRFD_OK) fatal("hrfd_txring_write", rc);
+}
+
+// BasebandDataProcessor.cc:834-887: standard input, 512 samples at a time, polled every 5 ms
+void *BasebandDataProcessor::basebandReaderProcedure(void *arg)
+{
+  BasebandDataProcessor *me = static_cast<BasebandDataProcessor *>(arg);
+  int16_t block[PCM_BLOCK_SIZE];
+  fprintf(stderr, "Entering Baseband Reader.\n");
+  while (!me->timeToStopReaderThread)
+  {
+    fd_set fds;
+    FD_ZERO(&fds);
+    FD_SET(0, &fds);
+    struct timeval tv = {0, 5000};
+    if (select(1, &fds, NULL, NULL, &tv) > 0)
+    {
+      memset(block, 0, sizeof(block));
+      if (fread(block, sizeof(int16_t), PCM_BLOCK_SIZE, stdin) == 0 && feof(stdin))
+      {
+        break;                                           // (the reference keeps polling a closed stdin)
+      }
+      me->putPcmBlock(block);
+    }
+  }
+  fprintf(stderr, "Exiting Baseband Reader.\n");
+  return NULL;
+}
+
+void BasebandDataProcessor::start(void)
+{
+  if (streamState == Idle)
+  {
+    timeToStopReaderThread = false;
+    hrfd_txring_set_running(ring, 0, 1);
+    pthread_create(&basebandReaderThread, NULL, basebandReaderProcedure, this);
+    readerThreadStarted = true;
+    streamState = Running;
+  }
+}
+
+void BasebandDataProcessor::startWithoutReader(void)
+{
+  if (streamState == Idle)
+  {
+    hrfd_txring_set_running(ring, 0, 1);
+    readerThreadStarted = false;
+    streamState = Running;
+  }
+}
+
+void BasebandDataProcessor::stop(void)
+{
+  if (streamState == Running)
+  {
+    timeToStopReaderThread = true;
+    if (readerThreadStarted)
+    {
+      pthread_join(basebandReaderThread, NULL);
+      readerThreadStarted = false;
+    }
+    hrfd_txring_set_running(ring, 0, 0);                 // also drops the ring's synchronisation (:352)
+    streamState = Idle;
+  }
+}
+
+void BasebandDataProcessor::getIqData(int8_t *bufferPtr,int32_t byteCount)
+{
+  modulateBasebandData(bufferPtr, (uint32_t)byteCount);
+}
+
+void BasebandDataProcessor::modulateBasebandData(int8_t *bufferPtr,uint32_t bufferLength)
+{
+  uint32_t outputBufferLength = 0;
+  const int rc = hrfd_txring_read_batch(ring, pcmBlock);
+  if (rc != HRFD_OK) fatal("hrfd_txring_read_batch", rc);
+  switch (modulatorMode)
+  {
+    case None: memset(bufferPtr, 64, bufferLength); break;
+    case Am: amModulatorPtr->acceptData(pcmBlock, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
+    case Fm: fmModulatorPtr->acceptData(pcmBlock, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
+    case WbFm: wbFmModulatorPtr->acceptData(pcmBlock, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
+    case Lsb:
+    case Usb: ssbModulatorPtr->acceptData(pcmBlock, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
+    default: break;
+  }
+}
+
+void BasebandDataProcessor::displayInternalInformation(void)
+{
+  uint32_t st[6] = {0, 0, 0, 0, 0, 0};
+  hrfd_txring_stats(ring, 0, st);
+  nprintf(stderr, "\n--------------------------------------------\n");
+  nprintf(stderr, "Baseband Data Processor Internal Information\n");
+  nprintf(stderr, "--------------------------------------------\n");
+  static const char *names[] = {"None", "AM", "FM", "WBFM", "LSB", "USB"};
+  nprintf(stderr, "Modulator Mode            : %s\n", names[(int)modulatorMode]);
+  nprintf(stderr, "Stream State              : %s\n", streamState == Running ? "Running" : "Idle");
+  nprintf(stderr, "PCM Buffers Produced      : %u\n", st[0]);
+  nprintf(stderr, "PCM Buffers Consumed      : %u\n", st[1]);
+  nprintf(stderr, "PCM Blocks Dropped        : %u\n", st[2]);
+  nprintf(stderr, "PCM Blocks Added          : %u\n", st[3]);
+  nprintf(stderr, "PCM Writer Index          : %u\n", st[4]);
+  nprintf(stderr, "PCM Reader Index          : %u\n", st[5]);
 }

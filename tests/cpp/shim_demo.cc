@@ -6,6 +6,9 @@
 // usage: shim_demo <mode 1..5> <outer|inner> <block_bytes> [iqdump udp port]
 //        shim_demo <port> udp <bytes per sendData>            (stdin -> UdpClient datagrams)
 //        shim_demo <calls> provider <bytes per call> <file>   (DataProvider playback -> stdout)
+//        shim_demo <mode 0..5> bbp 0 <schedule of w/r/s/p>     (BasebandDataProcessor: PCM blocks on stdin through the ring
+//                                                             and the mode's modulator, 262144 bytes of IQ per block -> stdout)
+//        shim_demo <0|1> fs4 <bytes>                          (upconvertByFsOver4 / downconvertByFsOver4 on stdin -> stdout)
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,6 +22,7 @@
 #include "FmModulator.h"
 #include "WbFmModulator.h"
 #include "DataProvider.h"
+#include "BasebandDataProcessor.h"
 
 uint32_t radio_adjustableReceiveGainInDb = 0;          // Radio.cc:15
 void nprintf(FILE *s, const char *formatPtr, ...)      // diagUi.cc:2881
@@ -90,6 +94,56 @@ int main(int argc, char **argv)
     return 0;
   }
 
+  if (strcmp(argv[2], "bbp") == 0)
+  {
+    // transmit boundary (BasebandDataProcessor.cc:381, 630-697): the ring is filled by hand (putPcmBlock) instead of the
+    // stdin reader thread so that the pacing is deterministic: the stream runs, seven blocks of lead, then one block
+    // in, one transfer buffer out -- the lag stays between the "repeat" and the "drop" marks
+    BasebandDataProcessor bbp;
+    AmModulator am;
+    FmModulator fm;
+    WbFmModulator wb;
+    SsbModulator ssb;
+    bbp.setAmModulator(&am);
+    bbp.setFmModulator(&fm);
+    bbp.setWbFmModulator(&wb);
+    bbp.setSsbModulator(&ssb);
+    bbp.setModulatorMode((BasebandDataProcessor::modulatorType)mode);
+    // argv[4]: a schedule -- 'w' one PCM block from stdin into the ring, 'r' one transfer buffer out,
+    // 's' / 'p' the stream starts (without the stdin reader thread) / stops
+    const char *ops = argc >= 5 ? argv[4] : "r";
+    std::vector<int16_t> pcm(512);
+    std::vector<int8_t> iq(262144);
+    for (const char *o = ops; *o; o++)
+    {
+      if (*o == 'w')
+      {
+        if (fread(pcm.data(), 2, 512, stdin) != 512) return 4;
+        bbp.putPcmBlock(pcm.data());
+      }
+      else if (*o == 'r')
+      {
+        bbp.getIqData(iq.data(), 262144);
+        fwrite(iq.data(), 1, 262144, stdout);
+      }
+      else if (*o == 's') bbp.startWithoutReader();
+      else if (*o == 'p') bbp.stop();
+    }
+    bbp.displayInternalInformation();
+    return 0;
+  }
+  if (strcmp(argv[2], "fs4") == 0)
+  {
+    IqDataProcessor *p = NULL;
+    static char ip2[] = "127.0.0.1";
+    IqDataProcessor proc2(ip2, 8001);
+    p = &proc2;
+    const size_t got = fread(buf.data(), 1, blockBytes, stdin);
+    if (mode) p->upconvertByFsOver4(buf.data(), (uint32_t)got);
+    else p->downconvertByFsOver4(buf.data(), (uint32_t)got);
+    fwrite(buf.data(), 1, got, stdout);
+    return 0;
+  }
   if (strcmp(argv[2], "udp") == 0)
   {
     // UdpClient alone: stdin -> datagrams towards 127.0.0.1:<mode>, <block_bytes> per sendData call

@@ -1,4 +1,4 @@
-// tests/cpp/udp_demo.cc -- the shim's UdpClient alone (no libhrfd): stdin -> datagrams towards
+// tests/cpp/udp_demo.cc -- the UdpClient test double alone (tests/cpp/UdpClient.h; no libhrfd): stdin -> datagrams towards
 // 127.0.0.1:<port>, <bytes> per sendData call.   usage: udp_demo <port> <bytes per call>
 #include <stdio.h>
 #include <stdlib.h>

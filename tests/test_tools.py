@@ -1,6 +1,6 @@
 """Tooling either side of the hot path, CPU part: the oracle's restatement
 of signals/{am,dsb,pm,fm}.cc against the reference-generated fixtures (and the reference programs
-themselves where oracle/_ref exists), and the shim's UdpClient (`enable iqdump` wire format) against
+themselves where oracle/_ref exists), and the `enable iqdump` wire format as the shim emits it (through a UdpClient: the application's own, a test double here) against
 the reference's datagram sequence."""
 import json
 import os

@@ -73,7 +73,7 @@ def orc_siggen(oracle, kind: str, pcm: np.ndarray, theta: float = 0.0):
 def build_udp_demo() -> str:
     exe = os.path.join(ROOT, "tests", "cpp", "udp_demo")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "udp_demo.cc"),
-                           os.path.join(SHIM, "hrfd_shim_io.cc"), "-I", SHIM])
+                           "-I", os.path.join(ROOT, "tests", "cpp")])
     return exe
 
 
