@@ -216,7 +216,7 @@ static int rx_free(hrfd_rx *h)
   if (h->side) (void)hipStreamSynchronize(h->side);
   void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_atcorr2, h->d_att0, h->d_dbfs, h->d_counters,
                   h->d_lists, h->d_sub_lists, h->d_chan, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
-                  h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq};
+                  h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq, h->d_dbg};
   for (void *p : ptrs)
   {
     if (p) (void)hipFree(p);
@@ -732,6 +732,12 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   if (channel_stride < (uint64_t)block_bytes * n_blocks)
   {
     return fail(HRFD_EINVAL, "channel_stride smaller than n_blocks*block_bytes");
+  }
+  if ((uint64_t)block_bytes * n_blocks > 0x7fffffffull)
+  {
+    // the kernels address a channel's input through a 32-bit buffer descriptor (num_records, byte offsets)
+    return fail(HRFD_EINVAL, "n_blocks*block_bytes = %llu exceeds 2^31 - 1 bytes per channel and call",
+                (unsigned long long)block_bytes * n_blocks);
   }
   HIP_TRY(hipSetDevice(h->device));
 

@@ -138,7 +138,7 @@ int hrfd_rx_failed_channels(hrfd_rx *h, uint8_t *out, uint32_t n);
  *           SsbDemodulator::set{Lsb,Usb}DemodulationMode
  *           (WbFmDemodulator.h:23-31, FmDemodulator.h:23-31, AmDemodulator.h:23-31,
  *            SsbDemodulator.h:24-34).
- * Input is 256 kS/s int8 IQ, already mixed; bytes_per_channel a multiple of 64,
+ * Input is 256 kS/s int8 IQ, already mixed; bytes_per_channel a multiple of 128 (two PCM samples: the kernels store PCM as 4-byte pairs),
  * <= 32768 (the reference's fixed member arrays).  The PCM callback of the
  * reference becomes the pcm/n_pcm output pair; the C++ shim invokes the callback.
  */

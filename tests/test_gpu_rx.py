@@ -605,3 +605,53 @@ def test_wbfm_batches_with_ragged_runs(oracle, C, B, bb):
             assert (pcm[c, b, :len(p)] == p).all(), (C, B, bb, c, b)
             assert int(mag[c, b]) == m
     assert rx.debug_counters()[5] == 0
+
+
+def test_setters_from_a_second_thread(oracle):
+    """SURVEY 8b, threading: acceptIqData has one caller thread, the setters arrive unsynchronised from the CLI
+    thread (reference: the telnet thread calls Radio's setters while DataConsumer's thread demodulates).  A second
+    thread hammers set_gain / set_threshold / set_mode / reset-free setters with the values already in force (so
+    that the expected PCM is known) while the first one processes blocks, single and batched: no crash, no torn
+    configuration -- every block equals the oracle's -- and a real gain change issued from the second thread
+    between two calls takes effect at the next block."""
+    import threading
+    C, B = 3, 10
+    xs = np.stack([synth.make_input("fmtone" if c else "lcg", 90 + c, B + 4) for c in range(C)]).reshape(C, B + 4, BLK)
+    g0 = float(np.float32(256000 / (2 * np.pi)))
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    stop = threading.Event()
+    calls = [0]
+
+    def hammer():
+        k = 0
+        while not stop.is_set():
+            rx.set_gain(api.WBFM, g0, channel=k % C)
+            rx.set_threshold(-200)
+            rx.set_mode(api.WBFM, channel=(k + 1) % C)
+            k += 1
+        calls[0] = k
+
+    t = threading.Thread(target=hammer)
+    t.start()
+    got = [rx.process_block(xs[:, b:b + 1], 1)[0] for b in range(B - 4)]
+    got.append(rx.process_block(xs[:, B - 4:B], 4)[0])
+    stop.set()
+    t.join()
+    assert calls[0] > 10
+    pcm = np.concatenate(got, axis=1)
+    # a real change from another thread, between two calls
+    t2 = threading.Thread(target=lambda: rx.set_gain(api.WBFM, g0 * 0.5))
+    t2.start()
+    t2.join()
+    tail = rx.process_block(xs[:, B:B + 4], 4)[0]
+    for c in range(C):
+        o = oracle.rx()
+        o.set_mode(WBFM)
+        for b in range(B):
+            p = o.process(xs[c, b])[0]
+            assert (pcm[c, b, :len(p)] == p).all(), (c, b)
+        o.set_gain(WBFM, g0 * 0.5)
+        for b in range(4):
+            p = o.process(xs[c, B + b])[0]
+            assert (tail[c, b, :len(p)] == p).all(), (c, B + b)
