@@ -384,15 +384,16 @@ def main():
             rx.set_mode([api.AM, api.FM, api.WBFM, api.LSB][(4 * c) // C], channel=c)
     stream = torch.cuda.Stream(device=device)
     iq_root = None
-    if args.scatter and world > 1:
-        # the north star's "per-channel scatter": every rank's IQ starts on rank 0
-        iq_root = torch.cat([iq] * world, dim=0) if rank == 0 else None
+    scatter = args.scatter and world > 1
+    if scatter and rank == 0:
+        # the north star's "per-channel scatter": every rank's IQ starts on rank 0, in ONE source buffer built once
+        iq_root = torch.cat([gen(C, B, device, first_channel=r * C) for r in range(world)], dim=0).contiguous()
     rx.debug_enable_timing(max(args.steps, 1))
 
     def step():
-        if iq_root is not None or (args.scatter and world > 1):
+        if scatter:
             with torch.cuda.stream(stream):
-                iq.copy_(shard.scatter_iq(iq_root, world * C, B, BLOCK, device))
+                shard.scatter_iq(iq_root, iq, world * C)     # one group of sends out of rank 0, straight into `iq`
         rx.process_device(iq.data_ptr(), B * BLOCK, BLOCK, B, pcm.data_ptr(), d_n_pcm=n_pcm.data_ptr(),
                           stream=stream.cuda_stream)
 

@@ -1,9 +1,13 @@
 """Multi-GPU plumbing: channels are independent, so N GPUs = N
 contiguous channel shards, one process per GPU, per-channel state pinned to its
 GPU for the life of the stream.  There is no collective on the data path when the
-IQ is fed per GPU; when all IQ lands on rank 0 it is scattered once per batch
-(RCCL over xGMI: a one-to-all scatter uses the 7 point-to-point links out of rank 0
-concurrently) and the PCM (1 KiB per channel-block) is gathered back.
+IQ is fed per GPU.  When all IQ lands on rank 0 (the north star's "per-channel
+scatter") it leaves rank 0 as ONE group of point-to-point sends
+(`dist.batch_isend_irecv` = ncclGroupStart ... ncclGroupEnd under RCCL): the 7 direct
+xGMI links out of rank 0 carry their shards at the same time -- RCCL has no native
+scatter, and xGMI is point-to-point, so this is the whole collective -- straight
+into each rank's persistent input tensor, and the PCM (1 KiB per channel-block) is
+gathered back the same way.
 
 Works with backend "nccl" (= RCCL on ROCm, GPU tensors) and "gloo" (CPU tensors;
 used by the CPU tests of this plumbing)."""
@@ -22,51 +26,57 @@ def channel_range(rank: int, world: int, n_channels: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def scatter_iq(iq_all: Optional[torch.Tensor], n_channels: int, blocks: int, block_bytes: int,
-               device: torch.device, src: int = 0) -> torch.Tensor:
-    """Rank `src` holds int8 [n_channels, blocks, block_bytes]; every rank gets its shard."""
+def _run(ops):
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def scatter_iq(iq_all: Optional[torch.Tensor], mine: torch.Tensor, n_channels: int, src: int = 0) -> torch.Tensor:
+    """Rank `src` holds int8 [n_channels, blocks, block_bytes] (contiguous); every rank receives its shard INTO
+    `mine` ([hi - lo, blocks, block_bytes], contiguous, persistent: no allocation, no second copy per step).
+    Shards may differ by one channel, hence sends and receives rather than a padded collective."""
     rank, world = dist.get_rank(), dist.get_world_size()
     lo, hi = channel_range(rank, world, n_channels)
-    mine = torch.empty((hi - lo, blocks, block_bytes), dtype=torch.int8, device=device)
-    if world == 1:
-        mine.copy_(iq_all)
-        return mine
-    # shards may differ by one channel: point-to-point sends, all links busy at once
+    assert mine.shape[0] == hi - lo and mine.is_contiguous()
     if rank == src:
-        reqs = []
+        assert iq_all is not None and iq_all.is_contiguous()
+        ops = []
         for r in range(world):
             a, b = channel_range(r, world, n_channels)
             if r == src:
                 mine.copy_(iq_all[a:b])
             elif b > a:
-                reqs.append(dist.isend(iq_all[a:b].contiguous(), dst=r))
-        for q in reqs:
-            q.wait()
+                ops.append(dist.P2POp(dist.isend, iq_all[a:b], r))      # a slice of leading rows is contiguous
+        _run(ops)
     elif hi > lo:
-        dist.recv(mine, src=src)
+        _run([dist.P2POp(dist.irecv, mine, src)])
     return mine
 
 
-def gather_pcm(pcm_mine: torch.Tensor, n_channels: int, dst: int = 0) -> Optional[torch.Tensor]:
-    """Inverse of scatter_iq for the int16 [shard, blocks, n_pcm] output; rank dst gets all."""
+def gather_pcm(pcm_mine: torch.Tensor, out: Optional[torch.Tensor], n_channels: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """Inverse of scatter_iq for the int16 [shard, blocks, n_pcm] output: rank dst receives every shard into
+    `out` ([n_channels, blocks, n_pcm], persistent); the others pass out=None."""
     rank, world = dist.get_rank(), dist.get_world_size()
     if world == 1:
+        if out is not None:
+            out.copy_(pcm_mine)
+            return out
         return pcm_mine
-    out = None
     if rank == dst:
-        out = torch.empty((n_channels,) + tuple(pcm_mine.shape[1:]), dtype=pcm_mine.dtype, device=pcm_mine.device)
-        reqs = []
+        assert out is not None and out.is_contiguous()
+        ops = []
         for r in range(world):
             a, b = channel_range(r, world, n_channels)
             if r == dst:
                 out[a:b].copy_(pcm_mine)
             elif b > a:
-                reqs.append((dist.irecv(out[a:b], src=r)))
-        for q in reqs:
-            q.wait()
-    elif pcm_mine.shape[0] > 0:
-        dist.send(pcm_mine.contiguous(), dst=dst)
-    return out
+                ops.append(dist.P2POp(dist.irecv, out[a:b], r))
+        _run(ops)
+        return out
+    if pcm_mine.shape[0] > 0:
+        _run([dist.P2POp(dist.isend, pcm_mine.contiguous(), dst)])
+    return None
 
 
 def max_over_ranks(seconds: float, device: torch.device) -> float:

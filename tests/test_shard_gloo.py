@@ -1,15 +1,17 @@
-"""world_size-2 (and 3) gloo tests of the multi-GPU plumbing: channel sharding,
-the rank-0 scatter of IQ blocks, the PCM gather and the max-over-ranks timing.
-The compute in the middle is a stand-in checksum: the HIP path itself needs a GPU
-and is covered by the -m gpu tests."""
+"""world_size-2 (and 3) gloo tests of the multi-GPU path: channel sharding, the grouped scatter of IQ blocks out
+of rank 0 into every rank's persistent input tensor, the demodulation of each rank's shard, the PCM gather and
+the max-over-ranks timing.  The demodulator in the middle is the real chain -- the CPU oracle, since this container
+has no GPU (on a GPU box the ranks run libhrfd on their shards exactly where the oracle runs here; the -m gpu
+tests pin libhrfd to the oracle) -- and rank 0 checks the gathered PCM against a single-process oracle run."""
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from hackrfdiags_amd import shard
+from hackrfdiags_amd import shard, synth
 
 
 def test_channel_range_partitions_exactly():
@@ -22,25 +24,44 @@ def test_channel_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, n_channels, blocks, block_bytes, q):
+def _oracle_pcm(xs):
+    """[channels, blocks, bytes] int8 -> [channels, blocks, 512] int16, WBFM, one sequential oracle per channel"""
+    from tests.reflib import Oracle, WBFM
+    orc = Oracle()
+    out = np.zeros((xs.shape[0], xs.shape[1], 512), dtype=np.int16)
+    for c in range(xs.shape[0]):
+        o = orc.rx()
+        o.set_mode(WBFM)
+        for b in range(xs.shape[1]):
+            out[c, b] = o.process(xs[c, b])[0]
+    return out
+
+
+def _inputs(n_channels, blocks):
+    return np.stack([synth.make_input("fmtone" if c % 2 else "lcg", 700 + c, blocks).reshape(blocks, synth.BLOCK_BYTES)
+                     for c in range(n_channels)])
+
+
+def _worker(rank, world, port, n_channels, blocks, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
-    torch.manual_seed(0)
-    iq_all = None
-    ref = torch.randint(-128, 128, (n_channels, blocks, block_bytes), dtype=torch.int8)   # same on all ranks
-    if rank == 0:
-        iq_all = ref.clone()
-    mine = shard.scatter_iq(iq_all, n_channels, blocks, block_bytes, dev)
+    BLK = synth.BLOCK_BYTES
+    ref = _inputs(n_channels, blocks)                       # every rank can build it: rank 0 is the one that sends
     lo, hi = shard.channel_range(rank, world, n_channels)
-    ok = bool((mine == ref[lo:hi]).all())
-    # stand-in for the demodulator: 4 "PCM" values per channel-block derived from the shard
-    pcm = mine.to(torch.int16).reshape(hi - lo, blocks, 4, -1).sum(dim=3).to(torch.int16)
-    allpcm = shard.gather_pcm(pcm, n_channels)
+    mine = torch.zeros((hi - lo, blocks, BLK), dtype=torch.int8)     # persistent input tensor of this rank
+    iq_all = torch.from_numpy(ref).contiguous() if rank == 0 else None
+    allpcm = torch.zeros((n_channels, blocks, 512), dtype=torch.int16) if rank == 0 else None
+    ok = True
+    for step in range(2):                                   # twice through the same buffers: nothing is reallocated
+        ptr = mine.data_ptr()
+        shard.scatter_iq(iq_all, mine, n_channels)
+        ok = ok and mine.data_ptr() == ptr and bool((mine.numpy() == ref[lo:hi]).all())
+        pcm = torch.from_numpy(_oracle_pcm(mine.numpy()))    # the rank's demodulator on its shard
+        shard.gather_pcm(pcm, allpcm, n_channels)
     if rank == 0:
-        want = ref.to(torch.int16).reshape(n_channels, blocks, 4, -1).sum(dim=3).to(torch.int16)
-        ok = ok and bool((allpcm == want).all())
+        ok = ok and bool((allpcm.numpy() == _oracle_pcm(ref)).all())
     t = shard.max_over_ranks(0.25 * (rank + 1), dev)
     ok = ok and abs(t - 0.25 * world) < 1e-9
     dist.barrier()
@@ -48,16 +69,16 @@ def _worker(rank, world, port, n_channels, blocks, block_bytes, q):
     q.put((rank, ok))
 
 
-@pytest.mark.parametrize("world,n_channels", [(2, 8), (2, 5), (3, 7)])
-def test_scatter_process_gather_gloo(world, n_channels):
+@pytest.mark.parametrize("world,n_channels", [(2, 4), (2, 5), (3, 7)])
+def test_scatter_demodulate_gather_gloo(world, n_channels):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000 + world * 7 + n_channels
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_channels, 2, 4096, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_channels, 2, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(world))
     assert all(results[r] for r in range(world)), results
