@@ -53,9 +53,15 @@
 #ifdef HRFD_FLOW_PROBE
 #define FLOW_MARK(i) { const unsigned long long tm_ = __builtin_readcyclecounter(); probe[i] += tm_ - tprev; tprev = tm_; }
 #define SVC_MARK(i) { const unsigned long long tm_ = __builtin_readcyclecounter(); sprobe[i] += tm_ - sprev; sprev = tm_; }
+// timeline of the workgroup on the 100 MHz constant clock (slots 42..46: entry, tables loaded, last stream wave through,
+// last service wave through, last wave at the end); the values of the last launch win
+#define FLOW_TIME_SET(i) { if (P.dbg != nullptr && tid == 0) P.dbg[(size_t)blockIdx.x * kDbgSlots + (i)] = __builtin_amdgcn_s_memrealtime(); }
+#define FLOW_TIME_MAX(i) { if (P.dbg != nullptr && lane == 0) atomicMax(&P.dbg[(size_t)blockIdx.x * kDbgSlots + (i)], (unsigned long long)__builtin_amdgcn_s_memrealtime()); }
 #else
 #define FLOW_MARK(i)
 #define SVC_MARK(i)
+#define FLOW_TIME_SET(i)
+#define FLOW_TIME_MAX(i)
 #endif
 
 namespace hrfd {
@@ -217,6 +223,8 @@ __device__ __forceinline__ void flow_tile_u(const uint32_t *tp, float y, FlowTil
   o.y = y;
 }
 
+constexpr int kFinWords = 168;
+
 template <int SVC>
 __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
 {
@@ -240,7 +248,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   __shared__ uint32_t blkout[64];          // per block of the run: mean magnitude | present << 31 (written out at the end:
                                            // a global store inside the unit loop costs the loop its counted vmcnt waits)
   __shared__ uint32_t wfin[4];             // the last finished generation's last lane: y, its last two S pairs
-  static_assert(sizeof(uint32_t) * (kFRingTiles * kFStride + kFUDw + kFVDw + 5 * kFEdges + kFPRing + 1024 + 48) + 5 * kCorrBytes <= 163840, "LDS");
+  __shared__ uint32_t finl[kFinWords];     // a channel that is ONE workgroup's is finished from here (no memory round trip behind
+                                           // the last sample): 0..63 y in front of block b, 128..159 the pending WBFM state
+                                           // section, 160 tracking, 161 poison, 162..165 the pending fe_tail
+  static_assert(sizeof(uint32_t) * (kFRingTiles * kFStride + kFUDw + kFVDw + 5 * kFEdges + kFPRing + 1024 + 48 + kFinWords) + 5 * kCorrBytes <= 163840, "LDS");
 
   uint32_t ci, run;
   if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
@@ -255,6 +266,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool first = (b_first == 0);                     // the stream continues from the carried state: exact start
+  const bool local = P.self_finish != 0 && P.n_runs == 1u && P.n_blocks <= 64u;   // the channel is this workgroup's alone
   const int hal = first ? 0 : P.flow_hal;                // history re-derived in front of the run (samples)
   const int L = hal + (int)(b_end - b_first) * n256;     // samples of the stream
   const int n_units = L >> 9, n_tiles = L >> 6, n_gens = (n_tiles + 63) >> 6;
@@ -269,6 +281,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   const unsigned long long t_kernel = __builtin_readcyclecounter();
   unsigned long long waited = 0;
   uint32_t fail_code = 0;                                // which wait expired, if any (diagnostics)
+  FLOW_TIME_SET(42)
 
   // tables and control words
   magl[0][tid] = 0u;
@@ -307,6 +320,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   {
     uring[kFUDw - 4 + (tid - 896)] = reinterpret_cast<const uint32_t *>(st->wb_u)[tid - 896];     // U[-8 .. -1]
   }
+  else if (tid == 904 && local)
+  {
+    finl[160] = st->tracking;
+    finl[161] = P.fin.chan_poison[c];
+  }
+  else if (tid >= 908 && tid < 912 && b_end == P.n_blocks)
+  {
+    // front-end carry for the next call: the last 16 raw bytes of the channel's input (pending, like the rest of state_out)
+    const int8_t *endp = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)P.n_blocks * P.block_bytes;
+    const uint32_t w = reinterpret_cast<const uint32_t *>(endp - 16)[tid - 908];
+    reinterpret_cast<uint32_t *>(so->fe_tail)[tid - 908] = w;
+    finl[162 + (tid - 908)] = w;
+  }
   else if (tid >= 960 && tid < 979 && first)
   {
     vring[kFVDw - 19 + (tid - 960)] = reinterpret_cast<const uint32_t *>(st->wb_v)[tid - 960];    // V[-38 .. -1]
@@ -317,6 +343,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     dbfs8[tid] = (int8_t)P.dbfs[tid];
   }
   __syncthreads();                                       // the only workgroup barriers of the kernel
+  FLOW_TIME_SET(43)
 
   if (wave >= SVC)
   {
@@ -590,6 +617,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
                  :
                  : "memory");
     finish_block();
+    FLOW_TIME_MAX(44)
     if (wave == SVC)
     {
       // every stream wave is through its units by now or about to be: wait for the last blocks, then the
@@ -618,12 +646,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       }
     }
 #endif
-    if (b_end == P.n_blocks && wave == SVC && lane < 4)
-    {
-      // front-end carry for the next call: the last 16 raw bytes of the channel's input
-      const int8_t *endp = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)P.n_blocks * P.block_bytes;
-      reinterpret_cast<uint32_t *>(so->fe_tail)[lane] = reinterpret_cast<const uint32_t *>(endp - 16)[lane];
-    }
   }
   else
   {
@@ -923,6 +945,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
               if (b < b_end)
               {
                 P.chk_spec[(size_t)c * P.n_blocks + b] = o.y;
+                if (local)
+                {
+                  lds_st(&finl[b & 63u], f2u(o.y));
+                }
               }
             }
           }
@@ -950,6 +976,29 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
           {
             reinterpret_cast<uint32_t *>(so->wb_v)[lane] = vring[(2 * n_tiles - 19 + lane) & (kFVDw - 1)];
           }
+          if (local)
+          {
+            // the same section in ChanState's order, dwords from wb_theta on: theta, p, y, pad, s (2), u (4), v (20)
+            static_assert(offsetof(ChanState, wb_s) - offsetof(ChanState, wb_theta) == 16 && offsetof(ChanState, wb_u) - offsetof(ChanState, wb_theta) == 24 &&
+                          offsetof(ChanState, wb_v) - offsetof(ChanState, wb_theta) == 40 && offsetof(ChanState, fm_tail) - offsetof(ChanState, wb_theta) == 120, "finl");
+            if (lane == 0)
+            {
+              lds_st(&finl[128], el[3]);
+              lds_st(&finl[129], f2u(numerator_p(u2f(el[3]), u2f(el[2]), kgain)));
+              lds_st(&finl[130], fy);
+              lds_st(&finl[131], 0u);
+              lds_st(&finl[132], fs0);
+              lds_st(&finl[133], fs1);
+            }
+            if (lane < 4)
+            {
+              lds_st(&finl[134 + lane], uring[(8 * n_tiles - 4 + lane) & (kFUDw - 1)]);
+            }
+            if (lane < 20)
+            {
+              lds_st(&finl[138 + lane], lane < 19 ? vring[(2 * n_tiles - 19 + lane) & (kFVDw - 1)] : 0u);
+            }
+          }
         }
         asm volatile("" ::: "memory");
         if (lane == 0)
@@ -959,6 +1008,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       }
       SVC_MARK(9)
     }
+    FLOW_TIME_MAX(45)
 #ifdef HRFD_FLOW_PROBE
     if (P.dbg != nullptr && lane == 0)
     {
@@ -977,7 +1027,40 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   // The last wave of the last workgroup of a channel finishes the channel (finish_channel: squelch tracker, checks
   // of both speculations, n_pcm / allowed outputs, commit of the pending state): no kernel behind this one.
   // Release / acquire at agent scope around the two counters (MI355X_MICROARCH, "Workgroup dispatch ... visibility").
-  if (P.self_finish)
+  if (local)
+  {
+    // the channel was this workgroup's alone: every input of the verdict is in LDS, nothing is read back from memory
+    // (no wait for this wave's stores either: the end of the kernel is their fence)
+    if (fail_code != 0u && lane == 0)
+    {
+      lds_st(&ctl[6], 1u);
+    }
+    uint32_t prev = 0;
+    if (lane == 0)
+    {
+      prev = atomicAdd(&ctl[5], 1u);
+    }
+    if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
+    {
+      lds_order();
+      const uint32_t nb = P.n_blocks;
+      FinishIn<3> I;
+      I.mode = 3;
+      I.tracking = lds_ld(&finl[160]);
+      I.poison = lds_ld(&finl[161]);
+      I.expired = lds_ld(&ctl[6]);
+      I.pres0 = ((uint32_t)lane < nb) ? (lds_ld(&blkout[lane]) >> 31) : 0u;
+      I.pl_raw = lds_ld(&blkout[(nb - 1u) & 63u]) >> 31;
+      I.pp_raw = lds_ld(&blkout[(nb - 2u) & 63u]) >> 31;  // n_blocks >= 2 here
+      // one run: the value published in front of a block IS the one the block started from (a NaN fails, as ever)
+      I.spec0 = (lane > 0 && (uint32_t)lane < nb) ? u2f(lds_ld(&finl[lane])) : 0.0f;
+      I.pub0 = I.spec0;
+      I.fe = (lane < 4) ? lds_ld(&finl[162 + lane]) : 0u;
+      I.sec[0] = (lane < 30) ? lds_ld(&finl[128 + lane]) : 0u;
+      finish_apply<3>(P.fin, c, lane, I);
+    }
+  }
+  else if (P.self_finish)
   {
     if (fail_code != 0u && lane == 0)
     {
@@ -1019,10 +1102,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       }
       if (last)
       {
-        finish_channel(P.fin, c, lane);
+        finish_channel<3>(P.fin, c, lane);
       }
     }
   }
+  FLOW_TIME_MAX(46)
   if (P.dbg != nullptr && lane == 0)
   {
     // per wave: cycles spent waiting (ring full / units not there yet / generation order); slot 0: the workgroup's cycles

@@ -2509,21 +2509,118 @@ template __global__ void k_rx_wbfm_stream<true>(const RxParams);
 //  Called from k_rx_finish (one workgroup per channel) and from the tail of k_rx_wbfm_flow (the
 //  last workgroup of a channel finishes it).
 // =============================================================================
-__device__ __forceinline__ void finish_channel(const EpilogueParams &E, const uint32_t c, const int lane)
+// Shaped for latency: one wave runs this while nothing else of the channel does (in k_rx_wbfm_flow the rest of the CU idles
+// behind it), so every input is requested before the first is used -- one memory round trip for everything that
+// depends on the channel number alone (two when the mode has to be read first), the pending state included, read
+// before the verdict is known -- and the stores come last (finish_gather, finish_apply).  k_rx_wbfm_flow hands the
+// inputs over from its own LDS when the channel was one workgroup's: no round trip at all (a load takes microseconds
+// while the other CUs still saturate the memory system).  MODE >= 0: the caller knows the channel's mode.
+template <int MODE>
+struct FinishIn
 {
-  const int mode = E.cfg[c].mode;
+  static constexpr int kSecDw = (MODE == 3) ? 1 : 6;
+  int mode;
+  uint32_t tracking, poison, expired;
+  uint32_t pl_raw, pp_raw;      // `present` of the last block and of the one before
+  uint32_t pres0;               // lane b: `present` of block b (the first 64 blocks)
+  float spec0, pub0;            // lane b: the check values around the start of block b
+  uint32_t fe;                  // lanes 0..3: the pending fe_tail
+  uint32_t sec[kSecDw];         // the mode's section of the pending state, dword lane + 64 k
+};
+
+// byte offset and dwords of a mode's section of ChanState (contiguous, 4-byte aligned)
+__device__ __forceinline__ void state_section(const int mode, int &off, int &nd)
+{
+  static_assert(offsetof(ChanState, wb_theta) % 4 == 0 && offsetof(ChanState, fm_tail) % 4 == 0 && offsetof(ChanState, am_tail) % 4 == 0 &&
+                offsetof(ChanState, ssb_tail) % 4 == 0 && sizeof(ChanState) % 4 == 0, "state sections are copied as dwords");
+  static_assert((offsetof(ChanState, fm_tail) - offsetof(ChanState, wb_theta)) / 4 <= 64 &&
+                (offsetof(ChanState, am_tail) - offsetof(ChanState, fm_tail)) / 4 <= 6 * 64 &&
+                (offsetof(ChanState, ssb_tail) - offsetof(ChanState, am_tail)) / 4 <= 6 * 64 &&
+                (sizeof(ChanState) - offsetof(ChanState, ssb_tail)) / 4 <= 6 * 64, "section sizes");
+  off = 0;
+  nd = 0;
+  if (mode == 3) { off = (int)offsetof(ChanState, wb_theta); nd = ((int)offsetof(ChanState, fm_tail) - off) / 4; }
+  else if (mode == 2) { off = (int)offsetof(ChanState, fm_tail); nd = ((int)offsetof(ChanState, am_tail) - off) / 4; }
+  else if (mode == 1) { off = (int)offsetof(ChanState, am_tail); nd = ((int)offsetof(ChanState, ssb_tail) - off) / 4; }
+  else if (mode == 4 || mode == 5) { off = (int)offsetof(ChanState, ssb_tail); nd = ((int)sizeof(ChanState) - off) / 4; }
+}
+
+template <int MODE>
+__device__ __forceinline__ void finish_gather(const EpilogueParams &E, const uint32_t c, const int lane, FinishIn<MODE> &I)
+{
+  const ChanState *dst = E.state + c;
+  const ChanState *src = E.state_out + c;
+  const uint32_t nb = E.n_blocks;
+  const uint8_t *pres = E.present + (size_t)c * nb;
+  // ---- round trip 1
+  I.mode = MODE;
+  if (MODE < 0)
+  {
+    I.mode = E.cfg[c].mode;
+  }
+  I.tracking = dst->tracking;
+  I.poison = E.chan_poison[c];
+  I.expired = E.chan_expired[c];
+  I.pl_raw = pres[nb - 1];
+  I.pp_raw = pres[nb >= 2 ? nb - 2 : 0];
+  const bool in0 = (uint32_t)lane < nb;
+  I.pres0 = in0 ? (uint32_t)pres[lane] : 0u;
+  I.spec0 = 0.0f;
+  I.pub0 = 0.0f;
+  if (in0 && lane > 0 && (MODE < 0 || MODE == 3))
+  {
+    I.spec0 = E.chk_spec[(size_t)c * nb + lane];
+    I.pub0 = E.chk_pub[(size_t)c * nb + lane - 1];
+  }
+  I.fe = (lane < 4) ? reinterpret_cast<const uint32_t *>(src->fe_tail)[lane] : 0u;
+  // ---- round trip 2 (the same one when the mode is known): the mode's section of the pending state
+  int off, nd;
+  state_section(I.mode, off, nd);
+  const uint32_t *ssec = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(src) + off);
+#pragma unroll
+  for (int k = 0; k < FinishIn<MODE>::kSecDw; k++)
+  {
+    I.sec[k] = (lane + 64 * k < nd) ? ssec[lane + 64 * k] : 0u;
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void finish_apply(const EpilogueParams &E, const uint32_t c, const int lane, const FinishIn<MODE> &I)
+{
   ChanState *dst = E.state + c;
-  uint32_t carry = dst->tracking != 0 ? 1u : 0u;          // `present` of the block before
+  const uint32_t nb = E.n_blocks;
+  const uint8_t *pres = E.present + (size_t)c * nb;
+  const int mode = I.mode;
+  const uint32_t tracking = I.tracking, poison = I.poison, expired = I.expired, pl_raw = I.pl_raw, pp_raw = I.pp_raw;
+  const uint32_t pres0 = I.pres0, fe = I.fe;
+  const float spec0 = I.spec0, pub0 = I.pub0;
+  constexpr int kSecDw = FinishIn<MODE>::kSecDw;
+  int off, nd;
+  state_section(mode, off, nd);
+  uint32_t *dsec = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(dst) + off);
+
+  // ---- the verdict: squelch tracker over the batch (Squelch.cc:227-273, SignalTracker.cc:104-146), both speculations
+  uint32_t carry = tracking != 0 ? 1u : 0u;               // `present` of the block before
   uint32_t gate_viol = 0, spec_viol = 0;
-  for (uint32_t b0 = 0; b0 < E.n_blocks; b0 += 64)
+  for (uint32_t b0 = 0; b0 < nb; b0 += 64)
   {
     const uint32_t b = b0 + lane;
-    const bool in = b < E.n_blocks;
-    const size_t unit = (size_t)c * E.n_blocks + b;
+    const bool in = b < nb;
+    const size_t unit = (size_t)c * nb + b;
     const size_t ounit = (size_t)c * E.out_blocks + E.out_b0 + b;
-    const uint32_t present = in ? (uint32_t)(E.present[unit] != 0) : 0u;
+    uint32_t present = pres0 != 0u ? 1u : 0u;
+    float spec = spec0, pub = pub0;
+    if (b0 != 0)                                          // more than 64 blocks: rare, not shaped
+    {
+      present = in ? (uint32_t)(pres[b] != 0) : 0u;
+      if (in && mode == 3)
+      {
+        spec = E.chk_spec[unit];
+        pub = E.chk_pub[unit - 1];
+      }
+    }
     const uint32_t prev = shr1(present, carry);           // lane 0 <- carried
-    const bool allowed = (present | prev) != 0;           // Squelch.cc:227-273, SignalTracker.cc:104-146
+    const bool allowed = (present | prev) != 0;
     if (in)
     {
       const bool demod = allowed && mode != 0;
@@ -2536,29 +2633,32 @@ __device__ __forceinline__ void finish_channel(const EpilogueParams &E, const ui
         E.n_pcm[ounit] = demod ? E.n_pcm_per_block : 0u;
       }
       // the batch assumed every gate open
-      gate_viol += (E.n_blocks > 1 && mode != 0 && !allowed) ? 1u : 0u;
+      gate_viol += (nb > 1 && mode != 0 && !allowed) ? 1u : 0u;
       if (b > 0 && mode == 3)
       {
-        spec_viol += same_trajectory(E.chk_spec[unit], E.chk_pub[unit - 1]) ? 0u : 1u;
+        spec_viol += same_trajectory(spec, pub) ? 0u : 1u;
       }
     }
     carry = (uint32_t)__builtin_amdgcn_readlane((int)present, 63);
   }
-  for (int off = 32; off > 0; off >>= 1)
+  for (int o = 32; o > 0; o >>= 1)
   {
-    gate_viol += __shfl_down(gate_viol, off);
-    spec_viol += __shfl_down(spec_viol, off);
+    gate_viol += __shfl_down(gate_viol, o);
+    spec_viol += __shfl_down(spec_viol, o);
   }
   gate_viol = (uint32_t)__builtin_amdgcn_readfirstlane((int)gate_viol);
   spec_viol = (uint32_t)__builtin_amdgcn_readfirstlane((int)spec_viol);
   // a launch behind an unrepaired failed one started this channel from a stale state: it must not commit
   const uint32_t bits = (gate_viol ? kFailGate : 0u) | (spec_viol ? kFailSpec : 0u) |
-                        (E.chan_poison[c] != 0u ? kFailPoison : 0u) | (E.chan_expired[c] != 0u ? kFailExpired : 0u);
+                        (poison != 0u ? kFailPoison : 0u) | (expired != 0u ? kFailExpired : 0u);
   const bool clean = bits == 0u;
   if (lane == 0)
   {
     E.chan_fail[c] = bits;
-    E.chan_expired[c] = 0u;
+    if (expired != 0u)
+    {
+      E.chan_expired[c] = 0u;
+    }
     if (!clean)
     {
       E.chan_poison[c] = 1u;
@@ -2586,49 +2686,36 @@ __device__ __forceinline__ void finish_channel(const EpilogueParams &E, const ui
   {
     return;
   }
-  const ChanState *src = E.state_out + c;
-  // tracker over the batch; was the last block demodulated?
-  const uint32_t nb = E.n_blocks;
-  const bool p_last = E.present[(size_t)c * nb + nb - 1] != 0;
-  const bool p_prev = (nb >= 2) ? (E.present[(size_t)c * nb + nb - 2] != 0) : (dst->tracking != 0);
-  const bool allowed = p_last || p_prev;
-  auto copy = [&](void *d, const void *s, int bytes) {    // sections are 2-byte aligned
-    uint16_t *dd = reinterpret_cast<uint16_t *>(d);
-    const uint16_t *ss = reinterpret_cast<const uint16_t *>(s);
-    for (int i = lane; i < bytes / 2; i += 64)
-    {
-      dd[i] = ss[i];
-    }
-  };
-  copy(dst->fe_tail, src->fe_tail, 16);
-  if (allowed)                                            // else: demodulator state frozen
+  // ---- commit: was the last block demodulated?  (else: demodulator state frozen)
+  const bool p_last = pl_raw != 0u;
+  const bool p_prev = (nb >= 2) ? (pp_raw != 0u) : (tracking != 0u);
+  if (lane < 4)
   {
-    if (mode == 3)
+    reinterpret_cast<uint32_t *>(dst->fe_tail)[lane] = fe;
+  }
+  if (p_last || p_prev)
+  {
+#pragma unroll
+    for (int k = 0; k < kSecDw; k++)
     {
-      copy(&dst->wb_theta, &src->wb_theta, 3 * (int)sizeof(float));
-      copy(dst->wb_s, src->wb_s, (int)(sizeof(dst->wb_s) + sizeof(dst->wb_u) + sizeof(dst->wb_v)));
-    }
-    else if (mode == 2)
-    {
-      copy(dst->fm_tail, src->fm_tail, (int)(sizeof(dst->fm_tail) + sizeof(dst->fm_u) + sizeof(dst->fm_v)));
-    }
-    else if (mode == 1)
-    {
-      copy(dst->am_tail, src->am_tail, (int)sizeof(dst->am_tail));
-      copy(&dst->am_x1, &src->am_x1, 2 * (int)sizeof(float));
-    }
-    else if (mode == 4 || mode == 5)
-    {
-      copy(dst->ssb_tail, src->ssb_tail, (int)sizeof(dst->ssb_tail));
-      copy(&dst->ssb_x1, &src->ssb_x1, 2 * (int)sizeof(float));
-      copy(dst->ssb_i, src->ssb_i, (int)(sizeof(dst->ssb_i) + sizeof(dst->ssb_q)));
+      if (lane + 64 * k < nd)
+      {
+        dsec[lane + 64 * k] = I.sec[k];
+      }
     }
   }
-  __builtin_amdgcn_s_waitcnt(0);                          // all lanes read `tracking` above
   if (lane == 0)
   {
     dst->tracking = p_last ? 1u : 0u;
   }
+}
+
+template <int MODE = -1>
+__device__ __forceinline__ void finish_channel(const EpilogueParams &E, const uint32_t c, const int lane)
+{
+  FinishIn<MODE> I;
+  finish_gather<MODE>(E, c, lane, I);
+  finish_apply<MODE>(E, c, lane, I);
 }
 
 // the channels that no kernel finishes by itself: one wave per channel of E.chan_list (or 0 .. n_channels - 1)
@@ -2639,7 +2726,7 @@ __global__ __launch_bounds__(64) void k_rx_finish(const EpilogueParams E)
     return;
   }
   const uint32_t c = (E.chan_list != nullptr) ? E.chan_list[blockIdx.x] : blockIdx.x;
-  finish_channel(E, c, (int)threadIdx.x);
+  finish_channel<>(E, c, (int)threadIdx.x);
 }
 
 // explicit instantiations used by the host side

@@ -13,7 +13,7 @@ x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev)
 pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
 torch.cuda.synchronize()
 rx = api.Rx(C); rx.set_mode(api.WBFM)
-grid = 8 * ((C + 7) // 8)
+grid = max(256, 8 * ((C + 7) // 8))
 for _ in range(100):
     rx.process_device(x.data_ptr(), B * BLK, BLK, B, pcm.data_ptr())
 rx.sync()
@@ -41,3 +41,14 @@ if sp.sum() > 0:
     print("service probe, cycles per service wave per launch (16 generations each):")
     print("   " + " | ".join(f"{n} {v:.0f}" for n, v in zip(names, (sp / N / 4).tolist())))
     print("   sum %.0f" % (sp.sum() / N / 4))
+tl = st[:, 42:47]
+if tl[:, 0].min() > 0:
+    t0 = tl[:, 0].min()
+    us = (tl - t0) / 100.0
+    print("timeline of the LAST launch, us from the first workgroup's entry (100 MHz clock), over %d workgroups:" % len(tl))
+    for i, n in enumerate(["entry", "tables loaded", "stream waves through", "service waves through", "last wave at the end"]):
+        print("   %-24s min %7.2f  mean %7.2f  max %7.2f" % (n, us[:, i].min(), us[:, i].mean(), us[:, i].max()))
+    print("   span first entry -> last end %.2f us; the events say %.2f us" % (us[:, 4].max(), 1e3 * ms[-1]))
+    d = us[:, 4] - us[:, 0]
+    print("   workgroup lifetime: min %.2f mean %.2f max %.2f us;  service tail behind the stream: mean %.2f max %.2f us"
+          % (d.min(), d.mean(), d.max(), (us[:, 3] - us[:, 2]).mean(), (us[:, 3] - us[:, 2]).max()))
