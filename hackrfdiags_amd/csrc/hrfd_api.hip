@@ -193,6 +193,7 @@ struct hrfd_rx
   std::vector<hipEvent_t> ev;           // 2 events per slot; slot = launch index % slots
   hipStream_t side = nullptr;           // the 8 kS/s AM / SSB recurrences run beside the next mode's kernel
   hipEvent_t ev_fir[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
+  hipEvent_t ev_rest = nullptr, ev_fin = nullptr;   // mixed bank: the other modes' kernels are all submitted / their channels finished
   uint32_t ev_launches = 0;
 
   // test hooks
@@ -230,6 +231,8 @@ static int rx_free(hrfd_rx *h)
     if (h->ev_fir[i]) (void)hipEventDestroy(h->ev_fir[i]);
     if (h->ev_post[i]) (void)hipEventDestroy(h->ev_post[i]);
   }
+  if (h->ev_rest) (void)hipEventDestroy(h->ev_rest);
+  if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -282,6 +285,8 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   };
   bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; i < 2 && ok; i++)
   {
     ok = hipEventCreateWithFlags(&h->ev_fir[i], hipEventDisableTiming) == hipSuccess &&
@@ -1045,6 +1050,20 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       }
       else if (flow)
       {
+        if (opt.subset == nullptr && list_count[6] != 0)
+        {
+          // A bank of several modes: k_rx_wbfm_flow finishes its own channels; the others' finisher goes to the side
+          // stream behind everything submitted so far (the AM / SSB recurrences are there already) and runs in the
+          // shadow of this kernel instead of behind it.
+          HIP_TRY(hipEventRecord(h->ev_rest, s));
+          HIP_TRY(hipStreamWaitEvent(h->side, h->ev_rest, 0));
+          EpilogueParams F = E;
+          F.chan_list = d_lists + (size_t)6 * h->n_channels;
+          F.n_channels = list_count[6];
+          hipLaunchKernelGGL(k_rx_finish, dim3(F.n_channels), dim3(64), 0, h->side, F);
+          HIP_TRY(hipEventRecord(h->ev_fin, h->side));
+          n_side = 4;                                      // the side stream is in order: this event covers the others
+        }
         P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here
         P.self_finish = 1;                                 // the last workgroup of a channel finishes it (finish_channel)
         flow_ran = true;
@@ -1080,6 +1099,10 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       HIP_TRY(hipStreamWaitEvent(s, h->ev_post[i], 0));
     }
   }
+  if (n_side & 4)
+  {
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_fin, 0));
+  }
   if (ev_slots)
   {
     HIP_TRY(hipEventRecord(h->ev[2 * ev_slot + 1], s));
@@ -1093,7 +1116,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     if (flow_ran)
     {
       F.chan_list = d_lists + (size_t)6 * h->n_channels;
-      F.n_channels = (opt.subset != nullptr) ? 0u : list_count[6];
+      F.n_channels = 0u;                                   // (the whole bank's list 6 was finished on the side stream)
       if (opt.subset != nullptr)
       {
         // the subset's list 6 holds all its channels: finish those that are not WBFM through their mode lists
