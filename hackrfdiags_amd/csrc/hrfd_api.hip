@@ -161,8 +161,9 @@ struct hrfd_rx
   uint32_t *d_counters = nullptr;       // [kNumDevCounters] + a second set of the per-launch counters [kCntSticky]
   uint32_t *d_local = nullptr;          // the per-launch counters of the latest launch (set 0 = d_counters, set 1 behind it)
   int parity = 0;
-  uint32_t *d_lists = nullptr;         // [7][n_channels] channel ids grouped by mode; list 6: every channel that is not WBFM
-  uint32_t list_count[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t *d_lists = nullptr;         // [8][n_channels] channel ids grouped by mode; list 6: every channel that is not WBFM,
+                                       // list 7: the AM and SSB channels
+  uint32_t list_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t *d_sub_lists = nullptr;     // the same for a launch over a subset of the channels (replay of failed channels);
                                        // list 6 there: the subset itself
   uint32_t *d_chan = nullptr;          // [4][n_channels]: chan_fail, chan_poison, chan_expired, chan_arrived (EpilogueParams)
@@ -302,8 +303,8 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && alloc((void **)&h->d_att0, sizeof(float) * kCorrBytes);
   ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
   ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * (kNumDevCounters + kCntSticky));
-  ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 7 * n_channels);
-  ok = ok && alloc((void **)&h->d_sub_lists, sizeof(uint32_t) * 7 * n_channels);
+  ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 8 * n_channels);
+  ok = ok && alloc((void **)&h->d_sub_lists, sizeof(uint32_t) * 8 * n_channels);
   ok = ok && alloc((void **)&h->d_chan, sizeof(uint32_t) * 4 * n_channels);
   if (!ok)
   {
@@ -778,15 +779,15 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   }
 
   // configuration snapshot
-  uint32_t sub_count[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t sub_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<std::pair<uint32_t, int>> resets;
   {
     std::lock_guard<std::mutex> g(h->mu);
     resets.swap(h->pending_resets);
     if (h->cfg_dirty)
     {
-      std::vector<uint32_t> lists((size_t)7 * h->n_channels);
-      uint32_t cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+      std::vector<uint32_t> lists((size_t)8 * h->n_channels);
+      uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (uint32_t c = 0; c < h->n_channels; c++)
       {
         const int m = h->h_cfg[c].mode;
@@ -794,6 +795,10 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
         if (m != HRFD_MODE_WBFM)
         {
           lists[(size_t)6 * h->n_channels + cnt[6]++] = c;
+        }
+        if (m == HRFD_MODE_AM || m == HRFD_MODE_LSB || m == HRFD_MODE_USB)
+        {
+          lists[(size_t)7 * h->n_channels + cnt[7]++] = c;
         }
       }
       memcpy(h->list_count, cnt, sizeof(cnt));
@@ -806,12 +811,16 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     if (opt.subset != nullptr)
     {
       // per-mode lists of the subset (list 6: the subset itself)
-      std::vector<uint32_t> lists((size_t)7 * h->n_channels);
+      std::vector<uint32_t> lists((size_t)8 * h->n_channels);
       for (uint32_t c : *opt.subset)
       {
         const int m = h->h_cfg[c].mode;
         lists[(size_t)m * h->n_channels + sub_count[m]++] = c;
         lists[(size_t)6 * h->n_channels + sub_count[6]++] = c;
+        if (m == HRFD_MODE_AM || m == HRFD_MODE_LSB || m == HRFD_MODE_USB)
+        {
+          lists[(size_t)7 * h->n_channels + sub_count[7]++] = c;
+        }
       }
       HIP_TRY(hipStreamSynchronize(s));
       HIP_TRY(hipMemcpy(h->d_sub_lists, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice));
@@ -945,63 +954,46 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   // the next mode's; the launch stream joins them before the epilogue.
   P.dbg = nullptr;
   int n_side = 0;
-  for (int m : {HRFD_MODE_AM, HRFD_MODE_LSB, HRFD_MODE_USB, HRFD_MODE_FM})
+  // AM and SSB: one launch for both kinds (k_rx_fir<14>: the same three decimators), their 8 kS/s recurrences likewise
+  // (k_rx_post<14>, one workgroup per channel)
+  if (list_count[7] != 0)
   {
-    const uint32_t n = list_count[m];
-    if (n == 0)
-    {
-      continue;
-    }
-    P.chan_list = d_lists + (size_t)m * h->n_channels;
+    const uint32_t n = list_count[7];
+    P.chan_list = d_lists + (size_t)7 * h->n_channels;
     P.n_list = n;
     const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
-    if (m == HRFD_MODE_FM)
+    if (opt.src256)
     {
-      if (opt.src256)
-      {
-        hipLaunchKernelGGL((k_rx_fir<2, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      else if (h->arith_ok && h->atan_mode != 0)
-      {
-        hipLaunchKernelGGL((k_rx_fir<2, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      else
-      {
-        hipLaunchKernelGGL((k_rx_fir<2, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-    }
-    else if (m == HRFD_MODE_AM)
-    {
-      if (opt.src256)
-      {
-        hipLaunchKernelGGL((k_rx_fir<1, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      else
-      {
-        hipLaunchKernelGGL((k_rx_fir<1, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      HIP_TRY(hipEventRecord(h->ev_fir[0], s));
-      HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fir[0], 0));
-      hipLaunchKernelGGL(k_rx_post<1>, dim3(n), dim3(256), 0, h->side, P);
-      HIP_TRY(hipEventRecord(h->ev_post[0], h->side));
-      n_side |= 1;
+      hipLaunchKernelGGL((k_rx_fir<14, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     else
     {
-      if (opt.src256)
-      {
-        hipLaunchKernelGGL((k_rx_fir<4, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      else
-      {
-        hipLaunchKernelGGL((k_rx_fir<4, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      // (LSB and USB channels are two lists: the side stream keeps their post kernels in order)
-      HIP_TRY(hipEventRecord(h->ev_fir[1], s));
-      HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fir[1], 0));
-      hipLaunchKernelGGL(k_rx_post<4>, dim3(n), dim3(256), 0, h->side, P);
-      HIP_TRY(hipEventRecord(h->ev_post[1], h->side));
-      n_side |= 2;
+      hipLaunchKernelGGL((k_rx_fir<14, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    HIP_TRY(hipEventRecord(h->ev_fir[0], s));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fir[0], 0));
+    hipLaunchKernelGGL(k_rx_post<14>, dim3(n), dim3(256), 0, h->side, P);
+    HIP_TRY(hipEventRecord(h->ev_post[0], h->side));
+    n_side |= 1;
+    HIP_TRY(hipGetLastError());
+  }
+  if (list_count[HRFD_MODE_FM] != 0)
+  {
+    const uint32_t n = list_count[HRFD_MODE_FM];
+    P.chan_list = d_lists + (size_t)HRFD_MODE_FM * h->n_channels;
+    P.n_list = n;
+    const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+    if (opt.src256)
+    {
+      hipLaunchKernelGGL((k_rx_fir<2, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    else if (h->arith_ok && h->atan_mode != 0)
+    {
+      hipLaunchKernelGGL((k_rx_fir<2, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    else
+    {
+      hipLaunchKernelGGL((k_rx_fir<2, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     HIP_TRY(hipGetLastError());
   }

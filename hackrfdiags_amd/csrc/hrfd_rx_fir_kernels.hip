@@ -83,6 +83,10 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
   const bool first = (b == 0);
   const ChanState *st = P.state + c;
   const ChanCfg cfg = P.cfg[c];
+  // MODE 14: AM and SSB channels in one launch (the same three decimators; what differs is where the tail is kept
+  // and what leaves the last stage) -- a bank of several modes pays one launch for both
+  constexpr int PM = (MODE == 14) ? 1 : MODE;
+  const bool am = (MODE == 14) ? (cfg.mode == 1) : (MODE == 1);
   const size_t unit = (size_t)c * P.n_blocks + b;
   int16_t *rails = reinterpret_cast<int16_t *>(lds);
   const int qoff = (H + n256 + 7) & ~7;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
   // last (offset-binary bytes, i then q)
   if (first)
   {
-    const uint8_t *tail = (MODE == 2) ? st->fm_tail : (MODE == 1) ? st->am_tail : st->ssb_tail;
+    const uint8_t *tail = (MODE == 2) ? st->fm_tail : am ? st->am_tail : st->ssb_tail;
     for (int t = tid; t < H; t += kThreads)
     {
       rails[t] = (int16_t)((int)tail[2 * t] - 128);
@@ -126,11 +130,11 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
     uint32_t e[4];
     if (P.iq256 != nullptr)
     {
-      produce_stream<MODE, false, true, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<PM, false, true, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
     }
     else
     {
-      produce_stream<MODE, false, false, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<PM, false, false, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
     }
   }
   for (int off = 32; off > 0; off >>= 1)
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
   if (last)
   {
     // the demodulator's new input tail (the rails are overwritten below)
-    uint8_t *tail = (MODE == 2) ? so->fm_tail : (MODE == 1) ? so->am_tail : so->ssb_tail;
+    uint8_t *tail = (MODE == 2) ? so->fm_tail : am ? so->am_tail : so->ssb_tail;
     for (int t = tid; t < H; t += kThreads)
     {
       tail[2 * t] = (uint8_t)(rails[n256 + t] + 128);
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
     }
     const int i0 = q15_out(fir_dot(xi, kRevAmD3, 0)), i1 = q15_out(fir_dot(xi, kRevAmD3, 1));
     const int q0 = q15_out(fir_dot(xq, kRevAmD3, 0)), q1 = q15_out(fir_dot(xq, kRevAmD3, 1));
-    if (MODE == 1)
+    if (am)
     {
       // AmDemodulator::demodulateSignal (:447-461): int16 abs, compare, add with wrap
       auto env = [](int iv, int qv) -> int {
@@ -508,6 +512,7 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
   const ChanState *st = P.state + c;
   ChanState *so = P.state_out + c;
   const ChanCfg cfg = P.cfg[c];
+  const bool am = (MODE == 14) ? (cfg.mode == 1) : (MODE == 1);   // MODE 14: both kinds in one launch
   const int npcm = (int)(P.n256 >> 5);
   const int N = (int)P.n_blocks * npcm;
   if (P.n_blocks == 1)
@@ -520,16 +525,16 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
     }
   }
   int16_t *pcm = P.pcm + ((size_t)c * P.out_blocks + P.out_b0) * (size_t)npcm;
-  const int16_t *siq = (MODE == 1) ? nullptr : P.ssb_iq + (size_t)c * P.n_blocks * (size_t)(2 * npcm);
-  const float gain = (MODE == 1) ? cfg.gain_am : cfg.gain_ssb;
-  float x1 = (MODE == 1) ? st->am_x1 : st->ssb_x1;        // x[-1], y[-1] of the stream
-  float y1 = (MODE == 1) ? st->am_y1 : st->ssb_y1;
+  const int16_t *siq = am ? nullptr : P.ssb_iq + (size_t)c * P.n_blocks * (size_t)(2 * npcm);
+  const float gain = am ? cfg.gain_am : cfg.gain_ssb;
+  float x1 = am ? st->am_x1 : st->ssb_x1;                 // x[-1], y[-1] of the stream
+  float y1 = am ? st->am_y1 : st->ssb_y1;
 
   for (int s0 = 0; s0 < N; s0 += kPostSeg)
   {
     const int len = min(kPostSeg, N - s0);
     // ---- step 1: x[n] of the segment
-    if (MODE == 1)
+    if (am)
     {
       // the envelope k_rx_fir<AM> left in the PCM buffer: all of a thread's loads first (one
       // memory round trip per segment instead of one per element)
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
   // ---- state for the next call
   if (tid == 0)
   {
-    if (MODE == 1)
+    if (am)
     {
       so->am_x1 = x1;
       so->am_y1 = y1;
@@ -693,7 +698,7 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
       so->ssb_y1 = y1;
     }
   }
-  if (MODE != 1)
+  if (!am)
   {
     for (int t = tid; t < kSsbHist; t += kPostThreads)
     {
@@ -716,14 +721,11 @@ __global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
   }
 }
 
-template __global__ void k_rx_fir<1, false, false>(const RxParams);
-template __global__ void k_rx_fir<1, true, false>(const RxParams);
 template __global__ void k_rx_fir<2, false, false>(const RxParams);
 template __global__ void k_rx_fir<2, false, true>(const RxParams);
 template __global__ void k_rx_fir<2, true, false>(const RxParams);
-template __global__ void k_rx_fir<4, false, false>(const RxParams);
-template __global__ void k_rx_fir<4, true, false>(const RxParams);
-template __global__ void k_rx_post<1>(const RxParams);
-template __global__ void k_rx_post<4>(const RxParams);
+template __global__ void k_rx_post<14>(const RxParams);
+template __global__ void k_rx_fir<14, false, false>(const RxParams);
+template __global__ void k_rx_fir<14, true, false>(const RxParams);
 
 } // namespace hrfd
