@@ -174,7 +174,7 @@ def bench_ssbmod(args, api, device, rank, world, dist):
                        "blocks_per_step": B},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": {"ssbmod": "hrfd::k_mod<1>", "wbfmmod": "hrfd::k_mod<101>, k_wb_step/phase/rails, hrfd::k_mod<102>"}.get(
+                         "kernel": {"ssbmod": "hrfd::k_mod<1>", "wbfmmod": "hrfd::k_mod<101> (x32 + Nco step), k_phase_scan, k_wb_rails, hrfd::k_mod<102> (x8)"}.get(
                              args.workload, "k_am_rails / k_fm_phase + k_fm_rails, then hrfd::k_mod<100>"),
                          "kernel_ms_mean": round(mean_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
         }), flush=True)

@@ -46,7 +46,8 @@ struct ModParams
   int16_t *tail_out;        //   rows 2,3 the last kH0 samples of the I and Q rails as they were
                             //   produced (the Q rail carries the sideband sign of its time)
   const uint8_t *lsb;       // [C] sideband (SSB)
-  int16_t *mid;             // WB_HEAD: [C][32 n] the PCM at 256 kS/s
+  uint32_t *wbstep;         // WB_HEAD: [C][32 n] out: the Nco step of every 256 kS/s sample (float bits)
+  const float *param;       // WB_HEAD: [C] frequency deviation
   const uint32_t *wbtail;   // WB_TAIL: [C][2] the last two (I,Q) rail pairs of the previous call
   uint32_t n;               // input samples per channel
   uint32_t n_channels;
@@ -105,6 +106,20 @@ constexpr int kO3 = kO1 + kH1 + 2 * kModTile;
 constexpr int kO4 = kO3 + kH3 + 8 * kModTile;
 constexpr int kO5 = kO4 + kH4 + 16 * kModTile;
 constexpr int kRail = kO5 + kH5 + 32 * kModTile + 6;
+
+// (float)(p / d) for a constant d without the double division (tens of instructions in the per-sample passes): the
+// product with the reciprocal is within two ulps (of double) of the correctly rounded quotient, so the float results
+// can only differ when the product lies within a few ulps of a midpoint between two floats (its 29 dropped mantissa
+// bits are 0x10000000 +- 8), or where the float is subnormal: those cases, and only those, take the division.
+__device__ __forceinline__ float div_then_float(const double p, const double d, const double recip_d)
+{
+  const double q = p * recip_d;
+  const uint64_t b = __builtin_bit_cast(uint64_t, q);
+  const uint32_t low = (uint32_t)b & 0x1fffffffu;
+  const uint32_t expo = (uint32_t)(b >> 52) & 0x7ffu;
+  const bool risky = (low + 8u - 0x10000000u) <= 16u || expo < 1023u - 100u;
+  return risky ? (float)(p / d) : (float)q;
+}
 
 template <int KIND>
 __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
@@ -347,13 +362,18 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 
     if constexpr (KIND == HRFD_MOD_WB_HEAD)
     {
-      // WbFmModulator::increasePcmSampleRate ends here (WbFmModulator.cc:389-425): rail 0 at
-      // 256 kS/s goes to the Nco kernels
+      // WbFmModulator::increasePcmSampleRate ends here (WbFmModulator.cc:389-425) with rail 0 at 256 kS/s; what
+      // leaves the kernel is the Nco step of every such sample, modulateSignal (:601-604): f = deviation * x / 1024
+      // (float), step = (float)((2*M_PI*f)/256000) (double expression, PhaseAccumulator.cc:105)
       const int valid32 = 32 * min(kModTile, n - t0);
-      int16_t *mid = M.mid + ((size_t)c * M.n + t0) * 32;
+      uint32_t *cell = M.wbstep + ((size_t)c * M.n + t0) * 32;
+      const float dev = M.param[c];
+      const double two_pi = 6.283185307179586476925286766559;
       for (int j = tid; j < valid32; j += kModThreads)
       {
-        mid[j] = r[0][kO5 + kH5 + j];
+        float f = dev * (float)(int)r[0][kO5 + kH5 + j];
+        f = f / 1024.0f;
+        cell[j] = __builtin_bit_cast(uint32_t, div_then_float(two_pi * (double)f, 256000.0, 1.0 / 256000.0));
       }
       return;
     }
@@ -420,9 +440,9 @@ struct BaseParams
   const float *param;       // [C] modulation index (AM) / frequency deviation in Hz (FM)
   float *acc;               // [C] FM: Nco phase accumulator (persists across calls)
   float *phase;             // [C][n] FM scratch: phase of every sample
-  const int16_t *mid;       // WBFM: [C][32 n] the PCM at 256 kS/s (k_mod<WB_HEAD>)
   uint32_t *wb;             // WBFM: [C][32 n] 4-byte cells: step -> phase -> (I,Q) rails, in place
   const float *cos_t, *sin_t; // WBFM: Nco::runFast tables (host libm, Nco.cc:50-61)
+  const uint32_t *wbpack;   // WBFM: [16384] (int16)(cos_t[i] * 900) | (int16)(sin_t[i] * 900) << 16
   uint32_t *wbtail_out;     // WBFM: [C][2] the call's last two rail pairs (next call's history)
   uint32_t n, n_channels;
 };
@@ -533,129 +553,361 @@ __global__ void k_fm_step(const BaseParams B)
   const double two_pi = 6.283185307179586476925286766559;
   float f = B.param[c] * (float)B.pcm[t];
   f = f / 32768.0f;
-  B.phase[t] = (float)((two_pi * (double)f) / (double)8000.0f);
+  B.phase[t] = div_then_float(two_pi * (double)f, 8000.0, 1.0 / 8000.0);
 }
 
-// The Nco phase recurrence of both FM modulators (PhaseAccumulator.cc:157-181), one thread per
-// channel, step -> phase in place over `steps` 4-byte cells per channel: return the current
-// phase, add the step in float, wrap with double compares and a double subtraction.  Nothing but
-// the float add and the wrap test is in the dependent chain; cells are moved 16 at a time (one
-// 64-byte line per lane) with the next group in flight, because one global access per step costs
-// a memory round trip per step.
-__global__ void k_phase_scan(uint32_t *cells, size_t steps, float *acc_io, uint32_t n_channels)
+// The Nco phase recurrence of both FM modulators (PhaseAccumulator.cc:157-181), step -> phase in place over `steps`
+// 4-byte cells per channel: return the current phase, add the step in float, wrap with double compares and a double
+// subtraction.  A float accumulate with a wrap is neither associative nor contracting (a start value that is off by
+// one ulp stays off), so the recurrence is serial per channel: 64 channels per wave, and the time of a launch is
+// steps x (instructions per step) x 4 cycles whatever the number of channels.  Everything else is kept out of that
+// wave's instruction stream:
+//   * the wrap is branch free, k = rint(acc * M) in {-1, 0, 1}, acc = fma(k, -C_LO, fma(k, -C_HI, acc)) -- equal to
+//     the reference's loops for EVERY float |acc| <= 8 (tools/proofs/wrap_rint_fma.c: 2.2e9 values, M one ulp above
+//     (float)(1/(2 pi)) so that the float above pi is the first to wrap): add, mul, rndne, fma, fma per step; a chunk
+//     with a step above 4.85 (absurd deviations: the loaders look) or an accumulator above pi is redone with the loops;
+//   * the cells move through LDS: loader waves bring chunks of 64 steps x 64 channels in with coalesced 16-byte
+//     loads, storer waves take them out, the recurrence wave reads and writes its channel's row with ds_*_b128.
+//     A wave that touches memory itself waits for it (one access per lane and 16 steps was a memory round trip per
+//     16 steps: 60 ns per step).
+// Flags in LDS, no barriers in the loop; every wait is bounded (an expired one aborts the workgroup and counts in *err).
+constexpr int kPsChunk = 64;                              // steps per chunk
+constexpr int kPsRow = kPsChunk + 4;                      // dwords per channel row in LDS: 16-byte aligned, rows 4 banks apart
+#ifndef HRFD_PS_SLOTS
+#define HRFD_PS_SLOTS 6
+#endif
+#ifndef HRFD_PS_LOADERS
+#define HRFD_PS_LOADERS 3
+#endif
+#ifndef HRFD_PS_STORERS
+#define HRFD_PS_STORERS 3
+#endif
+constexpr int kPsSlots = HRFD_PS_SLOTS;
+constexpr int kPsLoaders = HRFD_PS_LOADERS, kPsStorers = HRFD_PS_STORERS;
+constexpr int kPsThreads = 64 * (1 + kPsLoaders + kPsStorers);
+#ifndef HRFD_PS_CWAVE
+#define HRFD_PS_CWAVE 3
+#endif
+constexpr int kPsCompute = HRFD_PS_CWAVE;
+
+__device__ __forceinline__ uint32_t ps_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ps_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ps_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// the reference's wrap (PhaseAccumulator.cc:166-176).  It does not terminate for an accumulator so large that
+// subtracting 2 pi no longer changes it; this one gives up after 64 turns.
+__device__ __forceinline__ float ps_wrap_loops(float acc)
+{
+  const double pi = 3.14159265358979323846, two_pi = 6.283185307179586476925286766559;
+  for (int t = 0; t < 64 && (double)acc > pi; t++)
+  {
+    acc = (float)((double)acc - two_pi);
+  }
+  for (int t = 0; t < 64 && (double)acc < -pi; t++)
+  {
+    acc = (float)((double)acc + two_pi);
+  }
+  return acc;
+}
+
+// kPsChan: channels per workgroup (lanes of the recurrence wave in use).  The wave's time per step does not depend on
+// it, so a bank that leaves CUs idle anyway is spread thinly (16 per workgroup: less LDS traffic beside the chain, 8 %).
+template <int kPsChan>
+__global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size_t steps, float *acc_io, uint32_t n_channels, uint32_t *err)
+{
+  constexpr int kPsPieces = kPsChan / 4;                  // 16-byte pieces per mover lane and chunk
+  __shared__ __attribute__((aligned(16))) uint32_t ring[kPsSlots][kPsChan * kPsRow];
+  __shared__ uint32_t ready[kPsSlots];                    // slot holds chunk i, loaded: i + 1
+  __shared__ uint32_t freed[kPsSlots];                    // slot held chunk j, stored out: j + 1
+  __shared__ uint32_t ctl[2];                             // chunks computed; abort
+  const int tid = threadIdx.x, lane = tid & 63;
+  // roles: wave kPsCompute runs the recurrence (alone on its SIMD when waves go round the four SIMDs in order: 3 of 7),
+  // then loaders, then storers
+  const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = (hw_wave == kPsCompute) ? 0 : (hw_wave < kPsCompute ? hw_wave + 1 : hw_wave);
+  if (tid < kPsSlots)
+  {
+    ready[tid] = 0u;
+    freed[tid] = 0u;
+  }
+  if (tid < 2)
+  {
+    ctl[tid] = 0u;
+  }
+  __syncthreads();
+  const uint32_t c0 = blockIdx.x * (uint32_t)kPsChan;
+  const uint32_t nchunks = (uint32_t)((steps + kPsChunk - 1) / kPsChunk);
+  // bounded wait for `cond()`; false: expired or aborted
+  auto wait_for = [&](auto cond) -> bool {
+    for (uint32_t spins = 0; spins < (1u << 24); spins++)
+    {
+      if (cond())
+      {
+        ps_order();
+        return true;
+      }
+      if (ps_ld(&ctl[1]) != 0u)
+      {
+        return false;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0)
+    {
+      ps_st(&ctl[1], 1u);
+      atomicAdd(err, 1u);
+    }
+    return false;
+  };
+  // a mover lane's share of a chunk: piece r = channels 4r .. 4r+3, this lane: channel 4r + lane/16, steps 4 (lane%16) .. +3
+  const int mq = lane & 15, mc = lane >> 4;
+
+  if (wave == 0)
+  {
+    // ------------------------------------------------------------ the recurrence: lane = channel
+    // Per chunk: the next chunk's row is requested first (into the other register set), the previous chunk's
+    // "done" goes out once its writes have landed (a counted wait: only the requests just issued stay open), then
+    // the 64 steps of this chunk run out of registers and the row is written back.  No LDS latency is exposed in
+    // the steady state, and the readiness of the loaders' slots is polled for several chunks at a time.
+    __builtin_amdgcn_s_setprio(3);
+    const bool mine = lane < kPsChan;
+    const uint32_t c = c0 + (uint32_t)lane;
+    float acc = (mine && c < n_channels) ? acc_io[c] : 0.0f;
+    const float kM = 0x1.45f308p-3f, kChi = 0x1.921fb6p+2f, kClo = -0x1.777a5cp-23f;
+    // the branch-free wrap needs |acc + step| <= 8: |acc| <= pi (true behind every wrap) and |step| <= 4.85 (the loaders
+    // look at the steps of a chunk and mark it); anything else takes the loops
+    bool wild = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(acc) <= 3.1415927f)) != 0ull;
+#ifdef HRFD_PS_PROBE
+    const unsigned long long ps_t0 = __builtin_readcyclecounter();
+    unsigned long long ps_waited = 0;
+#endif
+    uint32_t known = 0;                                   // chunks [0, known) are in their slots
+    auto ensure = [&](uint32_t need) -> bool {
+      if (need < known)
+      {
+        return true;
+      }
+#ifdef HRFD_PS_PROBE
+      const unsigned long long tw = __builtin_readcyclecounter();
+#endif
+      const bool okw = wait_for([&] {
+        const uint32_t ch = known + (uint32_t)lane;       // lanes 0 .. kPsSlots-1: is chunk `ch` in its slot?
+        const bool ok = lane < kPsSlots && ch < nchunks && (ps_ld(&ready[ch % kPsSlots]) & 0x7fffffffu) == ch + 1u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+        known += (uint32_t)__builtin_ctzll(~m);           // the run of consecutive chunks from `known` on
+        return need < known;
+      });
+#ifdef HRFD_PS_PROBE
+      ps_waited += __builtin_readcyclecounter() - tw;
+#endif
+      return okw;
+    };
+    typedef uint4 Row[kPsChunk / 4];
+    auto request = [&](Row &in, uint32_t &flag, uint32_t i) {
+      const int slot = (int)(i % kPsSlots);
+      const uint32_t *row = &ring[slot][(mine ? lane : 0) * kPsRow];
+      if (mine)
+      {
+#pragma unroll
+        for (int j = 0; j < kPsChunk / 4; j++)
+        {
+          in[j] = *reinterpret_cast<const uint4 *>(row + 4 * j);
+        }
+      }
+      flag = ps_ld(&ready[slot]);
+    };
+    auto chunk = [&](const Row &in, const uint32_t flag, uint32_t i) {
+      uint32_t *row = &ring[(int)(i % kPsSlots)][(mine ? lane : 0) * kPsRow];
+      Row o;
+      float a = acc;
+      auto one = [&](uint32_t step_bits) -> uint32_t {
+        const uint32_t phase_bits = __builtin_bit_cast(uint32_t, a);
+        a = a + __builtin_bit_cast(float, step_bits);
+        const float k = __builtin_rintf(a * kM);
+        a = __builtin_fmaf(k, -kChi, a);
+        a = __builtin_fmaf(k, -kClo, a);
+        return phase_bits;
+      };
+#pragma unroll
+      for (int j = 0; j < kPsChunk / 4; j++)
+      {
+        o[j].x = one(in[j].x);
+        o[j].y = one(in[j].y);
+        o[j].z = one(in[j].z);
+        o[j].w = one(in[j].w);
+      }
+      if (wild || (flag >> 31) != 0u)
+      {
+        // a step or an accumulator outside the range the branch-free wrap is proven for: the chunk again, with the loops
+        a = acc;
+        for (int k = 0; k < kPsChunk && mine; k++)
+        {
+          const float st = __builtin_bit_cast(float, row[k]);
+          row[k] = __builtin_bit_cast(uint32_t, a);
+          a = ps_wrap_loops(a + st);
+        }
+        wild = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(a) <= 3.1415927f)) != 0ull;
+      }
+      else if (mine)
+      {
+#pragma unroll
+        for (int j = 0; j < kPsChunk / 4; j++)
+        {
+          *reinterpret_cast<uint4 *>(row + 4 * j) = o[j];
+        }
+      }
+      acc = a;
+    };
+    // one iteration: request chunk i + 1, release chunk i - 1, run chunk i
+    auto turn = [&](const Row &cur, const uint32_t cur_flag, Row &nxt, uint32_t &nxt_flag, uint32_t i) -> bool {
+      const bool more = i + 1u < nchunks;
+      if (more)
+      {
+        if (!ensure(i + 1u))
+        {
+          return false;
+        }
+        request(nxt, nxt_flag, i + 1u);
+        // LDS operations complete in order: all but the 15 youngest are through, chunk i - 1's writes among them
+        static_assert(kPsChunk / 4 + 1 > 15, "the counted wait below");
+        asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+      }
+      else
+      {
+        ps_order();
+      }
+      if (i > 0u && lane == 0)
+      {
+        ps_st(&ctl[0], i);
+      }
+      chunk(cur, cur_flag, i);
+      return true;
+    };
+    Row ra, rb;
+    uint32_t fa = 0u, fb = 0u;
+    bool alive = nchunks != 0u && ensure(0u);
+    if (alive)
+    {
+      request(ra, fa, 0u);
+    }
+    uint32_t i = 0;
+    while (alive && i < nchunks)
+    {
+      alive = turn(ra, fa, rb, fb, i);
+      i++;
+      if (alive && i < nchunks)
+      {
+        alive = turn(rb, fb, ra, fa, i);
+        i++;
+      }
+    }
+    if (alive)
+    {
+      ps_order();
+      if (lane == 0)
+      {
+        ps_st(&ctl[0], nchunks);
+      }
+    }
+    if (mine && c < n_channels && alive)
+    {
+      acc_io[c] = acc;
+    }
+#ifdef HRFD_PS_PROBE
+    if (lane == 0)
+    {
+      atomicAdd(&err[1], (uint32_t)((__builtin_readcyclecounter() - ps_t0) >> 8));   // cycles / 256 of the recurrence wave
+      atomicAdd(&err[2], (uint32_t)(ps_waited >> 8));                                  // of which in ensure()
+    }
+#endif
+  }
+  else if (wave <= kPsLoaders)
+  {
+    // ------------------------------------------------------------ loaders: chunk i of the 64 channels -> slot i % kPsSlots
+    for (uint32_t i = (uint32_t)(wave - 1); i < nchunks; i += kPsLoaders)
+    {
+      const int slot = (int)(i % kPsSlots);
+      if (i >= (uint32_t)kPsSlots && !wait_for([&] { return ps_ld(&freed[slot]) == i - kPsSlots + 1u; }))
+      {
+        break;
+      }
+      const size_t k0 = (size_t)i * kPsChunk + 4 * (size_t)mq;
+      uint4 v[kPsPieces];
+#pragma unroll
+      for (int r = 0; r < kPsPieces; r++)
+      {
+        const uint32_t ch = c0 + 4u * r + (uint32_t)mc;
+        v[r] = make_uint4(0u, 0u, 0u, 0u);               // a zero step leaves the accumulator alone (x + 0 = x, no wrap: |x| <= pi)
+        if (ch < n_channels && k0 < steps)
+        {
+          v[r] = *reinterpret_cast<const uint4 *>(cells + (size_t)ch * steps + k0);
+        }
+      }
+      uint32_t big = 0u;                                   // the largest |step| as bits (a NaN or an infinity is larger still)
+#pragma unroll
+      for (int r = 0; r < kPsPieces; r++)
+      {
+        *reinterpret_cast<uint4 *>(&ring[slot][(4 * r + mc) * kPsRow + 4 * mq]) = v[r];
+        big = max(max(big, v[r].x & 0x7fffffffu), max(v[r].y & 0x7fffffffu, max(v[r].z & 0x7fffffffu, v[r].w & 0x7fffffffu)));
+      }
+      const bool marked = __builtin_amdgcn_ballot_w64(big > __builtin_bit_cast(uint32_t, 4.85f)) != 0ull;
+      ps_order();
+      if (lane == 0)
+      {
+        ps_st(&ready[slot], (i + 1u) | (marked ? 0x80000000u : 0u));
+      }
+    }
+  }
+  else
+  {
+    // ------------------------------------------------------------ storers: finished chunk j -> memory, slot free
+    for (uint32_t j = (uint32_t)(wave - 1 - kPsLoaders); j < nchunks; j += kPsStorers)
+    {
+      const int slot = (int)(j % kPsSlots);
+      if (!wait_for([&] { return ps_ld(&ctl[0]) >= j + 1u; }))
+      {
+        break;
+      }
+      const size_t k0 = (size_t)j * kPsChunk + 4 * (size_t)mq;
+      const uint32_t nlive = (k0 < steps) ? (n_channels - c0 + 3u - (uint32_t)mc) / 4u : 0u;   // pieces r with c0 + 4r + mc < n_channels
+#pragma unroll
+      for (int r = 0; r < kPsPieces; r++)
+      {
+        const uint4 t = *reinterpret_cast<const uint4 *>(&ring[slot][(4 * r + mc) * kPsRow + 4 * mq]);
+        if ((uint32_t)r < nlive)
+        {
+          *reinterpret_cast<uint4 *>(cells + (size_t)(c0 + 4u * r + (uint32_t)mc) * steps + k0) = t;
+        }
+      }
+      ps_order();                                          // the slot has been read (the stores may still be on their way)
+      if (lane == 0)
+      {
+        ps_st(&freed[slot], j + 1u);
+      }
+    }
+  }
+}
+
+template __global__ void k_phase_scan<16>(uint32_t *, size_t, float *, uint32_t, uint32_t *);
+template __global__ void k_phase_scan<32>(uint32_t *, size_t, float *, uint32_t, uint32_t *);
+template __global__ void k_phase_scan<64>(uint32_t *, size_t, float *, uint32_t, uint32_t *);
+
+// the same recurrence for a cell count that is not a multiple of four (no 16-byte pieces): one thread per channel,
+// straight from memory
+__global__ void k_phase_scan_plain(uint32_t *cells, size_t steps, float *acc_io, uint32_t n_channels)
 {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_channels)
   {
     return;
   }
-  const double pi = 3.14159265358979323846, two_pi = 6.283185307179586476925286766559;
-  const float pi_up = 3.14159274101257324e+00f;          // (double)acc > M_PI  <=>  acc >= pi_up
   float acc = acc_io[c];
   uint32_t *cell = cells + (size_t)c * steps;
-  // The wrap: for pi < |acc| <= 8 one subtraction of 2*M_PI suffices, and the reference's double
-  // subtraction equals two float ones, (acc -+ C_HI) -+ C_LO -- checked for every one of the
-  // 2.4e7 floats in that range by tools/proofs/wrap_float_acc.c.  That keeps the dependent chain
-  // at add, subtract, subtract, select, with no scalar instruction in it: whether some |acc|
-  // exceeded 8 (absurd deviations) is only looked at once per group of 16 cells, and such a group
-  // is redone from its first cell with the double loops.
-  const uint32_t c_hi = 0x40c90fdbu, c_lo = 0xb43bbd2eu;
-  float maxmag = 0.0f;
-  auto advance_fast = [&](uint32_t step_bits) -> uint32_t {
-    const uint32_t phase_bits = __builtin_bit_cast(uint32_t, acc);
-    acc = acc + __builtin_bit_cast(float, step_bits);
-    const float mag = __builtin_fabsf(acc);
-    maxmag = __builtin_fmaxf(maxmag, mag);
-    const uint32_t sg = __builtin_bit_cast(uint32_t, acc) & 0x80000000u;
-    const float u = acc - __builtin_bit_cast(float, c_hi | sg);
-    const float w = u - __builtin_bit_cast(float, c_lo ^ sg);
-    acc = (mag >= pi_up) ? w : acc;
-    return phase_bits;
-  };
-  auto advance = [&](uint32_t step_bits) -> uint32_t {
-    const uint32_t phase_bits = __builtin_bit_cast(uint32_t, acc);
-    acc = acc + __builtin_bit_cast(float, step_bits);
-    while ((double)acc > pi)
-    {
-      acc = (float)((double)acc - two_pi);
-    }
-    while ((double)acc < -pi)
-    {
-      acc = (float)((double)acc + two_pi);
-    }
-    return phase_bits;
-  };
-  size_t k = 0;
-  if ((steps & 15) == 0 && steps >= 16)
+  for (size_t k = 0; k < steps; k++)
   {
-    // groups of 16 cells (four 16-byte pieces: one 64-byte line per lane), kGroups groups in
-    // flight in a register ring: the group just finished is refilled from 16*kGroups cells ahead
-    constexpr int kGroups = 4;
-    uint4 *v = reinterpret_cast<uint4 *>(cell);         // 16-byte aligned: steps is a multiple of 16
-    const size_t ngroups = steps >> 4;
-    uint4 g[kGroups][4];
-#pragma unroll
-    for (int d = 0; d < kGroups; d++)
-    {
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-      {
-        g[d][j] = ((size_t)d < ngroups) ? v[(size_t)d * 4 + j] : make_uint4(0u, 0u, 0u, 0u);
-      }
-    }
-    for (size_t gi = 0; gi < ngroups; gi += kGroups)
-    {
-#pragma unroll
-      for (int d = 0; d < kGroups; d++)
-      {
-        const size_t cur = gi + d;
-        if (cur < ngroups)
-        {
-          const float acc0 = acc;
-          uint4 o[4];
-          maxmag = 0.0f;
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-          {
-            o[j].x = advance_fast(g[d][j].x);
-            o[j].y = advance_fast(g[d][j].y);
-            o[j].z = advance_fast(g[d][j].z);
-            o[j].w = advance_fast(g[d][j].w);
-          }
-          if (__builtin_amdgcn_ballot_w64(maxmag > 8.0f) != 0ull)
-          {
-            acc = acc0;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-            {
-              o[j].x = advance(g[d][j].x);
-              o[j].y = advance(g[d][j].y);
-              o[j].z = advance(g[d][j].z);
-              o[j].w = advance(g[d][j].w);
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-          {
-            v[cur * 4 + j] = o[j];
-          }
-          const size_t nxt = cur + kGroups;
-          if (nxt < ngroups)
-          {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-            {
-              g[d][j] = v[nxt * 4 + j];
-            }
-          }
-        }
-      }
-    }
-    k = steps;
-  }
-  for (; k < steps; k++)
-  {
-    cell[k] = advance(cell[k]);
+    const float st = __builtin_bit_cast(float, cell[k]);
+    cell[k] = __builtin_bit_cast(uint32_t, acc);
+    acc = ps_wrap_loops(acc + st);
   }
   acc_io[c] = acc;
 }
@@ -689,51 +941,53 @@ __global__ void k_wb_pairs(const BaseParams B)
   }
 }
 
-// per 256 kS/s sample, in parallel: the Nco step of modulateSignal (:601-604) --
-// f = deviation * x / 1024 (float), step = (float)((2*M_PI*f)/256000) (double expression,
-// PhaseAccumulator.cc:105)
-__global__ void k_wb_step(const BaseParams B)
-{
-  const size_t n32 = (size_t)B.n * 32;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n32 * B.n_channels)
-  {
-    return;
-  }
-  const uint32_t c = (uint32_t)(t / n32);
-  const double two_pi = 6.283185307179586476925286766559;
-  float f = B.param[c] * (float)B.mid[t];
-  f = f / 1024.0f;
-  const float step = (float)((two_pi * (double)f) / (double)256000.0f);
-  B.wb[t] = __builtin_bit_cast(uint32_t, step);
-}
-
 // per sample, in parallel: Nco::runFast (Nco.cc:222-257) on the stored phase, x900, (int16_t):
-// phase -> (I,Q) rail pair in place; the call's last two pairs are kept for the next call
-__global__ void k_wb_rails(const BaseParams B)
+// phase -> (I,Q) rail pair in place; the call's last two pairs are kept for the next call.
+// The two float tables, x900 and narrowed, are one table of 16384 rail pairs (B.wbpack, built by the host with the
+// same float multiply): 64 KiB, held in LDS by every workgroup -- one ds_read per sample instead of two gathers
+// from memory -- and the workgroups walk the cells four at a time (16-byte accesses).
+constexpr int kWbRailsThreads = 512;
+__global__ __launch_bounds__(kWbRailsThreads) void k_wb_rails(const BaseParams B)
 {
-  const size_t n32 = (size_t)B.n * 32;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n32 * B.n_channels)
+  __shared__ __attribute__((aligned(16))) uint32_t pack[16384];
+  for (int i = threadIdx.x; i < 16384 / 4; i += kWbRailsThreads)
   {
-    return;
+    reinterpret_cast<uint4 *>(pack)[i] = reinterpret_cast<const uint4 *>(B.wbpack)[i];
   }
+  __syncthreads();
+  const size_t n32 = (size_t)B.n * 32;
+  const size_t quads = n32 * B.n_channels / 4;
   const double two_pi = 6.283185307179586476925286766559;
-  const float phase = __builtin_bit_cast(float, B.wb[t]);
-  const float scaled = phase * 16384.0f;
-  int idx = (int)(short)(int)((double)scaled / two_pi);
-  idx += 8192;
-  idx = max(0, min(16383, idx));
-  float iv = B.cos_t[idx], qv = B.sin_t[idx];
-  iv = iv * 900.0f;
-  qv = qv * 900.0f;
-  const int i16 = (int)(short)(int)iv, q16 = (int)(short)(int)qv;
-  const uint32_t w = ((uint32_t)i16 & 0xffffu) | ((uint32_t)q16 << 16);
-  B.wb[t] = w;
-  const size_t k = t % n32;
-  if (k + 2 >= n32)
+  for (size_t q = (size_t)blockIdx.x * kWbRailsThreads + threadIdx.x; q < quads; q += (size_t)gridDim.x * kWbRailsThreads)
   {
-    B.wbtail_out[(size_t)(t / n32) * 2 + (k + 2 - n32)] = w;
+    const size_t t = 4 * q;
+    const uint4 ph = *reinterpret_cast<const uint4 *>(B.wb + t);
+    const uint32_t pb[4] = {ph.x, ph.y, ph.z, ph.w};
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      const float scaled = __builtin_bit_cast(float, pb[j]) * 16384.0f;
+      // (int)(x / two_pi): the product with the reciprocal is within two ulps of the quotient, so the truncation can only
+      // differ when an integer is that close -- then, and only then, the division itself
+      double quot = (double)scaled * (1.0 / two_pi);
+      if (__builtin_fabs(quot - __builtin_rint(quot)) < 1e-6)
+      {
+        quot = (double)scaled / two_pi;
+      }
+      int idx = (int)(short)(int)quot;
+      idx += 8192;
+      idx = max(0, min(16383, idx));
+      w[j] = pack[idx];
+    }
+    *reinterpret_cast<uint4 *>(B.wb + t) = make_uint4(w[0], w[1], w[2], w[3]);
+    const size_t k = t % n32;
+    if (k + 4 == n32)
+    {
+      const size_t c = t / n32;
+      B.wbtail_out[c * 2] = w[2];
+      B.wbtail_out[c * 2 + 1] = w[3];
+    }
   }
 }
 
