@@ -159,6 +159,28 @@ def test_wbfm_modulator_bit_exact(oracle):
     assert _mod_case(oracle, "wbfmmod", api.MOD_WBFM, 0) == 0.0
 
 
+def test_wbfm_modulator_absurd_deviation_takes_the_loops(oracle):
+    """setFrequencyDeviation tests the CURRENT value against its limit (WbFmModulator.cc:313), so one absurd deviation
+    gets through: Nco steps of tens of radians, several turns of the wrap loops per sample.  k_phase_scan's branch-free
+    wrap is proven for |acc + step| <= 8 only; chunks with larger steps must come out of the loops, bit-exact, and the
+    chunks of the other channels in the same workgroup with them.  17 channels: two workgroups, the second with one."""
+    C = 17
+    n = 700
+    pcm = np.stack([synth.lcg_pcm(90 + c, n) for c in range(C)])
+    m = api.Mod(api.MOD_WBFM, C)
+    os_ = [oracle.wbfmmod() for _ in range(C)]
+    for c, dev in ((2, 2.0e6), (16, 9.0e5)):
+        m.set_param(dev, channel=c)
+        os_[c].set_param(dev)
+    off = 0
+    for k in (300, 1, 399):
+        got = m.process(pcm[:, off:off + k])
+        for c in range(C):
+            want = os_[c].process(pcm[c, off:off + k])
+            assert (got[c] == want).all(), (k, c)
+        off += k
+
+
 def test_fm_modulator_within_one_lsb(oracle):
     """FmModulator's Nco calls libm cosf/sinf (Nco.cc:186-199); the device evaluates cos/sin in
     double and rounds to float.  The phase recurrence is exact, so the only difference is an
