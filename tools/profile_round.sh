@@ -32,7 +32,7 @@ if [ "$2" = "all" ]; then
   stats wbfm1024x16 --steps 60 --warmup 40 --channels 1024
   stats mixed --steps 100 --warmup 50 --workload mixed
   stats ssbmod1024 --steps 100 --warmup 50 --workload ssbmod
-  stats wbfmmod --steps 20 --warmup 10 --workload wbfmmod --channels 256
+  stats wbfmmod1024 --steps 20 --warmup 10 --workload wbfmmod
 fi
 for CNT in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc_$CNT -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extras > /dev/null 2> $O/pmc_$CNT.log
