@@ -262,6 +262,13 @@ int hrfd_play_get(hrfd_play *h, int8_t *out, uint32_t bytes_per_channel);
  * Nco (Nco/Nco.cc:186-257, Nco/PhaseAccumulator.cc:157-181): n_channels
  * oscillators advanced `count` samples each; fast != 0 selects runFast's table.
  * i_out/q_out are [n_channels][count] float host buffers.
+ * Accuracy: the phase sequence is the reference's bit for bit (float accumulate, double-compare
+ * wrap).  fast != 0 (Nco::runFast): the values are the host-built table's -- bit-exact.
+ * fast == 0 (Nco::run): the reference calls libm sinf/cosf; the device evaluates cos/sin of the
+ * same phase in double and rounds to float, so a value may differ from glibc's by one ulp (the
+ * float-trig tolerance the north star allows; tests/test_gpu_tx_nco.py states it).  The same holds
+ * for what is built on Nco::run: the FM modulator and the pm / fm generators (int8 IQ within
+ * +-1 LSB, see hrfd_mod_create).
  */
 typedef struct hrfd_nco hrfd_nco;
 int hrfd_nco_create(uint32_t n_channels, float sample_rate, float frequency, int device,
