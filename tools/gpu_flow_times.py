@@ -52,3 +52,9 @@ if tl[:, 0].min() > 0:
     d = us[:, 4] - us[:, 0]
     print("   workgroup lifetime: min %.2f mean %.2f max %.2f us;  service tail behind the stream: mean %.2f max %.2f us"
           % (d.min(), d.mean(), d.max(), (us[:, 3] - us[:, 2]).mean(), (us[:, 3] - us[:, 2]).max()))
+if tl[:, 0].min() > 0:
+    # who is late?  workgroup ids go round the 8 XCDs
+    st_us = (tl[:, 2] - tl[:, 0]) / 100.0
+    print("stream time by XCD (blockIdx % 8): " + "  ".join("%d: %.1f" % (x, st_us[x::8].mean()) for x in range(8)))
+    order = np.argsort(st_us)
+    print("   slowest workgroups:", [(int(i), round(float(st_us[i]), 1)) for i in order[-8:]], " fastest:", [(int(i), round(float(st_us[i]), 1)) for i in order[:4]])
