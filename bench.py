@@ -356,12 +356,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libhrfd has no CPU path)")
+    # HRFD_BENCH_REHEARSE=1: N ranks on however many GPUs there are, over gloo -- a dry run of the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device).  Never set by the driver; the line it prints says so.
+    rehearse = os.environ.get("HRFD_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
 
     from hackrfdiags_amd import api, shard
 
