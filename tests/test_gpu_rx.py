@@ -230,8 +230,11 @@ def test_squelch_in_a_batch_falls_back_to_exact_path(oracle):
     assert rx.debug_counters()[7] == 0          # replays only count de-emphasis redo, none needed
 
 
-def test_one_quiet_channel_does_not_stop_the_bank(oracle):
-    """The verdict of a batch is per channel: with a real squelch threshold, one channel whose gate closes
+@pytest.mark.parametrize("run_len", [0, 16], ids=["several_runs_per_channel", "one_workgroup_per_channel"])
+def test_one_quiet_channel_does_not_stop_the_bank(oracle, run_len):
+    """(run_len 16: every channel is ONE workgroup's, which finishes it from its LDS -- the path of a full bank;
+    run_len 0, automatic: a small bank is cut into several runs per channel, finished by the workgroup that arrives last.)
+    The verdict of a batch is per channel: with a real squelch threshold, one channel whose gate closes
     inside the batch fails ITS speculation and is replayed block by block; the other channels commit from
     the batch launch (device path: sync() reports one failed channel and says which).  Squelched units
     hand back zeros, not what the failed batch launch left in the buffer."""
@@ -245,6 +248,7 @@ def test_one_quiet_channel_does_not_stop_the_bank(oracle):
     rx = api.Rx(C)
     rx.set_mode(api.WBFM)
     rx.set_threshold(-30)
+    rx.debug_set_run_len(run_len)
     pcm, n_pcm, mag, allowed, _ = rx.process_block(xs, B)
     for c in range(C):
         want = _oracle_stream(oracle, WBFM, xs[c], B, threshold=-30)
@@ -258,6 +262,7 @@ def test_one_quiet_channel_does_not_stop_the_bank(oracle):
     rx2 = api.Rx(C)
     rx2.set_mode(api.WBFM)
     rx2.set_threshold(-30)
+    rx2.debug_set_run_len(run_len)
     x = torch.from_numpy(xs).to(dev)
     out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
     torch.cuda.synchronize()
