@@ -162,6 +162,9 @@ def bench_ssbmod(args, api, device, rank, world, dist):
     algo_bytes = C * n * (2 + 512)
     mean_ms = float(np.mean(kernel_ms))
     achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
+    fill = None
+    if rank == 0 and not args.no_extras:
+        fill = stream_fill_gbs(device, out)
     if rank == 0:
         print(json.dumps({
             "metric": f"IQ MSamples/s modulated (8 kS/s PCM -> 2.048 MS/s int8 IQ, {kname}) per GPU; % HBM roofline",
@@ -174,6 +177,8 @@ def bench_ssbmod(args, api, device, rank, world, dist):
                        "blocks_per_step": B},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "measured_stream_fill_GBps": None if fill is None else round(fill, 1),
+                         "frac_of_measured_fill": None if fill is None else round(achieved / fill, 4),
                          "kernel": {"ssbmod": "hrfd::k_mod<1>", "wbfmmod": "hrfd::k_mod<101> (x32 + Nco step), k_phase_scan, k_wb_rails, hrfd::k_mod<102> (x8)"}.get(
                              args.workload, "k_am_rails / k_fm_phase + k_fm_rails, then hrfd::k_mod<100>"),
                          "kernel_ms_mean": round(mean_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
@@ -282,6 +287,21 @@ def stream_copy_gbs(device):
     ms = e0.elapsed_time(e1) / 10
     del a, b
     return 2 * n / (ms * 1e-3) / 1e9
+
+
+def stream_fill_gbs(device, out):
+    """The write-side counterpart: what the library's fill of the modulators' own output buffer reaches on this GPU in
+    this run (bytes written over the time of the fill kernel, HIP events, 10 fills after 3 warm-ups)."""
+    for _ in range(3):
+        out.fill_(1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        out.fill_(1)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    return out.numel() * out.element_size() / (ms * 1e-3) / 1e9
 
 
 def end_to_end(api, device, C):
