@@ -47,20 +47,21 @@ class BasebandDataProcessor
 
   private:
 
-  void modulateBasebandData(int8_t *bufferPtr,uint32_t bufferLength);
-  static void *basebandReaderProcedure(void *arg);
+  // BasebandDataProcessor.cc:630-697 (modulateBasebandData): one PCM block from the ring through the mode's modulator
+  void fill_transfer_buffer(int8_t *bufferPtr,uint32_t bufferLength);
+  static void *reader_main(void *arg);
 
   hrfd_txring *ring;
-  streamStateType streamState;
-  modulatorType modulatorMode;
-  AmModulator *amModulatorPtr;
-  FmModulator *fmModulatorPtr;
-  WbFmModulator *wbFmModulatorPtr;
-  SsbModulator *ssbModulatorPtr;
-  volatile bool timeToStopReaderThread;
-  bool readerThreadStarted;
-  pthread_t basebandReaderThread;
-  int16_t pcmBlock[PCM_BLOCK_SIZE];
+  streamStateType running_state;
+  modulatorType mode_now;
+  AmModulator *am_mod;
+  FmModulator *fm_mod;
+  WbFmModulator *wbfm_mod;
+  SsbModulator *ssb_mod;
+  volatile bool reader_must_stop;
+  bool reader_running;
+  pthread_t reader_thread;
+  int16_t one_block[PCM_BLOCK_SIZE];
 };
 
 #endif

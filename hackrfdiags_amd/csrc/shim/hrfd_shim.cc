@@ -738,13 +738,13 @@ void DataProvider::displayInternalInformation(void)
 #include "BasebandDataProcessor.h"
 
 BasebandDataProcessor::BasebandDataProcessor(void)
-    : ring(NULL), streamState(Idle), modulatorMode(None), amModulatorPtr(NULL), fmModulatorPtr(NULL),
-      wbFmModulatorPtr(NULL), ssbModulatorPtr(NULL), timeToStopReaderThread(false), readerThreadStarted(false),
-      basebandReaderThread()
+    : ring(NULL), running_state(Idle), mode_now(None), am_mod(NULL), fm_mod(NULL),
+      wbfm_mod(NULL), ssb_mod(NULL), reader_must_stop(false), reader_running(false),
+      reader_thread()
 {
   const int rc = hrfd_txring_create(1, &ring);
   if (rc != HRFD_OK) fatal("hrfd_txring_create", rc);
-  memset(pcmBlock, 0, sizeof(pcmBlock));
+  memset(one_block, 0, sizeof(one_block));
 }
 
 BasebandDataProcessor::~BasebandDataProcessor(void)
@@ -753,18 +753,18 @@ BasebandDataProcessor::~BasebandDataProcessor(void)
   hrfd_txring_destroy(ring);
 }
 
-void BasebandDataProcessor::setAmModulator(AmModulator *modulatorPtr) { amModulatorPtr = modulatorPtr; }
-void BasebandDataProcessor::setFmModulator(FmModulator *modulatorPtr) { fmModulatorPtr = modulatorPtr; }
-void BasebandDataProcessor::setWbFmModulator(WbFmModulator *modulatorPtr) { wbFmModulatorPtr = modulatorPtr; }
-void BasebandDataProcessor::setSsbModulator(SsbModulator *modulatorPtr) { ssbModulatorPtr = modulatorPtr; }
+void BasebandDataProcessor::setAmModulator(AmModulator *modulatorPtr) { am_mod = modulatorPtr; }
+void BasebandDataProcessor::setFmModulator(FmModulator *modulatorPtr) { fm_mod = modulatorPtr; }
+void BasebandDataProcessor::setWbFmModulator(WbFmModulator *modulatorPtr) { wbfm_mod = modulatorPtr; }
+void BasebandDataProcessor::setSsbModulator(SsbModulator *modulatorPtr) { ssb_mod = modulatorPtr; }
 
 void BasebandDataProcessor::setModulatorMode(modulatorType mode)
 {
-  modulatorMode = mode;
-  if (ssbModulatorPtr != NULL)
+  mode_now = mode;
+  if (ssb_mod != NULL)
   {
-    if (mode == Lsb) ssbModulatorPtr->setLsbModulationMode();
-    if (mode == Usb) ssbModulatorPtr->setUsbModulationMode();
+    if (mode == Lsb) ssb_mod->setLsbModulationMode();
+    if (mode == Usb) ssb_mod->setUsbModulationMode();
   }
 }
 
@@ -775,12 +775,12 @@ void BasebandDataProcessor::putPcmBlock(const int16_t *pcm512)
 }
 
 // BasebandDataProcessor.cc:834-887: standard input, 512 samples at a time, polled every 5 ms
-void *BasebandDataProcessor::basebandReaderProcedure(void *arg)
+void *BasebandDataProcessor::reader_main(void *arg)
 {
   BasebandDataProcessor *me = static_cast<BasebandDataProcessor *>(arg);
   int16_t block[PCM_BLOCK_SIZE];
   fprintf(stderr, "Entering Baseband Reader.\n");
-  while (!me->timeToStopReaderThread)
+  while (!me->reader_must_stop)
   {
     fd_set fds;
     FD_ZERO(&fds);
@@ -802,59 +802,59 @@ void *BasebandDataProcessor::basebandReaderProcedure(void *arg)
 
 void BasebandDataProcessor::start(void)
 {
-  if (streamState == Idle)
+  if (running_state == Idle)
   {
-    timeToStopReaderThread = false;
+    reader_must_stop = false;
     hrfd_txring_set_running(ring, 0, 1);
-    pthread_create(&basebandReaderThread, NULL, basebandReaderProcedure, this);
-    readerThreadStarted = true;
-    streamState = Running;
+    pthread_create(&reader_thread, NULL, reader_main, this);
+    reader_running = true;
+    running_state = Running;
   }
 }
 
 void BasebandDataProcessor::startWithoutReader(void)
 {
-  if (streamState == Idle)
+  if (running_state == Idle)
   {
     hrfd_txring_set_running(ring, 0, 1);
-    readerThreadStarted = false;
-    streamState = Running;
+    reader_running = false;
+    running_state = Running;
   }
 }
 
 void BasebandDataProcessor::stop(void)
 {
-  if (streamState == Running)
+  if (running_state == Running)
   {
-    timeToStopReaderThread = true;
-    if (readerThreadStarted)
+    reader_must_stop = true;
+    if (reader_running)
     {
-      pthread_join(basebandReaderThread, NULL);
-      readerThreadStarted = false;
+      pthread_join(reader_thread, NULL);
+      reader_running = false;
     }
     hrfd_txring_set_running(ring, 0, 0);                 // also drops the ring's synchronisation (:352)
-    streamState = Idle;
+    running_state = Idle;
   }
 }
 
 void BasebandDataProcessor::getIqData(int8_t *bufferPtr,int32_t byteCount)
 {
-  modulateBasebandData(bufferPtr, (uint32_t)byteCount);
+  fill_transfer_buffer(bufferPtr, (uint32_t)byteCount);
 }
 
-void BasebandDataProcessor::modulateBasebandData(int8_t *bufferPtr,uint32_t bufferLength)
+void BasebandDataProcessor::fill_transfer_buffer(int8_t *bufferPtr,uint32_t bufferLength)
 {
   uint32_t outputBufferLength = 0;
-  const int rc = hrfd_txring_read_batch(ring, pcmBlock);
+  const int rc = hrfd_txring_read_batch(ring, one_block);
   if (rc != HRFD_OK) fatal("hrfd_txring_read_batch", rc);
-  switch (modulatorMode)
+  switch (mode_now)
   {
     case None: memset(bufferPtr, 64, bufferLength); break;
-    case Am: amModulatorPtr->acceptData(pcmBlock, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
-    case Fm: fmModulatorPtr->acceptData(pcmBlock, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
-    case WbFm: wbFmModulatorPtr->acceptData(pcmBlock, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
+    case Am: am_mod->acceptData(one_block, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
+    case Fm: fm_mod->acceptData(one_block, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
+    case WbFm: wbfm_mod->acceptData(one_block, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
     case Lsb:
-    case Usb: ssbModulatorPtr->acceptData(pcmBlock, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
+    case Usb: ssb_mod->acceptData(one_block, PCM_BLOCK_SIZE, bufferPtr, &outputBufferLength); break;
     default: break;
   }
 }
@@ -867,8 +867,8 @@ void BasebandDataProcessor::displayInternalInformation(void)
   nprintf(stderr, "Baseband Data Processor Internal Information\n");
   nprintf(stderr, "--------------------------------------------\n");
   static const char *names[] = {"None", "AM", "FM", "WBFM", "LSB", "USB"};
-  nprintf(stderr, "Modulator Mode            : %s\n", names[(int)modulatorMode]);
-  nprintf(stderr, "Stream State              : %s\n", streamState == Running ? "Running" : "Idle");
+  nprintf(stderr, "Modulator Mode            : %s\n", names[(int)mode_now]);
+  nprintf(stderr, "Stream State              : %s\n", running_state == Running ? "Running" : "Idle");
   nprintf(stderr, "PCM Buffers Produced      : %u\n", st[0]);
   nprintf(stderr, "PCM Buffers Consumed      : %u\n", st[1]);
   nprintf(stderr, "PCM Blocks Dropped        : %u\n", st[2]);
