@@ -13,7 +13,7 @@
 //        kFRingTiles 64-sample tiles.  The next unit's loads are issued while the current unit
 //        is computed, across unit boundaries: a stream wave only ever waits when the ring is full.
 //   waves 0..SVC-1 ("service") follow in GENERATIONS of 64 tiles (one per lane): geometric partial
-//        sums, seed, warm-up over the three tiles in front (reads only: v is never overwritten),
+//        sums, seed, warm-up over the two tiles in front (reads only: v is never overwritten),
 //        then the tile itself, where the lane also narrows y to int16 and runs D(8,4) in registers
 //        (WbFmDemodulator.cc:468-476).  Neither y nor its int16 form ever goes to LDS; a lane keeps
 //        16 U samples.  Generations complete in order (b_done): verification against the left
@@ -24,7 +24,9 @@
 // A run (consecutive blocks of one channel) is one stream: positions count from the run's first
 // sample, blocks only matter for the squelch magnitude and the cross-block check values.  A run
 // that does not start the call re-derives kFHal samples of history like the other kernels do and
-// is checked by k_rx_epilogue (y at block-relative position -705).
+// is checked by finish_channel (y at block-relative position -705).  The kernel finishes its own
+// channels: the last wave of a channel's last workgroup runs finish_channel -- from LDS, without a
+// memory round trip, when the channel was one workgroup's (`local`).
 //
 // Mirrors IqDataProcessor::reduceSampleRate (IqDataProcessor.cc:429-500), upconvertByFsOver4
 // (:771-815), SignalDetector::detectSignal (SignalDetector.cc:205-274),
