@@ -504,7 +504,7 @@ def main():
                 "measured_stream_copy_GBps": round(copy_gbs, 1),
                 "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                 "kernel": ("hrfd::k_rx_wbfm_flow<4> (one persistent workgroup per CU, LDS ring, first-octant-table atan2)"
-                           if args.workload == "wbfm" else "all demodulator kernels of a step"),
+                           if args.workload == "wbfm" else "all demodulator kernels of a step: first kernel's start to the later of the two streams' last kernel end (HIP events on both)"),
                 "kernel_ms_mean": round(mean_ms, 4),
                 "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                 "kernel_ms_median": round(float(np.median(kernel_ms)), 4),

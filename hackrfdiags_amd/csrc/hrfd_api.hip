@@ -196,6 +196,7 @@ struct hrfd_rx
   hipEvent_t ev_fir[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
   hipEvent_t ev_rest = nullptr, ev_fin = nullptr;   // mixed bank: the other modes' kernels are all submitted / their channels finished
   uint32_t ev_launches = 0;
+  std::vector<uint8_t> ev_side_used;    // per slot: the side stream ran kernels in that launch
 
   // test hooks
   unsigned long long *d_dbg = nullptr;  // optional phase stamps (hrfd_rx_debug_stamps)
@@ -546,22 +547,32 @@ extern "C" int hrfd_rx_debug_enable_timing(hrfd_rx *h, int slots)
   }
   h->ev.clear();
   h->ev_launches = 0;
-  for (int i = 0; i < 2 * slots; i++)
+  // per slot: the launch stream's start and end, and the side stream's end (a bank of several modes)
+  for (int i = 0; i < 3 * slots; i++)
   {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     h->ev.push_back(e);
   }
+  h->ev_side_used.assign((size_t)slots, 0);
   return HRFD_OK;
 }
 
 extern "C" int hrfd_rx_debug_kernel_ms(hrfd_rx *h, int slot, float *ms)
 {
-  if (h == nullptr || ms == nullptr || slot < 0 || (size_t)(2 * slot + 1) >= h->ev.size())
+  if (h == nullptr || ms == nullptr || slot < 0 || (size_t)(3 * slot + 2) >= h->ev.size())
   {
     return fail(HRFD_EINVAL, "timing slot out of range");
   }
-  HIP_TRY(hipEventElapsedTime(ms, h->ev[2 * slot], h->ev[2 * slot + 1]));
+  // From the launch's first kernel to the end of its last one: the later of the two streams' ends.  (The join of the
+  // side stream into the launch stream comes behind both and is the caller's time between steps, not the kernels'.)
+  HIP_TRY(hipEventElapsedTime(ms, h->ev[3 * slot], h->ev[3 * slot + 1]));
+  if (h->ev_side_used[(size_t)slot])
+  {
+    float side_ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&side_ms, h->ev[3 * slot], h->ev[3 * slot + 2]));
+    *ms = std::max(*ms, side_ms);
+  }
   return HRFD_OK;
 }
 
@@ -942,12 +953,21 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.sticky = h->d_counters;
   bool flow_ran = false;
 
-  const size_t ev_slots = h->ev.size() / 2;
+  const size_t ev_slots = h->ev.size() / 3;
   const size_t ev_slot = ev_slots ? (h->ev_launches % ev_slots) : 0;
   if (ev_slots)
   {
-    HIP_TRY(hipEventRecord(h->ev[2 * ev_slot], s));
+    HIP_TRY(hipEventRecord(h->ev[3 * ev_slot], s));
+    h->ev_side_used[ev_slot] = 0;
   }
+  auto side_stamp = [&]() -> hipError_t {               // behind every kernel that goes to the side stream
+    if (!ev_slots)
+    {
+      return hipSuccess;
+    }
+    h->ev_side_used[ev_slot] = 1;
+    return hipEventRecord(h->ev[3 * ev_slot + 2], h->side);
+  };
   // per-mode dispatch (BASELINE config 3): AM, SSB, FM first, WBFM / NONE last.  The 8 kS/s
   // recurrences of AM and SSB are one workgroup per channel (a quarter of the chip for a 64-channel
   // quarter of the bank): they go to a side stream behind their mode's front kernel and run beside
@@ -974,6 +994,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fir[0], 0));
     hipLaunchKernelGGL(k_rx_post<14>, dim3(n), dim3(256), 0, h->side, P);
     HIP_TRY(hipEventRecord(h->ev_post[0], h->side));
+    HIP_TRY(side_stamp());
     n_side |= 1;
     HIP_TRY(hipGetLastError());
   }
@@ -1054,6 +1075,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
           F.n_channels = list_count[6];
           hipLaunchKernelGGL(k_rx_finish, dim3(F.n_channels), dim3(64), 0, h->side, F);
           HIP_TRY(hipEventRecord(h->ev_fin, h->side));
+          HIP_TRY(side_stamp());
           n_side = 4;                                      // the side stream is in order: this event covers the others
         }
         P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here
@@ -1084,6 +1106,11 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     }
     HIP_TRY(hipGetLastError());
   }
+  if (ev_slots)
+  {
+    HIP_TRY(hipEventRecord(h->ev[3 * ev_slot + 1], s));    // behind the launch stream's last kernel, in front of the join
+    h->ev_launches++;
+  }
   for (int i = 0; i < 2; i++)
   {
     if (n_side & (1 << i))
@@ -1094,11 +1121,6 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   if (n_side & 4)
   {
     HIP_TRY(hipStreamWaitEvent(s, h->ev_fin, 0));
-  }
-  if (ev_slots)
-  {
-    HIP_TRY(hipEventRecord(h->ev[2 * ev_slot + 1], s));
-    h->ev_launches++;
   }
 
   // the channels that no kernel finished by itself (finish_channel): everything but the WBFM channels when
