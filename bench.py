@@ -357,7 +357,7 @@ def main():
                          "(config 4: 4096 channels over 8 GPUs), 1024 for the modulator workloads (config 5)")
     ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
     ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")
-    ap.add_argument("--workload", choices=["wbfm", "mixed", "ssbmod", "ammod", "fmmod", "wbfmmod", "ingest"], default="wbfm",
+    ap.add_argument("--workload", choices=["wbfm", "mixed", "am", "fm", "ssb", "ssbmod", "ammod", "fmmod", "wbfmmod", "ingest"], default="wbfm",
                     help="wbfm = BASELINE config 2 (the headline); mixed = config 3 (AM+FM+WBFM+SSB bank, "
                          "per-mode dispatch); ssbmod = config 5 (SSB modulator, 8-stage x256 interpolator)")
     ap.add_argument("--scatter", action="store_true",
@@ -406,6 +406,8 @@ def main():
     torch.cuda.synchronize()                             # inputs and outputs were written on torch's stream
     rx = api.Rx(C, device=local_rank)
     rx.set_mode(api.WBFM)
+    if args.workload in ("am", "fm", "ssb"):
+        rx.set_mode({"am": api.AM, "fm": api.FM, "ssb": api.LSB}[args.workload])     # a bank of one of the other modes
     if args.workload == "mixed":
         # BASELINE config 3: equal quarters of AM, FM, WBFM and SSB channels
         for c in range(C):
@@ -480,6 +482,8 @@ def main():
             "config": {
                 "workload": (f"{C} concurrent WBFM channels per GPU at 2.048 MS/s (BASELINE config 2), "
                              if args.workload == "wbfm" else
+                             f"{C} concurrent {args.workload.upper()} demodulator channels per GPU (not a BASELINE config), "
+                             if args.workload in ("am", "fm", "ssb") else
                              f"mixed-mode bank {C // 4} AM + {C // 4} FM + {C // 4} WBFM + {C // 4} SSB per GPU "
                              f"(BASELINE config 3), ") +
                             (f"= {world * C} channels over {world} GPUs (BASELINE config 4 asks for 4096 over 8), "
