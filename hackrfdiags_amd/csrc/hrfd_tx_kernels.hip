@@ -93,6 +93,13 @@ __device__ __forceinline__ void hb4(int xn, int xm1, int &y0, int &y1)
   y0 = ((1 << 14) + H * (xn + xm1)) >> 15;
   y1 = (xn + 1) >> 1;
 }
+// the same stage with its outputs as twice the Q15 numerators: z >> 16 is the output, byte 2 of z its low byte
+template <int H>
+__device__ __forceinline__ void hb4z(int xn, int xm1, int &z0, int &z1)
+{
+  z0 = (1 << 15) + 2 * H * (xn + xm1);
+  z1 = (xn << 15) + (1 << 15);
+}
 static_assert(Q_INTERP_HB3[0] == Q_INTERP_HB3[2] && Q_INTERP_HB3[1] == 16384 && Q_INTERP_HB3[3] == 0, "hb4 relies on the table's shape");
 static_assert(Q_INTERP_HB2[0] == Q_INTERP_HB2[2] && Q_INTERP_HB2[1] == 16384 && Q_INTERP_HB2[3] == 0, "hb4 relies on the table's shape");
 static_assert(Q_INTERP_HB1[0] == Q_INTERP_HB1[2] && Q_INTERP_HB1[1] == 16384 && Q_INTERP_HB1[3] == 0, "hb4 relies on the table's shape");
@@ -384,7 +391,8 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   int8_t *out = M.out + ((size_t)c * M.n + t0) * 512;
   for (int j = tid; j < 32 * kModTile; j += kModThreads)
   {
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    uint32_t w[4];
+    int z[2][8];
 #pragma unroll
     for (int rail = 0; rail < 2; rail++)
     {
@@ -400,18 +408,21 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       (void)p0;
       hb4<Q_INTERP_HB2[0]>(a0, p1, b0, b1);               // y7[4j], y7[4j+1]
       hb4<Q_INTERP_HB2[0]>(a1, a0, b2, b3);               // y7[4j+2], y7[4j+3]
-      // stage 8 (HB1): y8[8j .. 8j+7], (int8_t) narrowing (:607-610)
-      int y[8];
-      hb4<Q_INTERP_HB1[0]>(b0, q1, y[0], y[1]);
-      hb4<Q_INTERP_HB1[0]>(b1, b0, y[2], y[3]);
-      hb4<Q_INTERP_HB1[0]>(b2, b1, y[4], y[5]);
-      hb4<Q_INTERP_HB1[0]>(b3, b2, y[6], y[7]);
+      // stage 8 (HB1): y8[8j .. 8j+7], (int8_t) narrowing (:607-610).  Only the low byte of an output is kept, so the
+      // outputs are left as TWICE their Q15 numerators -- the byte wanted is then byte 2 of the word, which v_perm picks
+      // from two words at a time: no shift and no mask per output (hb4z)
+      hb4z<Q_INTERP_HB1[0]>(b0, q1, z[rail][0], z[rail][1]);
+      hb4z<Q_INTERP_HB1[0]>(b1, b0, z[rail][2], z[rail][3]);
+      hb4z<Q_INTERP_HB1[0]>(b2, b1, z[rail][4], z[rail][5]);
+      hb4z<Q_INTERP_HB1[0]>(b3, b2, z[rail][6], z[rail][7]);
+    }
 #pragma unroll
-      for (int k = 0; k < 8; k++)
-      {
-        // byte 2k (I) or 2k+1 (Q) of the lane's 16 output bytes
-        w[k >> 1] |= ((uint32_t)y[k] & 0xffu) << (8 * (2 * (k & 1) + rail));
-      }
+    for (int d = 0; d < 4; d++)
+    {
+      // output dword d = I[2d], Q[2d], I[2d+1], Q[2d+1]: byte 2 of z[0][2d], z[1][2d], z[0][2d+1], z[1][2d+1]
+      const uint32_t lo = __builtin_amdgcn_perm((uint32_t)z[1][2 * d], (uint32_t)z[0][2 * d], 0x0c0c0602u);
+      const uint32_t hi = __builtin_amdgcn_perm((uint32_t)z[1][2 * d + 1], (uint32_t)z[0][2 * d + 1], 0x06020c0cu);
+      w[d] = lo | hi;
     }
     if (j < 32 * valid)
     {
