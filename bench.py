@@ -69,19 +69,66 @@ def make_random_batch(channels, blocks, device, first_channel=0):
     return torch.randint(-128, 128, (channels, blocks, BLOCK), dtype=torch.int8, device=device, generator=gen)
 
 
-def cpu_baseline(seconds, threads):
-    """Reference CPU chain (IqDataProcessor::acceptIqData in WBFM mode), one
-    channel per thread, each looping over the same 8-block FM test signal."""
+def host_core_counts():
+    """(hardware threads this process may run on, physical cores among them) from the affinity mask and
+    /sys topology; physical == threads when the topology cannot be read."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/core_id") as f:
+                core = f.read().strip()
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id") as f:
+                pkg = f.read().strip()
+            cores.add((pkg, core))
+        except OSError:
+            return len(cpus), len(cpus)
+    return len(cpus), len(cores)
+
+
+def cpu_baseline(seconds):
+    """The reference's own CPU chain (IqDataProcessor::acceptIqData in WBFM mode, oracle/_ref compiled from the
+    reference sources), one channel per host thread as DataConsumer.cc:319-351 runs it: std::threads inside the
+    harness, one IqDataProcessor + demodulators per thread, no allocation and no interpreter in the loop
+    (ref_bench_rx).  One run on every hardware thread of the box, one on ONE thread (BASELINE config 1's shape)."""
     from hackrfdiags_amd import synth
     from tests import reflib
-    kind = "reference"
+    nb = 8
+    x = synth.make_input("fmtone", 0, nb).reshape(nb, BLOCK)
+    threads, physical = host_core_counts()
     try:
         eng = reflib.Ref()
     except (FileNotFoundError, OSError):
-        eng = reflib.Oracle()          # our restatement, if the prebuilt reference did not travel
-        kind = "port"
-    nb = 8
-    x = synth.make_input("fmtone", 0, nb).reshape(nb, BLOCK)
+        return cpu_baseline_port(seconds, threads, x)
+    n1, dt1, _ = eng.bench_rx(reflib.WBFM, 1, min(3.0, seconds), x)
+    single = n1 * (BLOCK // 2) / dt1 / 1e6
+    n, dt, pcm = eng.bench_rx(reflib.WBFM, threads, seconds, x)
+    assert pcm == n * 512, "the reference chain did not produce 512 PCM samples per block"
+    value = n * (BLOCK // 2) / dt / 1e6
+    return {
+        "value": round(value, 2),
+        "unit": "MSamples/s",
+        "cores": threads,
+        "threads": threads,
+        "physical_cores": physical,
+        "kind": "reference",
+        "single_thread_value": round(single, 2),
+        "scaling_vs_single_thread": round(value / single, 1),
+        "efficiency_vs_physical_cores": round(value / (single * physical), 3),
+        "sample": f"{n} blocks of 262144 B (FM test signal, WBFM mode) over {dt:.1f} s on {threads} std::thread(s), "
+                  f"one IqDataProcessor + demodulators per thread; single thread: {n1} blocks over {dt1:.1f} s",
+    }
+
+
+def cpu_baseline_port(seconds, threads, x):
+    """Fallback when the prebuilt reference did not travel: our CPU restatement (oracle/, plain C, it allocates per
+    call), one channel per Python thread (ctypes releases the GIL inside the call)."""
+    from tests import reflib
+    eng = reflib.Oracle()
+    nb = x.shape[0]
     handles = []
     for _ in range(threads):
         h = eng.rx()
@@ -108,31 +155,30 @@ def cpu_baseline(seconds, threads):
     dt = time.perf_counter() - t0
     blocks = sum(counts)
     return {
-        "value": round(blocks * (BLOCK // 2) / dt / 1e6, 2),
-        "unit": "MSamples/s",
-        "cores": threads,
-        "kind": kind,
-        "sample": f"{blocks} blocks of 262144 B (FM test signal, WBFM mode) over {dt:.1f} s, "
-                  f"{threads} thread(s), one channel per thread",
+        "value": round(blocks * (BLOCK // 2) / dt / 1e6, 2), "unit": "MSamples/s", "cores": threads, "kind": "port",
+        "sample": f"{blocks} blocks of 262144 B (FM test signal, WBFM mode) over {dt:.1f} s, {threads} Python "
+                  f"thread(s) around the C restatement, one channel per thread",
     }
 
 
-def bench_ssbmod(args, api, device, rank, world, dist):
-    """BASELINE config 5: `channels` SSB modulators, 512 PCM samples (64 ms) per block,
-    `blocks` blocks per step -> int8 IQ at 2.048 MS/s.  Unit of work: one output IQ sample."""
-    from hackrfdiags_amd import shard
-    C, B = args.channels, args.blocks
+MOD_KINDS = {"ssbmod": ("MOD_SSB", "SSB"), "ammod": ("MOD_AM", "AM"), "fmmod": ("MOD_FM", "FM"), "wbfmmod": ("MOD_WBFM", "WBFM")}
+MOD_KERNELS = {"ssbmod": "hrfd::k_mod<1>",
+               "wbfmmod": "hrfd::k_mod<101> (x32 + Nco step), k_phase_scan, k_wb_rails, hrfd::k_mod<102> (x8)"}
+
+
+def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle, rank, world, extras=True):
+    """`C` modulators of one kind, `B` blocks of 512 PCM samples (64 ms) each per step -> int8 IQ at 2.048 MS/s
+    (BASELINE config 5 for 1024 SSB channels).  Unit of work: one output IQ sample."""
     n = 512 * B
     gen = torch.Generator(device=device)
     gen.manual_seed(7 + rank)
     pcm = torch.randint(-32768, 32768, (C, n), dtype=torch.int16, device=device, generator=gen)
     out = torch.empty((C, 512 * n), dtype=torch.int8, device=device)
     torch.cuda.synchronize()                             # the PCM was generated on torch's stream
-    kind = {"ssbmod": api.MOD_SSB, "ammod": api.MOD_AM, "fmmod": api.MOD_FM, "wbfmmod": api.MOD_WBFM}[args.workload]
-    kname = {"ssbmod": "SSB", "ammod": "AM", "fmmod": "FM", "wbfmmod": "WBFM"}[args.workload]
-    m = api.Mod(kind, C, device=device.index)
+    kind, kname = MOD_KINDS[workload]
+    m = api.Mod(getattr(api, kind), C, device=device.index)
     stream = torch.cuda.Stream(device=device)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
     def step(i=None):
         if i is not None:
@@ -141,7 +187,7 @@ def bench_ssbmod(args, api, device, rank, world, dist):
         if i is not None:
             ev[i][1].record(stream)
 
-    for _ in range(max(0, SETTLE_STEPS - args.warmup) + args.warmup):   # see SETTLE_STEPS
+    for _ in range(settle + warmup):
         step()
     m.sync()
     torch.cuda.synchronize()
@@ -149,39 +195,51 @@ def bench_ssbmod(args, api, device, rank, world, dist):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     stream.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device)
+    m.sync()                                             # raises if a k_phase_scan wait expired
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     samples = C * n * 256
-    value = world * samples * args.steps / elapsed / 1e6
     algo_bytes = C * n * (2 + 512)
     mean_ms = float(np.mean(kernel_ms))
     achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
-    fill = None
-    if rank == 0 and not args.no_extras:
-        fill = stream_fill_gbs(device, out)
+    fill = stream_fill_gbs(device, out) if (rank == 0 and extras) else None
+    del out, pcm
+    return {
+        "kname": kname, "value": world * samples * steps / elapsed / 1e6, "ms_per_step": 1e3 * elapsed / steps,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "measured_stream_fill_GBps": None if fill is None else round(fill, 1),
+                     "frac_of_measured_fill": None if fill is None else round(achieved / fill, 4),
+                     "kernel": MOD_KERNELS.get(workload, "k_am_rails / k_fm_phase + k_fm_rails, then hrfd::k_mod<100>"),
+                     "kernel_ms_mean": round(mean_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
+                     "algorithmic_bytes_per_launch": algo_bytes},
+    }
+
+
+def bench_mod(args, api, device, rank, world, dist):
+    from hackrfdiags_amd import shard
+    C, B = args.channels, args.blocks
+    settle = max(0, SETTLE_STEPS - args.warmup)
+    r = measure_mod(api, shard, device, dist, args.workload, C, B, args.steps, args.warmup, settle, rank, world,
+                    extras=not args.no_extras)
+    kname = r["kname"]
     if rank == 0:
         print(json.dumps({
             "metric": f"IQ MSamples/s modulated (8 kS/s PCM -> 2.048 MS/s int8 IQ, {kname}) per GPU; % HBM roofline",
-            "value": round(value, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "value": round(r["value"], 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "settle_steps": settle, "ms_per_step": round(r["ms_per_step"], 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int16 PCM -> Q15 int32 -> int8 IQ", "data": "synthetic",
             "config": {"workload": f"{C} {kname} modulator channels per GPU (BASELINE config 5" + ("" if (C, args.workload) == (1024, "ssbmod") else
                                    " is 1024 SSB channels") + f"), {B} blocks of 512 PCM "
                                    f"samples per step, 8-stage x256 half-band interpolator", "channels_per_gpu": C,
                        "blocks_per_step": B},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "measured_stream_fill_GBps": None if fill is None else round(fill, 1),
-                         "frac_of_measured_fill": None if fill is None else round(achieved / fill, 4),
-                         "kernel": {"ssbmod": "hrfd::k_mod<1>", "wbfmmod": "hrfd::k_mod<101> (x32 + Nco step), k_phase_scan, k_wb_rails, hrfd::k_mod<102> (x8)"}.get(
-                             args.workload, "k_am_rails / k_fm_phase + k_fm_rails, then hrfd::k_mod<100>"),
-                         "kernel_ms_mean": round(mean_ms, 4), "algorithmic_bytes_per_launch": algo_bytes},
+            "roofline": r["roofline"],
         }), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -346,6 +404,179 @@ def single_block_latency_ms(api, device):
     return round(1e3 * float(np.median(ts[4:])), 3)
 
 
+def make_quiet_batch(channels, blocks, device, first_channel=0):
+    """A channel with no signal: uniform noise in [-1, 1] (block-mean magnitude 1 -> about -42 dBFS)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(99 + first_channel)
+    return torch.randint(-1, 2, (channels, blocks, BLOCK), dtype=torch.int8, device=device, generator=gen)
+
+
+def rx_workload_text(workload, C, B, world, signal, scatter, quiet_fraction=0.0, threshold=None, iqdump=False):
+    if workload == "wbfm":
+        if world > 1 and world * C == 4096:
+            head = f"{world * C} WBFM channels sharded over {world} GPUs, {C} per GPU (BASELINE config 4), "
+        elif world > 1:
+            head = (f"{C} concurrent WBFM channels per GPU at 2.048 MS/s = {world * C} channels over {world} GPUs "
+                    f"(BASELINE config 4's shape: it asks for 4096 over 8), ")
+        elif C == 256:
+            head = f"{C} concurrent WBFM channels per GPU at 2.048 MS/s (BASELINE config 2), "
+        else:
+            head = f"{C} concurrent WBFM channels per GPU at 2.048 MS/s (BASELINE config 2 is 256; the north star's target is >= 1000), "
+    elif workload in ("am", "fm", "ssb"):
+        head = f"{C} concurrent {workload.upper()} demodulator channels per GPU (not a BASELINE config), "
+    else:
+        head = f"mixed-mode bank {C // 4} AM + {C // 4} FM + {C // 4} WBFM + {C // 4} SSB per GPU (BASELINE config 3), "
+    tail = f"{B} blocks of 262144 B per channel per step, input resident in HBM"
+    if quiet_fraction > 0:
+        tail += f", {quiet_fraction:.0%} of the channels carry no signal under a squelch threshold of {threshold} dBFS (their gates close)"
+    if iqdump:
+        tail += ", the 256 kS/s stream of `enable iqdump` written out as well"
+    if scatter and world > 1:
+        tail += ", IQ scattered from rank 0 over RCCL each step"
+    return head + tail
+
+
+def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmup, settle, rank, world,
+               scatter=False, quiet_fraction=0.0, threshold=None, iqdump=False, idle_s=0.0):
+    """K timed steps of the receive path over one resident batch [C][B][262144]; returns the figures of a bench line.
+    The dominant kernels' time comes from HIP events the library records on its launch stream(s) around the
+    demodulator kernels of every launch (hrfd_rx_debug_enable_timing)."""
+    gen = make_fm_batch if signal == "fmtone" else make_random_batch
+    iq = gen(C, B, device, first_channel=rank * C)
+    n_quiet = int(round(C * quiet_fraction))
+    quiet = []
+    if n_quiet:
+        # every (C / n_quiet)-th channel is silent
+        quiet = [int(i * C / n_quiet) for i in range(n_quiet)]
+        q = make_quiet_batch(n_quiet, B, device, first_channel=rank * C)
+        iq[torch.tensor(quiet, device=device)] = q
+        del q
+    pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=device)
+    n_pcm = torch.zeros((C, B), dtype=torch.int32, device=device)
+    iq256 = torch.zeros((C, B, BLOCK // 8), dtype=torch.int8, device=device) if iqdump else None
+    torch.cuda.synchronize()                             # inputs and outputs were written on torch's stream
+    rx = api.Rx(C, device=device.index)
+    rx.set_mode(api.WBFM)
+    if workload in ("am", "fm", "ssb"):
+        rx.set_mode({"am": api.AM, "fm": api.FM, "ssb": api.LSB}[workload])     # a bank of one of the other modes
+    if workload == "mixed":
+        # BASELINE config 3: equal quarters of AM, FM, WBFM and SSB channels
+        for c in range(C):
+            rx.set_mode([api.AM, api.FM, api.WBFM, api.LSB][(4 * c) // C], channel=c)
+    if threshold is not None:
+        rx.set_threshold(int(threshold))
+    stream = torch.cuda.Stream(device=device)
+    iq_root = None
+    scatter = scatter and world > 1
+    if scatter and rank == 0:
+        # the north star's "per-channel scatter": every rank's IQ starts on rank 0, in ONE source buffer built once
+        iq_root = torch.cat([gen(C, B, device, first_channel=r * C) for r in range(world)], dim=0).contiguous()
+    rx.debug_enable_timing(max(steps, 1))
+
+    def step():
+        if scatter:
+            with torch.cuda.stream(stream):
+                shard.scatter_iq(iq_root, iq, world * C)     # one group of sends out of rank 0, straight into `iq`
+        rx.process_device(iq.data_ptr(), B * BLOCK, BLOCK, B, pcm.data_ptr(), d_n_pcm=n_pcm.data_ptr(),
+                          d_iq256=None if iq256 is None else iq256.data_ptr(), stream=stream.cuda_stream)
+
+    if idle_s > 0:
+        torch.cuda.synchronize()
+        time.sleep(idle_s)                               # the clock governor falls back to its idle state
+    for _ in range(settle + warmup):
+        step()
+    rx.sync()
+    rx.debug_enable_timing(max(steps, 1))               # restart the slot counter
+
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    stream.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, device)
+
+    rx.sync()
+    counters = rx.debug_counters()
+    kernel_ms = [rx.debug_kernel_ms(i) for i in range(steps)]
+    produced = int(n_pcm.sum().item())
+    # a closed gate produces no PCM (the tracker lets one "tail" block through after a signal: none here, the quiet
+    # channels are quiet from the start)
+    expect = (C - n_quiet) * B * 512
+    samples_per_step = C * B * (BLOCK // 2)
+    algo_bytes = C * B * (BLOCK + 1024 + 4) + (C * B * (BLOCK // 8) if iqdump else 0)   # SURVEY 8(d): 2.0078 B / IQ sample
+    mean_ms = float(np.mean(kernel_ms))
+    achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
+    out = {
+        "value": world * samples_per_step * steps / elapsed / 1e6,            # MSamples/s, whole job
+        "ms_per_step": 1e3 * elapsed / steps, "mean_ms": mean_ms, "achieved": achieved,
+        "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_median": float(np.median(kernel_ms)),
+        "algo_bytes": algo_bytes, "counters": counters, "quiet_channels": n_quiet,
+        "pcm_produced": produced, "pcm_expected": expect,
+    }
+    rx.close()
+    del iq, pcm, n_pcm, iq256, iq_root
+    return out
+
+
+def brief(r, text, extra=None):
+    """one entry of the bench line's `also` object"""
+    d = {"workload": text, "ms_per_step": round(r["ms_per_step"], 4), "value_MSamples_per_s": round(r["value"], 1)}
+    if "roofline" in r:                                  # modulators
+        d["kernel_ms_mean"] = r["roofline"]["kernel_ms_mean"]
+        d["roofline_frac"] = r["roofline"]["frac"]
+        d["algorithmic_bytes_per_launch"] = r["roofline"]["algorithmic_bytes_per_launch"]
+    else:
+        d["kernel_ms_mean"] = round(r["mean_ms"], 4)
+        d["kernel_ms_min"] = round(r["kernel_ms_min"], 4)
+        d["roofline_frac"] = round(r["achieved"] / HBM_PEAK_GBS, 4)
+        d["algorithmic_bytes_per_launch"] = r["algo_bytes"]
+        d["uncommitted_launches"] = r["counters"][5]
+        if r["counters"][5] != 0:
+            d["invalid"] = f"{r['counters'][5]} launch(es) were not committed"
+        elif r["pcm_produced"] != r["pcm_expected"]:
+            d["invalid"] = f"PCM samples produced {r['pcm_produced']} != {r['pcm_expected']}"
+    if extra:
+        d.update(extra)
+    return d
+
+
+def also_lines(api, shard, device, args):
+    """The other BASELINE configurations that fit one GPU, the >= 1000-channel target, the worst-case input and the
+    cold-clock figure, each a short measurement of its own (N = 1 only; SURVEY 8(d), BASELINE.json configs 3 and 5)."""
+    K, W = 40, 10
+    settle = max(0, SETTLE_STEPS - W)
+    common = dict(steps=K, warmup=W, settle=settle, rank=0, world=1)
+    out = {}
+
+    def rx(name, **kw):
+        text_kw = {k: kw[k] for k in ("quiet_fraction", "threshold", "iqdump") if k in kw}
+        r = measure_rx(api, shard, device, None, **{**common, **kw})
+        out[name] = brief(r, rx_workload_text(kw["workload"], kw["C"], kw["B"], 1, kw["signal"], False, **text_kw),
+                          {"steps": kw.get("steps", K), "warmup": kw.get("warmup", W), "settle_steps": kw.get("settle", settle)})
+        return r
+
+    rx("wbfm_1024x16", workload="wbfm", C=1024, B=16, signal="fmtone")
+    rx("mixed_256x16", workload="mixed", C=256, B=16, signal="fmtone")
+    rx("wbfm_256x16_random", workload="wbfm", C=256, B=16, signal="random")
+    # what a caller sees that launches into an idle GPU (the reference's cadence is one block per 64 ms): the driver's
+    # own warm-up, no settling launches, after a second of idleness
+    rx("wbfm_256x16_unsettled", workload="wbfm", C=256, B=16, signal="fmtone", steps=min(args.steps, 20),
+       warmup=min(args.warmup, 5), settle=0, idle_s=1.0)
+    rx("wbfm_256x16_quiet25", workload="wbfm", C=256, B=16, signal="fmtone", quiet_fraction=0.25, threshold=-30)
+    rx("wbfm_256x16_iqdump", workload="wbfm", C=256, B=16, signal="fmtone", iqdump=True)
+    for name, wl, C in (("ssbmod_1024x16", "ssbmod", 1024), ("wbfmmod_1024x16", "wbfmmod", 1024)):
+        r = measure_mod(api, shard, device, None, wl, C, 16, K, W, settle, 0, 1, extras=False)
+        out[name] = brief(r, f"{C} {r['kname']} modulator channels, 16 blocks of 512 PCM samples per step"
+                          + (" (BASELINE config 5)" if wl == "ssbmod" else ""), {"steps": K, "warmup": W, "settle_steps": settle})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -362,16 +593,20 @@ def main():
                          "per-mode dispatch); ssbmod = config 5 (SSB modulator, 8-stage x256 interpolator)")
     ap.add_argument("--scatter", action="store_true",
                     help="N > 1 only: all IQ starts on rank 0 and is scattered over RCCL inside the timed region")
+    ap.add_argument("--quiet-fraction", type=float, default=0.0,
+                    help="this fraction of the channels carries no signal (with --threshold: their squelch gates close)")
+    ap.add_argument("--threshold", type=int, default=None, help="squelch threshold in dBFS (setSignalDetectThreshold)")
+    ap.add_argument("--iqdump", action="store_true", help="also write the 256 kS/s stream (`enable iqdump`)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="leave out the end-to-end and single-block latency figures (profiling runs: only the headline "
-                         "launches in the kernel statistics)")
+                    help="leave out the end-to-end and single-block latency figures and the `also` measurements "
+                         "(profiling runs: only the headline launches in the kernel statistics)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.channels <= 0:
-        args.channels = 1024 if args.workload in ("ssbmod", "ammod", "fmmod", "wbfmmod") else (256 if world == 1 else 512)
+        args.channels = 1024 if args.workload in MOD_KINDS else (256 if world == 1 else 512)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -387,82 +622,35 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if rehearse:
+            if args.scatter:
+                raise SystemExit("--scatter needs RCCL: gloo cannot send device tensors (rehearsal mode)")
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
 
     from hackrfdiags_amd import api, shard
 
-    if args.workload in ("ssbmod", "ammod", "fmmod", "wbfmmod"):
-        return bench_ssbmod(args, api, device, rank, world, dist)
+    if args.workload in MOD_KINDS:
+        return bench_mod(args, api, device, rank, world, dist)
     if args.workload == "ingest":
         return bench_ingest(args, api, device, rank, world, dist)
 
     C, B = args.channels, args.blocks
-    gen = make_fm_batch if args.signal == "fmtone" else make_random_batch
-    iq = gen(C, B, device, first_channel=rank * C)
-    pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=device)
-    n_pcm = torch.zeros((C, B), dtype=torch.int32, device=device)
-    torch.cuda.synchronize()                             # inputs and outputs were written on torch's stream
-    rx = api.Rx(C, device=local_rank)
-    rx.set_mode(api.WBFM)
-    if args.workload in ("am", "fm", "ssb"):
-        rx.set_mode({"am": api.AM, "fm": api.FM, "ssb": api.LSB}[args.workload])     # a bank of one of the other modes
-    if args.workload == "mixed":
-        # BASELINE config 3: equal quarters of AM, FM, WBFM and SSB channels
-        for c in range(C):
-            rx.set_mode([api.AM, api.FM, api.WBFM, api.LSB][(4 * c) // C], channel=c)
-    stream = torch.cuda.Stream(device=device)
-    iq_root = None
-    scatter = args.scatter and world > 1
-    if scatter and rank == 0:
-        # the north star's "per-channel scatter": every rank's IQ starts on rank 0, in ONE source buffer built once
-        iq_root = torch.cat([gen(C, B, device, first_channel=r * C) for r in range(world)], dim=0).contiguous()
-    rx.debug_enable_timing(max(args.steps, 1))
-
-    def step():
-        if scatter:
-            with torch.cuda.stream(stream):
-                shard.scatter_iq(iq_root, iq, world * C)     # one group of sends out of rank 0, straight into `iq`
-        rx.process_device(iq.data_ptr(), B * BLOCK, BLOCK, B, pcm.data_ptr(), d_n_pcm=n_pcm.data_ptr(),
-                          stream=stream.cuda_stream)
-
     # The clock governor needs ~25 ms of this load before it holds its clock (profiles/README.md): when
     # the caller asks for a short warm-up, untimed "settle" launches come first so that the K timed
-    # steps are measured at the clock a long-running stream sees, whatever W is.
+    # steps are measured at the clock a long-running stream sees, whatever W is.  (`also.wbfm_256x16_unsettled`
+    # is the figure without them.)
     settle = max(0, SETTLE_STEPS - args.warmup)
-    for _ in range(settle + args.warmup):
-        step()
-    rx.sync()
-    rx.debug_enable_timing(max(args.steps, 1))          # restart the slot counter
-
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    stream.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, device)
-
-    rx.sync()
-    counters = rx.debug_counters()
-    kernel_ms = [rx.debug_kernel_ms(i) for i in range(args.steps)]
-    produced = int(n_pcm.sum().item())
-    assert produced == C * B * 512, f"PCM samples produced {produced} != {C * B * 512}"
-
+    r = measure_rx(api, shard, device, dist, workload=args.workload, C=C, B=B, signal=args.signal, steps=args.steps,
+                   warmup=args.warmup, settle=settle, rank=rank, world=world, scatter=args.scatter,
+                   quiet_fraction=args.quiet_fraction, threshold=args.threshold, iqdump=args.iqdump)
+    counters = r["counters"]
+    assert r["pcm_produced"] == r["pcm_expected"], f"PCM samples produced {r['pcm_produced']} != {r['pcm_expected']}"
     traffic, ptag = pmc_traffic_bytes(args, C, B)
+    if args.quiet_fraction > 0 or args.iqdump:
+        traffic = None
     copy_gbs = stream_copy_gbs(device)
-    samples_per_step = C * B * (BLOCK // 2)
-    value = world * samples_per_step * args.steps / elapsed / 1e6            # MSamples/s, whole job
-    algo_bytes = C * B * (BLOCK + 1024 + 4)                                   # 2.0078 B / IQ sample
-    mean_ms = float(np.mean(kernel_ms))
-    achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
+    value, achieved = r["value"], r["achieved"]
 
     if rank == 0:
         line = {
@@ -473,25 +661,18 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "settle_steps": settle,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "ms_per_step": round(r["ms_per_step"], 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "int8 IQ -> Q15 int16/int32 + f32 recurrence -> int16 PCM",
             "data": "synthetic",
             "config": {
-                "workload": (f"{C} concurrent WBFM channels per GPU at 2.048 MS/s (BASELINE config 2), "
-                             if args.workload == "wbfm" else
-                             f"{C} concurrent {args.workload.upper()} demodulator channels per GPU (not a BASELINE config), "
-                             if args.workload in ("am", "fm", "ssb") else
-                             f"mixed-mode bank {C // 4} AM + {C // 4} FM + {C // 4} WBFM + {C // 4} SSB per GPU "
-                             f"(BASELINE config 3), ") +
-                            (f"= {world * C} channels over {world} GPUs (BASELINE config 4 asks for 4096 over 8), "
-                             if world > 1 and args.workload == "wbfm" else "") +
-                            f"{B} blocks of 262144 B per channel per step, input resident in HBM"
-                            + (", IQ scattered from rank 0 over RCCL each step" if args.scatter and world > 1 else ""),
+                "workload": rx_workload_text(args.workload, C, B, world, args.signal, args.scatter,
+                                             args.quiet_fraction, args.threshold, args.iqdump),
                 "channels_per_gpu": C, "blocks_per_step": B, "signal": args.signal,
-                "parallelism": f"channels sharded, {world} rank(s), no data-path collective",
+                "parallelism": f"channels sharded, {world} rank(s), no data-path collective"
+                               + (" (REHEARSAL over gloo on shared GPUs: not a measurement)" if rehearse and world > 1 else ""),
             },
             "per_gpu_value": round(value / world, 1),
             "realtime_channels_per_gpu": int(value / world / 2.048),
@@ -509,26 +690,28 @@ def main():
                 "frac_of_measured_copy": round(achieved / copy_gbs, 4),
                 "kernel": ("hrfd::k_rx_wbfm_flow<4> (one persistent workgroup per CU, LDS ring, first-octant-table atan2)"
                            if args.workload == "wbfm" else "all demodulator kernels of a step: first kernel's start to the later of the two streams' last kernel end (HIP events on both)"),
-                "kernel_ms_mean": round(mean_ms, 4),
-                "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
-                "kernel_ms_median": round(float(np.median(kernel_ms)), 4),
-                "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel_ms_mean": round(r["mean_ms"], 4),
+                "kernel_ms_min": round(r["kernel_ms_min"], 4),
+                "kernel_ms_median": round(r["kernel_ms_median"], 4),
+                "algorithmic_bytes_per_launch": r["algo_bytes"],
             },
             "verification": {"uncommitted_launches": counters[5], "tiles_repaired_in_place": counters[4],
                              "launches": counters[6]},
+            "kernel_source_tag": kernel_source_tag(),
         }
         if counters[5] != 0:
             # a launch that did not commit means later launches started from a stale state and the batch path was
             # not what ran: the number is not a measurement of it
             line["invalid"] = f"{counters[5]} launch(es) were not committed"
+        default_headline = (world == 1 and args.workload == "wbfm" and (C, B) == (256, 16) and args.signal == "fmtone"
+                            and args.quiet_fraction == 0 and not args.iqdump)
         if world == 1 and args.workload == "wbfm" and not args.no_extras:
             line["end_to_end"] = end_to_end(api, device, C)
             line["single_block_latency_ms"] = single_block_latency_ms(api, device)
+        if default_headline and not args.no_extras:
+            line["also"] = also_lines(api, shard, device, args)
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, os.cpu_count() or 1)
-            # also the reference on ONE host thread (config 1's shape), a short sample
-            one = cpu_baseline(min(3.0, args.cpu_seconds), 1)
-            line["cpu_baseline"]["single_thread_value"] = one["value"]
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

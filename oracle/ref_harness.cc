@@ -26,6 +26,9 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 // The harness (and only the harness) peeks at private members to dump
@@ -208,6 +211,91 @@ void ref_rx_wbfm_float_stream(void *hv, float *out, uint32_t count)
 {
   RefRx *h = (RefRx *)hv;
   memcpy(out, h->wbfm->demodulatedData, count * sizeof(float));
+}
+
+// bench.py's cpu_baseline leg: `threads` host threads, each with an IqDataProcessor
+// and its four demodulators of its own (the wiring of Radio.cc:179-203), looping over the same
+// n_blocks x block_bytes of IQ for `seconds` the way DataConsumer's consumer thread does
+// (DataConsumer.cc:319-351: one acceptIqData call per 262144-byte block).  The loop allocates
+// nothing: every thread copies the input once (acceptIqData takes a non-const buffer) and the PCM
+// sink keeps its capacity.  Returns the number of blocks all threads processed and the wall time
+// from the common start to the last thread's end.
+uint64_t ref_bench_rx(int mode, uint32_t threads, double seconds, const int8_t *iq, uint32_t n_blocks,
+                      uint32_t block_bytes, double *elapsed_s, uint64_t *pcm_samples)
+{
+  if (threads == 0 || n_blocks == 0)
+  {
+    return 0;
+  }
+  std::vector<RefRx *> rx(threads);
+  for (uint32_t t = 0; t < threads; t++)
+  {
+    rx[t] = (RefRx *)ref_rx_create();
+    ref_rx_set_mode(rx[t], mode);
+    rx[t]->sink.pcm.reserve(4096);
+  }
+  std::vector<uint64_t> blocks(threads, 0), samples(threads, 0);
+  std::vector<double> ends(threads, 0.0);
+  std::atomic<uint32_t> ready(0);
+  std::atomic<bool> go(false);
+  typedef std::chrono::steady_clock clk;
+  clk::time_point t0;
+  auto body = [&](uint32_t t) {
+    std::vector<int8_t> mine(iq, iq + (size_t)n_blocks * block_bytes);
+    RefRx *h = rx[t];
+    g_sink = &h->sink;
+    ready.fetch_add(1);
+    while (!go.load(std::memory_order_acquire))
+    {
+      std::this_thread::yield();
+    }
+    uint64_t n = 0, pcm = 0;
+    for (;;)
+    {
+      for (uint32_t b = 0; b < n_blocks; b++)
+      {
+        h->proc->acceptIqData(0, mine.data() + (size_t)b * block_bytes, block_bytes);
+        pcm += h->sink.pcm.size();
+        h->sink.pcm.clear();
+      }
+      n += n_blocks;
+      if (std::chrono::duration<double>(clk::now() - t0).count() >= seconds)
+      {
+        break;
+      }
+    }
+    g_sink = nullptr;
+    ends[t] = std::chrono::duration<double>(clk::now() - t0).count();
+    blocks[t] = n;
+    samples[t] = pcm;
+  };
+  std::vector<std::thread> pool;
+  for (uint32_t t = 0; t < threads; t++)
+  {
+    pool.emplace_back(body, t);
+  }
+  while (ready.load() < threads)
+  {
+    std::this_thread::yield();
+  }
+  t0 = clk::now();
+  go.store(true, std::memory_order_release);
+  for (std::thread &th : pool)
+  {
+    th.join();
+  }
+  uint64_t total = 0, pcm_total = 0;
+  double last = 0.0;
+  for (uint32_t t = 0; t < threads; t++)
+  {
+    total += blocks[t];
+    pcm_total += samples[t];
+    last = ends[t] > last ? ends[t] : last;
+    ref_rx_destroy(rx[t]);
+  }
+  if (elapsed_s != nullptr) *elapsed_s = last;
+  if (pcm_samples != nullptr) *pcm_samples = pcm_total;
+  return total;
 }
 
 //---------------------------------------------------------------- rx, inner

@@ -443,6 +443,19 @@ class Ref:
         L.ref_dbfs_table.argtypes = [_i32p]
         L.ref_magnitude_to_dbfs.restype = C.c_int32
         L.ref_magnitude_to_dbfs.argtypes = [C.c_uint32]
+        L.ref_bench_rx.restype = C.c_uint64
+        L.ref_bench_rx.argtypes = [C.c_int, C.c_uint32, C.c_double, _i8p, C.c_uint32, C.c_uint32,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+
+    def bench_rx(self, mode, threads, seconds, iq):
+        """bench.py's cpu_baseline leg: `threads` std::threads inside the harness, one IqDataProcessor and its
+        demodulators per thread, each looping over iq [n_blocks][block_bytes] for `seconds` (one ctypes call: the
+        interpreter is not in the loop).  -> (blocks processed by all threads, wall seconds, PCM samples produced)"""
+        iq = np.ascontiguousarray(iq, dtype=np.int8)
+        nb, bb = iq.shape
+        dt, pcm = C.c_double(0.0), C.c_uint64(0)
+        n = self.lib.ref_bench_rx(mode, threads, seconds, _p(iq, _i8p), nb, bb, C.byref(dt), C.byref(pcm))
+        return int(n), float(dt.value), int(pcm.value)
 
     def quantise(self, coeffs):
         c = np.ascontiguousarray(coeffs, dtype=np.float32)
