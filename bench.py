@@ -69,13 +69,32 @@ def make_random_batch(channels, blocks, device, first_channel=0):
     return torch.randint(-128, 128, (channels, blocks, BLOCK), dtype=torch.int8, device=device, generator=gen)
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited / unknown"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def host_core_counts():
-    """(hardware threads this process may run on, physical cores among them) from the affinity mask and
-    /sys topology; physical == threads when the topology cannot be read."""
+    """(hardware threads this process may run on, physical cores among them, CPU quota of the container or None)
+    from the affinity mask, /sys topology and the cgroup; physical == threads when the topology cannot be read."""
     try:
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
         cpus = list(range(os.cpu_count() or 1))
+    quota = cgroup_cpu_quota()
     cores = set()
     for c in cpus:
         try:
@@ -85,8 +104,8 @@ def host_core_counts():
                 pkg = f.read().strip()
             cores.add((pkg, core))
         except OSError:
-            return len(cpus), len(cpus)
-    return len(cpus), len(cores)
+            return len(cpus), len(cpus), quota
+    return len(cpus), len(cores), quota
 
 
 def cpu_baseline(seconds):
@@ -98,7 +117,11 @@ def cpu_baseline(seconds):
     from tests import reflib
     nb = 8
     x = synth.make_input("fmtone", 0, nb).reshape(nb, BLOCK)
-    threads, physical = host_core_counts()
+    hw_threads, physical, quota = host_core_counts()
+    # one thread per CPU the box actually grants: a container with a CPU quota below its visible CPUs (a one-GPU box:
+    # 16 of 256) only thrashes when every visible hardware thread gets a busy thread
+    threads = hw_threads if quota is None else max(1, min(hw_threads, int(quota)))
+    cores_granted = min(physical, threads)
     try:
         eng = reflib.Ref()
     except (FileNotFoundError, OSError):
@@ -114,10 +137,12 @@ def cpu_baseline(seconds):
         "cores": threads,
         "threads": threads,
         "physical_cores": physical,
+        "hardware_threads_visible": hw_threads,
+        "cgroup_cpu_quota": quota,
         "kind": "reference",
         "single_thread_value": round(single, 2),
         "scaling_vs_single_thread": round(value / single, 1),
-        "efficiency_vs_physical_cores": round(value / (single * physical), 3),
+        "efficiency_vs_cores_used": round(value / (single * cores_granted), 3),
         "sample": f"{n} blocks of 262144 B (FM test signal, WBFM mode) over {dt:.1f} s on {threads} std::thread(s), "
                   f"one IqDataProcessor + demodulators per thread; single thread: {n1} blocks over {dt1:.1f} s",
     }

@@ -132,6 +132,10 @@ class Rx:
         2 = k_rx_wbfm_flow where it applies (the default)"""
         check(self.L.hrfd_rx_debug_set_stream(self.h, int(kernel)), "hrfd_rx_debug_set_stream")
 
+    def debug_expire(self, where: int):
+        """test hook: workgroup 0 of the next k_rx_wbfm_flow launch treats its wait `where` (1..6) as expired"""
+        check(self.L.hrfd_rx_debug_expire(self.h, int(where)), "hrfd_rx_debug_expire")
+
     def debug_set_stagger(self, units: int):
         check(self.L.hrfd_rx_debug_set_stagger(self.h, units), "hrfd_rx_debug_set_stagger")
 

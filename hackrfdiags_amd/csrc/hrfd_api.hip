@@ -205,6 +205,7 @@ struct hrfd_rx
   int stagger = 4;
   int run_len = 0;                     // test hook: blocks per workgroup run of k_rx_wbfm (0 = automatic)
   int use_stream = 2;                  // test hook: WBFM batches on 0 = k_rx_wbfm, 1 = k_rx_wbfm_stream, 2 = k_rx_wbfm_flow (where it applies)
+  int expire_once = 0;                 // test hook: the next k_rx_wbfm_flow launch treats this wait (1..6) of workgroup 0 as expired
   uint32_t last_counters[kNumCounters] = {0};
 };
 
@@ -628,6 +629,19 @@ extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
   return HRFD_OK;
 }
 
+// test hook: workgroup 0 of the NEXT k_rx_wbfm_flow launch treats its wait number `where` (1 ring space, 2 blocks
+// finished, 3 a generation's units, 4 partial sums, 5 verification order, 6 integer-stage order) as expired the first
+// time it polls it -- the bounded-spin failure path (kFailExpired, abort word, host replay of the channel) on demand
+extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
+{
+  if (h == nullptr || where < 0 || where > 6)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 6");
+  }
+  h->expire_once = where;
+  return HRFD_OK;
+}
+
 extern "C" int hrfd_rx_debug_set_stagger(hrfd_rx *h, int units)
 {
   if (h == nullptr || units < 0)
@@ -791,6 +805,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
 
   // configuration snapshot
   uint32_t sub_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<uint32_t> sub_lists;
   std::vector<std::pair<uint32_t, int>> resets;
   {
     std::lock_guard<std::mutex> g(h->mu);
@@ -821,21 +836,25 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     }
     if (opt.subset != nullptr)
     {
-      // per-mode lists of the subset (list 6: the subset itself)
-      std::vector<uint32_t> lists((size_t)8 * h->n_channels);
+      // per-mode lists of the subset (list 6: the subset itself); only the modes are read under the lock
+      sub_lists.resize((size_t)8 * h->n_channels);
       for (uint32_t c : *opt.subset)
       {
         const int m = h->h_cfg[c].mode;
-        lists[(size_t)m * h->n_channels + sub_count[m]++] = c;
-        lists[(size_t)6 * h->n_channels + sub_count[6]++] = c;
+        sub_lists[(size_t)m * h->n_channels + sub_count[m]++] = c;
+        sub_lists[(size_t)6 * h->n_channels + sub_count[6]++] = c;
         if (m == HRFD_MODE_AM || m == HRFD_MODE_LSB || m == HRFD_MODE_USB)
         {
-          lists[(size_t)7 * h->n_channels + sub_count[7]++] = c;
+          sub_lists[(size_t)7 * h->n_channels + sub_count[7]++] = c;
         }
       }
-      HIP_TRY(hipStreamSynchronize(s));
-      HIP_TRY(hipMemcpy(h->d_sub_lists, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice));
     }
+  }
+  if (opt.subset != nullptr && !opt.subset->empty())
+  {
+    // (outside the configuration lock: the CLI thread's setters do not wait for this upload)
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(h->d_sub_lists, sub_lists.data(), sizeof(uint32_t) * sub_lists.size(), hipMemcpyHostToDevice));
   }
   const uint32_t *const list_count = (opt.subset != nullptr) ? sub_count : h->list_count;
   const uint32_t *const d_lists = (opt.subset != nullptr) ? h->d_sub_lists : h->d_lists;
@@ -1081,7 +1100,10 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
         P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here
         P.self_finish = 1;                                 // the last workgroup of a channel finishes it (finish_channel)
         flow_ran = true;
+        P.dbg_flags |= h->expire_once << 16;
+        h->expire_once = 0;
         hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC>), dim3(grid), dim3(kThreads), 0, s, P);
+        P.dbg_flags &= 0xffff;
         P.self_finish = 0;
       }
       else if (streaming)
@@ -1230,7 +1252,7 @@ extern "C" int hrfd_rx_failed_channels(hrfd_rx *h, uint8_t *out, uint32_t n)
 // outputs are the full [n_channels][n_blocks][...] device buffers of the call being repaired.
 static int rx_replay(hrfd_rx *h, const std::vector<uint32_t> &subset, const int8_t *d_iq, uint64_t stride,
                      uint32_t block_bytes, uint32_t n_blocks, uint32_t gain_db, int16_t *d_pcm, uint32_t *d_npcm,
-                     uint32_t *d_mag, uint8_t *d_allowed, int8_t *d_iq256, hipStream_t s)
+                     uint32_t *d_mag, uint8_t *d_allowed, int8_t *d_iq256, hipStream_t s, bool pcm_is_clear)
 {
   if (subset.empty())
   {
@@ -1238,7 +1260,12 @@ static int rx_replay(hrfd_rx *h, const std::vector<uint32_t> &subset, const int8
   }
   // squelched units write no PCM: they must read as zeros, not as what a failed batch left there
   const size_t row = (size_t)n_blocks * (block_bytes / 512) * sizeof(int16_t);
-  if (subset.size() == h->n_channels)
+  const bool whole_bank = subset.size() == h->n_channels;
+  if (pcm_is_clear)
+  {
+    // (no batch ran over this buffer: the caller's memset still stands)
+  }
+  else if (whole_bank)
   {
     HIP_TRY(hipMemsetAsync(d_pcm, 0, row * h->n_channels, s));
   }
@@ -1251,11 +1278,19 @@ static int rx_replay(hrfd_rx *h, const std::vector<uint32_t> &subset, const int8
   }
   for (uint32_t b = 0; b < n_blocks; b++)
   {
-    std::vector<uint32_t> todo = subset;
-    for (int attempt = 0; attempt < 2 && !todo.empty(); attempt++)
+    // attempt 0: the exact per-block kernel; attempt 1: its one-lane de-emphasis for the channels whose tiles did not
+    // re-synchronise.  The whole bank runs on the cached per-mode lists (no subset, no upload: the reference's own
+    // cadence of one block per call takes this path on every call).
+    bool all = whole_bank, clean = false;
+    std::vector<uint32_t> todo;
+    if (!all)
+    {
+      todo = subset;
+    }
+    for (int attempt = 0; attempt < 2 && !clean; attempt++)
     {
       LaunchOpts opt = {n_blocks, b, attempt, 0};
-      opt.subset = &todo;
+      opt.subset = all ? nullptr : &todo;
       int rc = rx_launch(h, d_iq + (size_t)b * block_bytes, stride, block_bytes, 1, gain_db, d_pcm, d_npcm, d_mag,
                          d_allowed, d_iq256, s, opt);
       if (rc != HRFD_OK) return rc;
@@ -1263,18 +1298,19 @@ static int rx_replay(hrfd_rx *h, const std::vector<uint32_t> &subset, const int8
       if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
       if (viol == 0)
       {
-        todo.clear();
+        clean = true;
         break;
       }
       h->replays++;
       std::vector<uint32_t> again;
-      for (uint32_t c : todo)
+      for (uint32_t c : (all ? subset : todo))
       {
         if (h->h_fail[c] != 0) again.push_back(c);
       }
       todo.swap(again);
+      all = false;
     }
-    if (!todo.empty())
+    if (!clean)
     {
       return fail(HRFD_ESTATE, "internal: exact replay still reports %zu failed channel(s)", todo.size());
     }
@@ -1339,8 +1375,9 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
   {
     for (uint32_t c = 0; c < C; c++) redo.push_back(c);
   }
+  const bool batch_ran = (n_blocks > 1 && (uint32_t)(kMaxHal + 64) * 16u <= block_bytes);
   if ((rc = rx_replay(h, redo, h->d_iq, stride, block_bytes, n_blocks, gain_db, h->d_pcm, h->d_npcm, h->d_mag_out,
-                      h->d_allowed, d_iq256, s)) != HRFD_OK)
+                      h->d_allowed, d_iq256, s, !batch_ran)) != HRFD_OK)
   {
     return rc;
   }
@@ -1596,8 +1633,9 @@ extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_m
   if (e == hipSuccess) e = hipMalloc((void **)&h->d_param, sizeof(float) * n_channels);
   if (e == hipSuccess) e = hipMalloc((void **)&h->d_acc, sizeof(float) * n_channels);
   if (e == hipSuccess) e = hipMemset(h->d_acc, 0, sizeof(float) * n_channels);
-  if (e == hipSuccess) e = hipMalloc((void **)&h->d_err, sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMemset(h->d_err, 0, sizeof(uint32_t));
+  // [0] waits that expired; [1], [2] counters of the -DHRFD_PS_PROBE diagnostic build of k_phase_scan
+  if (e == hipSuccess) e = hipMalloc((void **)&h->d_err, 3 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(h->d_err, 0, 3 * sizeof(uint32_t));
   if (kind == HRFD_MOD_WBFM)
   {
     // Nco.cc:50-61: tables from a float angle accumulated by float increments; sinf/cosf: host libm

@@ -241,7 +241,7 @@ extern "C" int hrfd_ingest_collect(hrfd_ingest *g, const int16_t **pcm, const ui
         continue;
       }
       const int rc = rx_replay(rx, redo, r.d_iq, (uint64_t)g->block_bytes * g->n_blocks, g->block_bytes, g->n_blocks,
-                               r.gain_db, r.d_pcm, r.d_npcm, r.d_mag, r.d_allowed, nullptr, rx->stream);
+                               r.gain_db, r.d_pcm, r.d_npcm, r.d_mag, r.d_allowed, nullptr, rx->stream, false);
       if (rc != HRFD_OK)
       {
         return rc;

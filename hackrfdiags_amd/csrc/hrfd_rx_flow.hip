@@ -100,18 +100,25 @@ __device__ __forceinline__ void lds_order()
 }
 // Every wait of this kernel is bounded: a wave that has spun for ~0.1 s (a protocol error -- the normal waits are
 // microseconds) marks its channel as failed (chan_expired), which makes the host replay that channel on the exact
-// path, and goes on; the grid always drains.  `where` identifies the wait in the diagnostics.
+// path, raises the workgroup's ABORT word and leaves its loop; every other wait of the workgroup looks at that word
+// every 256 polls and gives up as well, so a stuck workgroup drains within one spin limit, not one per wait.
+// `where` identifies the wait in the diagnostics.  RxParams::dbg_flags >> 16 names a wait that workgroup 0 treats as
+// expired the first time it polls it (test hook: hrfd_rx_debug_expire).
 constexpr uint32_t kFSpinLimit = 1u << 20;
+constexpr int kFAbort = 7;                      // ctl[kFAbort] != 0: a wait of this workgroup has expired
 struct FlowSpin
 {
   uint32_t n = 0;
-  __device__ __forceinline__ bool expired(const RxParams &P, uint32_t &fail_code, uint32_t where)
+  __device__ __forceinline__ bool expired(const RxParams &P, uint32_t *ctl, uint32_t &fail_code, uint32_t where)
   {
-    if (++n < kFSpinLimit)
+    ++n;
+    const bool forced = (uint32_t)(P.dbg_flags >> 16) == where && blockIdx.x == 0;
+    if (n < kFSpinLimit && !forced && ((n & 255u) != 0u || __hip_atomic_load(&ctl[kFAbort], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u))
     {
       return false;
     }
     fail_code = where;                                   // reported as chan_expired at the end of the wave
+    __hip_atomic_store(&ctl[kFAbort], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return true;
   }
 };
@@ -502,11 +509,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       {
         const unsigned long long t0 = __builtin_readcyclecounter();
         FlowSpin sp;
-        while (8 * u + 8 + wt > 64 * (int)lds_ld(&ctl[1]) + kFRingTiles && !sp.expired(P, fail_code, 1))
+        while (8 * u + 8 + wt > 64 * (int)lds_ld(&ctl[1]) + kFRingTiles && !sp.expired(P, ctl, fail_code, 1))
         {
           __builtin_amdgcn_s_sleep(8);
         }
         waited += __builtin_readcyclecounter() - t0;
+        if (fail_code != 0u)
+        {
+          break;                                         // the workgroup is aborting: the channel will be replayed
+        }
       }
       finish_block();                                    // of the previous unit
       FLOW_MARK(3)
@@ -626,7 +637,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       // squelch inputs of the whole run go out
       const uint32_t nb = b_end - b_first;
       FlowSpin sp;
-      while (lds_ld(&ctl[3]) != nb && !sp.expired(P, fail_code, 2))
+      while (lds_ld(&ctl[3]) != nb && !sp.expired(P, ctl, fail_code, 2))
       {
         __builtin_amdgcn_s_sleep(2);
       }
@@ -686,7 +697,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
         for (;;)
         {
           const bool ok = (uu >= uhi) || lds_ld(&uflag[uu & (kFEdges - 1)]) == (uint32_t)uu + 1u;
-          if (__all(ok) || sp.expired(P, fail_code, 3))
+          if (__all(ok) || sp.expired(P, ctl, fail_code, 3))
           {
             break;
           }
@@ -694,6 +705,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
         }
         waited += __builtin_readcyclecounter() - tw0;
         lds_order();
+      }
+      if (fail_code != 0u)
+      {
+        break;                                           // the workgroup is aborting (FlowSpin): the channel will be replayed
       }
       SVC_MARK(1)
       // 2. the two provisional samples at the start of every unit (they need theta of the two samples in
@@ -747,12 +762,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       {
         const unsigned long long tw0 = __builtin_readcyclecounter();
         FlowSpin sp;
-        while (lds_ld(&pflag[(g - 1) & 7]) != (uint32_t)g && !sp.expired(P, fail_code, 4))
+        while (lds_ld(&pflag[(g - 1) & 7]) != (uint32_t)g && !sp.expired(P, ctl, fail_code, 4))
         {
           __builtin_amdgcn_s_sleep(4);
         }
         waited += __builtin_readcyclecounter() - tw0;
         lds_order();
+        if (fail_code != 0u)
+        {
+          break;
+        }
       }
       SVC_MARK(4)
       // 4. seed, warm-up, tile
@@ -809,12 +828,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       {
         const unsigned long long tw0 = __builtin_readcyclecounter();
         FlowSpin sp;
-        while (lds_ld(&ctl[1]) != (uint32_t)g && !sp.expired(P, fail_code, 5))
+        while (lds_ld(&ctl[1]) != (uint32_t)g && !sp.expired(P, ctl, fail_code, 5))
         {
           __builtin_amdgcn_s_sleep(2);
         }
         waited += __builtin_readcyclecounter() - tw0;
         lds_order();
+      }
+      if (fail_code != 0u)
+      {
+        break;
       }
       SVC_MARK(6)
       const uint32_t left_y = wfin[0], left_s0 = wfin[1], left_s1 = wfin[2];
@@ -867,12 +890,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       {
         const unsigned long long tw0 = __builtin_readcyclecounter();
         FlowSpin sp;
-        while (lds_ld(&ctl[2]) != (uint32_t)g && !sp.expired(P, fail_code, 6))
+        while (lds_ld(&ctl[2]) != (uint32_t)g && !sp.expired(P, ctl, fail_code, 6))
         {
           __builtin_amdgcn_s_sleep(2);
         }
         waited += __builtin_readcyclecounter() - tw0;
         lds_order();
+      }
+      if (fail_code != 0u)
+      {
+        break;
       }
       // 7. U[0] of every tile: S[-4 .. -1] are the LEFT lane's last four samples (its final ones)
       {

@@ -19,7 +19,7 @@ struct hrfd_txring
   static constexpr int kRing = 16, kBlock = 512;          // PCM_RING_SIZE, PCM_BLOCK_SIZE
   struct Chan
   {
-    uint32_t writer = kRing - 1, reader = 8;              // ctor :78-79 (table[15] = 7 ... see create)
+    uint32_t writer = kRing - 1, reader = 7;              // ctor :78-79: the last slot, and the start slot that goes with it
     bool running = false, synchronized = false;
     uint32_t produced = 0, consumed = 0, dropped = 0, added = 0;
     std::mutex writer_lock;                               // the reference's writerLock
@@ -29,7 +29,8 @@ struct hrfd_txring
 };
 
 namespace {
-const int kReaderStart[16] = {8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7};   // :19-20
+// where a reader starts for a given writer slot: half a ring behind it (the reference's start table, :19-20)
+inline uint32_t reader_start(uint32_t writer) { return (writer + hrfd_txring::kRing / 2) % hrfd_txring::kRing; }
 }
 
 extern "C" int hrfd_txring_create(uint32_t n_channels, hrfd_txring **out)
@@ -43,7 +44,7 @@ extern "C" int hrfd_txring_create(uint32_t n_channels, hrfd_txring **out)
   for (auto &c : r->ch)
   {
     c.writer = hrfd_txring::kRing - 1;
-    c.reader = (uint32_t)kReaderStart[c.writer];
+    c.reader = reader_start(c.writer);
     memset(c.buf, 0, sizeof(c.buf));
   }
   *out = r;
@@ -103,8 +104,58 @@ extern "C" int hrfd_txring_write(hrfd_txring *r, uint32_t channel, const int16_t
   return HRFD_OK;
 }
 
-// getNextFilledBuffer (:476-606) for every channel: batch [n_channels][512], the input of
-// hrfd_mod_process(h, batch, 512, ...)
+// One read of a channel's ring, the policy of getNextFilledBuffer (BasebandDataProcessor.cc:476-606) restated:
+//
+//   lag     how many blocks the writer is ahead of the reader.  The reference unwraps a writer index that is
+//           numerically below the reader by adding RING - 1 (not RING), so a wrapped lag reads one short -- the
+//           pacing decisions below depend on it and the oracle tests pin it.
+//   nudge   the pacing decision as a signed reader adjustment: +1 skips a block (lag above 10: the writer is
+//           running away), -1 steps back so that the previous block goes out again (lag below 6: the writer is
+//           about to be caught), 0 otherwise.  It is applied whether or not the stream is running, as in the
+//           reference, and counted as a dropped / an added block.
+//   start   the first read after start() ignores where the reader was and takes the slot half a ring behind
+//           the writer (the reference's start table is (writer + 8) mod 16).
+//   idle    a stream that is not running hands out silence and does not advance.
+namespace {
+constexpr uint32_t kSlots = hrfd_txring::kRing;
+
+inline uint32_t ring_add(uint32_t index, int delta) { return (index + kSlots + (uint32_t)delta) % kSlots; }
+
+inline int writer_lag(uint32_t writer, uint32_t reader)
+{
+  return (writer >= reader) ? (int)(writer - reader) : (int)(writer + (kSlots - 1) - reader);
+}
+
+void read_one(hrfd_txring::Chan &k, int16_t *dst)
+{
+  uint32_t writer_now;
+  {
+    std::lock_guard<std::mutex> g(k.writer_lock);
+    writer_now = k.writer;
+  }
+  const int lag = writer_lag(writer_now, k.reader);
+  const int nudge = (lag > 10) - (lag < 6);
+  k.reader = ring_add(k.reader, nudge);
+  k.dropped += (nudge > 0);
+  k.added += (nudge < 0);
+  if (!k.running)
+  {
+    memset(dst, 0, sizeof(k.buf[0]));
+    return;
+  }
+  if (!k.synchronized)
+  {
+    std::lock_guard<std::mutex> g(k.writer_lock);
+    k.reader = reader_start(k.writer);
+    k.synchronized = true;
+  }
+  memcpy(dst, k.buf[k.reader], sizeof(k.buf[0]));
+  k.reader = ring_add(k.reader, 1);
+  k.consumed++;
+}
+} // namespace
+
+// batch [n_channels][512]: one block per channel, the input of hrfd_mod_process(h, batch, 512, ...)
 extern "C" int hrfd_txring_read_batch(hrfd_txring *r, int16_t *batch)
 {
   if (r == nullptr || batch == nullptr)
@@ -113,50 +164,7 @@ extern "C" int hrfd_txring_read_batch(hrfd_txring *r, int16_t *batch)
   }
   for (size_t c = 0; c < r->ch.size(); c++)
   {
-    hrfd_txring::Chan &k = r->ch[c];
-    int16_t *dst = batch + c * hrfd_txring::kBlock;
-    int32_t u;
-    {
-      std::lock_guard<std::mutex> g(k.writer_lock);
-      u = (int32_t)k.writer;
-    }
-    const int32_t l = (int32_t)k.reader;
-    if (u < l)
-    {
-      u += hrfd_txring::kRing - 1;                        // as written in the reference (:513)
-    }
-    const int32_t lag = u - l;
-    if (lag > 10)
-    {
-      k.reader = (k.reader + 1) % hrfd_txring::kRing;     // writer too far ahead: drop a block
-      k.dropped++;
-    }
-    else if (lag < 6)
-    {
-      int32_t d = (int32_t)k.reader - 1;                  // writer too close: send the previous block again
-      if (d < 0)
-      {
-        d += hrfd_txring::kRing;
-      }
-      k.reader = (uint32_t)d;
-      k.added++;
-    }
-    if (k.running)
-    {
-      if (!k.synchronized)
-      {
-        k.synchronized = true;
-        std::lock_guard<std::mutex> g(k.writer_lock);
-        k.reader = (uint32_t)kReaderStart[k.writer];
-      }
-      memcpy(dst, k.buf[k.reader], sizeof(k.buf[0]));
-      k.reader = (k.reader + 1) % hrfd_txring::kRing;
-      k.consumed++;
-    }
-    else
-    {
-      memset(dst, 0, sizeof(k.buf[0]));                   // zeroPcmBuffer
-    }
+    read_one(r->ch[c], batch + c * hrfd_txring::kBlock);
   }
   return HRFD_OK;
 }

@@ -286,6 +286,57 @@ def test_one_quiet_channel_does_not_stop_the_bank(oracle, run_len):
             assert (got2[c] == pcm2[c]).all(), c
 
 
+@pytest.mark.parametrize("run_len", [0, 16], ids=["several_runs_per_channel", "one_workgroup_per_channel"])
+@pytest.mark.parametrize("where", [3, 5, 6, 1])
+def test_expired_wait_fails_the_channel_and_is_replayed(oracle, where, run_len):
+    """The bounded-spin failure path of k_rx_wbfm_flow (FlowSpin: kFailExpired, the workgroup's abort word, host
+    replay).  hrfd_rx_debug_expire makes workgroup 0 of the next launch treat one of its waits as expired the first
+    time it polls it: the workgroup must drain at once (not one spin limit per wait), its channel must be reported
+    as failed with bit 8 and must not commit, the other channels commit, and the blocking entry -- which replays
+    the failed channel on the exact path -- still returns the oracle's PCM for every channel.  Wait 3 (a
+    generation's units) is polled by every workgroup at its start, so its failure is certain; the others (1 ring
+    space, 5 / 6 generation order) are polled only when a wave actually has to wait: either way the results are exact."""
+    import time
+    import torch
+    C, B = 3, 4
+    xs = np.stack([synth.make_input("fmtone", 60 + c, B).reshape(B, BLK) for c in range(C)])
+    want = [_oracle_stream(oracle, WBFM, xs[c], B) for c in range(C)]
+    dev = torch.device("cuda:0")
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    rx.debug_set_run_len(run_len)
+    x = torch.from_numpy(xs).to(dev)
+    out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    rx.debug_expire(where)
+    t0 = time.perf_counter()
+    rx.process_device(x.data_ptr(), B * BLK, BLK, B, out.data_ptr())
+    failed = rx.sync()
+    assert time.perf_counter() - t0 < 2.0, "an aborting workgroup must drain promptly"
+    f = rx.failed_channels()
+    if where == 3:
+        assert failed == 1 and f[0] & 8, (failed, f)
+    assert failed == int((f != 0).sum()) and failed <= 1 and not f[1:].any()
+    got = out.cpu().numpy()
+    for c in range(C):
+        if f[c] == 0:
+            assert all((got[c, b] == want[c][b][0]).all() for b in range(B)), c
+    # the blocking entry repairs the channel by itself
+    rx2 = api.Rx(C)
+    rx2.set_mode(api.WBFM)
+    rx2.debug_set_run_len(run_len)
+    rx2.debug_expire(where)
+    pcm = rx2.process_block(xs, B)[0]
+    for c in range(C):
+        assert all((pcm[c, b] == want[c][b][0]).all() for b in range(B)), c
+    # ... and the streams go on from the right state
+    xs2 = np.stack([synth.make_input("fmtone", 60 + c, 2 * B).reshape(2 * B, BLK)[B:] for c in range(C)])
+    pcm2 = rx2.process_block(xs2, B)[0]
+    for c in range(C):
+        w2 = _oracle_stream(oracle, WBFM, np.concatenate([xs[c], xs2[c]]), 2 * B)
+        assert all((pcm2[c, b] == w2[B + b][0]).all() for b in range(B)), c
+
+
 @pytest.mark.parametrize("warm", [64, 256, 384])
 def test_short_warmup_is_repaired_exactly(oracle, warm):
     """Shrinking the de-emphasis warm-up makes tiles fail to re-synchronise; the

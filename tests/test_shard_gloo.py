@@ -25,7 +25,9 @@ def test_channel_range_partitions_exactly():
 
 
 def _oracle_pcm(xs):
-    """[channels, blocks, bytes] int8 -> [channels, blocks, 512] int16, WBFM, one sequential oracle per channel"""
+    """[channels, blocks, bytes] int8 -> [channels, blocks, 512] int16, WBFM, one sequential oracle per channel.
+    (The ranks only LOAD the oracle: the parent test builds it once before spawning, so that concurrent ranks
+    never race on writing the same .so.)"""
     from tests.reflib import Oracle, WBFM
     orc = Oracle()
     out = np.zeros((xs.shape[0], xs.shape[1], 512), dtype=np.int16)
@@ -71,6 +73,8 @@ def _worker(rank, world, port, n_channels, blocks, q):
 
 @pytest.mark.parametrize("world,n_channels", [(2, 4), (2, 5), (3, 7)])
 def test_scatter_demodulate_gather_gloo(world, n_channels):
+    from tests.reflib import build_oracle
+    build_oracle()                                          # once, here: the ranks find it up to date
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000 + world * 7 + n_channels

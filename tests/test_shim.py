@@ -92,12 +92,14 @@ def test_shim_am_fm_modulators_reproduce_oracle(oracle, kind, arg, param, tol):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
 def test_shim_baseband_data_processor_dispatch(oracle, mode):
     """SURVEY 8a row T5: BasebandDataProcessor::getIqData -> modulateBasebandData (BasebandDataProcessor.cc:381,
     630-697) through the shim class: one 512-sample block off the PCM ring (drop / repeat pacing, zeros while the
     stream is idle) through the modulator of the mode; mode None fills the transfer buffer with 64.  Expected: the
-    oracle's ring model driven with the same schedule feeding the oracle's modulator."""
+    oracle's ring model driven with the same schedule feeding the oracle's modulator.  Bit-exact, except FM (mode 2):
+    FmModulator goes through libm cosf/sinf in the reference and through double cos/sin on the device, so its int8 IQ
+    is within +-1 LSB (the trig-path tolerance of BASELINE.json's north star)."""
     _build_demo()
     ops = "r" + "w" * 16 + "s" + "r" * 3 + "wr" * 6 + "rrrr" + "w" * 9 + "rr" + "p" + "r"
     n_w = ops.count("w")
@@ -106,7 +108,7 @@ def test_shim_baseband_data_processor_dispatch(oracle, mode):
                          stderr=subprocess.PIPE, check=True).stdout
     got = np.frombuffer(out, dtype=np.int8).reshape(-1, 262144)
     ring = oracle.txring()
-    mod = {1: lambda: oracle.ammod(), 3: lambda: oracle.wbfmmod(), 4: lambda: oracle.ssbmod(True),
+    mod = {1: lambda: oracle.ammod(), 2: lambda: oracle.fmmod(), 3: lambda: oracle.wbfmmod(), 4: lambda: oracle.ssbmod(True),
            5: lambda: oracle.ssbmod(False)}.get(mode, lambda: None)()
     want, w = [], 0
     for o in ops:
@@ -118,7 +120,12 @@ def test_shim_baseband_data_processor_dispatch(oracle, mode):
         else:
             ring.set_running(o == "s")
     want = np.stack(want)
-    assert got.shape == want.shape and (got == want).all()
+    assert got.shape == want.shape
+    tol = 1 if mode == 2 else 0
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert np.minimum(d, 256 - d).max() <= tol
+    if mode == 2:
+        assert (d != 0).mean() < 0.02, "FM: only isolated bytes may differ"
     st = ring.stats()
     assert st[2] > 0 and st[3] > 0, "the schedule should exercise both the drop and the repeat branch"
 
