@@ -462,7 +462,7 @@ def rx_workload_text(workload, C, B, world, signal, scatter, quiet_fraction=0.0,
 
 
 def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmup, settle, rank, world,
-               scatter=False, quiet_fraction=0.0, threshold=None, iqdump=False, idle_s=0.0):
+               scatter=False, quiet_fraction=0.0, threshold=None, iqdump=False, idle_s=0.0, serial_modes=False):
     """K timed steps of the receive path over one resident batch [C][B][262144]; returns the figures of a bench line.
     The dominant kernels' time comes from HIP events the library records on its launch stream(s) around the
     demodulator kernels of every launch (hrfd_rx_debug_enable_timing)."""
@@ -490,6 +490,8 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
             rx.set_mode([api.AM, api.FM, api.WBFM, api.LSB][(4 * c) // C], channel=c)
     if threshold is not None:
         rx.set_threshold(int(threshold))
+    if serial_modes:
+        rx.debug_set_split(False)
     stream = torch.cuda.Stream(device=device)
     iq_root = None
     scatter = scatter and world > 1
@@ -622,6 +624,8 @@ def main():
                     help="this fraction of the channels carries no signal (with --threshold: their squelch gates close)")
     ap.add_argument("--threshold", type=int, default=None, help="squelch threshold in dBFS (setSignalDetectThreshold)")
     ap.add_argument("--iqdump", action="store_true", help="also write the 256 kS/s stream (`enable iqdump`)")
+    ap.add_argument("--serial-modes", action="store_true",
+                    help="mixed bank: the modes' kernels one after the other (test hook; default: the WBFM flow kernel beside the rest)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -668,7 +672,8 @@ def main():
     settle = max(0, SETTLE_STEPS - args.warmup)
     r = measure_rx(api, shard, device, dist, workload=args.workload, C=C, B=B, signal=args.signal, steps=args.steps,
                    warmup=args.warmup, settle=settle, rank=rank, world=world, scatter=args.scatter,
-                   quiet_fraction=args.quiet_fraction, threshold=args.threshold, iqdump=args.iqdump)
+                   quiet_fraction=args.quiet_fraction, threshold=args.threshold, iqdump=args.iqdump,
+                   serial_modes=args.serial_modes)
     counters = r["counters"]
     assert r["pcm_produced"] == r["pcm_expected"], f"PCM samples produced {r['pcm_produced']} != {r['pcm_expected']}"
     traffic, ptag = pmc_traffic_bytes(args, C, B)

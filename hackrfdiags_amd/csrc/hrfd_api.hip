@@ -137,6 +137,7 @@ extern "C" int hrfd_q15_table(const char *name, int16_t *out, int cap)
 struct hrfd_rx
 {
   int device = 0;
+  int n_cus = 256;                     // compute units of the device
   uint32_t n_channels = 0;
   hipStream_t stream = nullptr;
   hipStream_t last_stream = nullptr;
@@ -161,9 +162,9 @@ struct hrfd_rx
   uint32_t *d_counters = nullptr;       // [kNumDevCounters] + a second set of the per-launch counters [kCntSticky]
   uint32_t *d_local = nullptr;          // the per-launch counters of the latest launch (set 0 = d_counters, set 1 behind it)
   int parity = 0;
-  uint32_t *d_lists = nullptr;         // [8][n_channels] channel ids grouped by mode; list 6: every channel that is not WBFM,
-                                       // list 7: the AM and SSB channels
-  uint32_t list_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t *d_lists = nullptr;         // [9][n_channels] channel ids grouped by mode; list 6: every channel that is not WBFM,
+                                       // list 7: the AM and SSB channels, list 8: those followed by the FM channels
+  uint32_t list_count[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t *d_sub_lists = nullptr;     // the same for a launch over a subset of the channels (replay of failed channels);
                                        // list 6 there: the subset itself
   uint32_t *d_chan = nullptr;          // [4][n_channels]: chan_fail, chan_poison, chan_expired, chan_arrived (EpilogueParams)
@@ -192,9 +193,8 @@ struct hrfd_rx
 
   // measurement hook: HIP events around the demodulator kernels of a launch
   std::vector<hipEvent_t> ev;           // 2 events per slot; slot = launch index % slots
-  hipStream_t side = nullptr;           // the 8 kS/s AM / SSB recurrences run beside the next mode's kernel
-  hipEvent_t ev_fir[2] = {nullptr, nullptr}, ev_post[2] = {nullptr, nullptr};
-  hipEvent_t ev_rest = nullptr, ev_fin = nullptr;   // mixed bank: the other modes' kernels are all submitted / their channels finished
+  hipStream_t side = nullptr;           // a bank of several modes: everything but the WBFM flow kernel runs here, beside it
+  hipEvent_t ev_rest = nullptr, ev_fin = nullptr;   // mixed bank: fork (the launch stream so far) and join (the side stream's last kernel)
   uint32_t ev_launches = 0;
   std::vector<uint8_t> ev_side_used;    // per slot: the side stream ran kernels in that launch
 
@@ -205,6 +205,7 @@ struct hrfd_rx
   int stagger = 4;
   int run_len = 0;                     // test hook: blocks per workgroup run of k_rx_wbfm (0 = automatic)
   int use_stream = 2;                  // test hook: WBFM batches on 0 = k_rx_wbfm, 1 = k_rx_wbfm_stream, 2 = k_rx_wbfm_flow (where it applies)
+  int split_modes = 1;                 // test hook: 0 = a bank of several modes runs its kernels one after the other
   int expire_once = 0;                 // test hook: the next k_rx_wbfm_flow launch treats this wait (1..6) of workgroup 0 as expired
   uint32_t last_counters[kNumCounters] = {0};
 };
@@ -228,11 +229,6 @@ static int rx_free(hrfd_rx *h)
   for (hipEvent_t e : h->ev)
   {
     (void)hipEventDestroy(e);
-  }
-  for (int i = 0; i < 2; i++)
-  {
-    if (h->ev_fir[i]) (void)hipEventDestroy(h->ev_fir[i]);
-    if (h->ev_post[i]) (void)hipEventDestroy(h->ev_post[i]);
   }
   if (h->ev_rest) (void)hipEventDestroy(h->ev_rest);
   if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
@@ -275,6 +271,13 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   hrfd_rx *h = new hrfd_rx;
   h->device = device;
   h->n_channels = n_channels;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+    {
+      h->n_cus = cus;
+    }
+  }
   h->h_cfg.assign(n_channels, default_cfg());
   int rc = HRFD_OK;
   auto alloc = [&](void **p, size_t bytes) -> bool {
@@ -290,11 +293,6 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming) == hipSuccess &&
        hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; i < 2 && ok; i++)
-  {
-    ok = hipEventCreateWithFlags(&h->ev_fir[i], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&h->ev_post[i], hipEventDisableTiming) == hipSuccess;
-  }
   ok = ok && alloc((void **)&h->d_cfg, sizeof(ChanCfg) * n_channels);
   ok = ok && alloc((void **)&h->d_state, sizeof(ChanState) * n_channels);
   ok = ok && alloc((void **)&h->d_state_out, sizeof(ChanState) * n_channels);
@@ -305,8 +303,8 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && alloc((void **)&h->d_att0, sizeof(float) * kCorrBytes);
   ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
   ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * (kNumDevCounters + kCntSticky));
-  ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 8 * n_channels);
-  ok = ok && alloc((void **)&h->d_sub_lists, sizeof(uint32_t) * 8 * n_channels);
+  ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 9 * n_channels);
+  ok = ok && alloc((void **)&h->d_sub_lists, sizeof(uint32_t) * 9 * n_channels);
   ok = ok && alloc((void **)&h->d_chan, sizeof(uint32_t) * 4 * n_channels);
   if (!ok)
   {
@@ -548,8 +546,8 @@ extern "C" int hrfd_rx_debug_enable_timing(hrfd_rx *h, int slots)
   }
   h->ev.clear();
   h->ev_launches = 0;
-  // per slot: the launch stream's start and end, and the side stream's end (a bank of several modes)
-  for (int i = 0; i < 3 * slots; i++)
+  // per slot: the launch stream's start and end, and the ends of the two other streams a bank of several modes uses
+  for (int i = 0; i < 4 * slots; i++)
   {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
@@ -561,18 +559,21 @@ extern "C" int hrfd_rx_debug_enable_timing(hrfd_rx *h, int slots)
 
 extern "C" int hrfd_rx_debug_kernel_ms(hrfd_rx *h, int slot, float *ms)
 {
-  if (h == nullptr || ms == nullptr || slot < 0 || (size_t)(3 * slot + 2) >= h->ev.size())
+  if (h == nullptr || ms == nullptr || slot < 0 || (size_t)(4 * slot + 3) >= h->ev.size())
   {
     return fail(HRFD_EINVAL, "timing slot out of range");
   }
   // From the launch's first kernel to the end of its last one: the later of the two streams' ends.  (The join of the
   // side stream into the launch stream comes behind both and is the caller's time between steps, not the kernels'.)
-  HIP_TRY(hipEventElapsedTime(ms, h->ev[3 * slot], h->ev[3 * slot + 1]));
-  if (h->ev_side_used[(size_t)slot])
+  HIP_TRY(hipEventElapsedTime(ms, h->ev[4 * slot], h->ev[4 * slot + 1]));
+  for (int k = 0; k < 2; k++)
   {
-    float side_ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&side_ms, h->ev[3 * slot], h->ev[3 * slot + 2]));
-    *ms = std::max(*ms, side_ms);
+    if (h->ev_side_used[(size_t)slot] & (1 << k))
+    {
+      float side_ms = 0.0f;
+      HIP_TRY(hipEventElapsedTime(&side_ms, h->ev[4 * slot], h->ev[4 * slot + 2 + k]));
+      *ms = std::max(*ms, side_ms);
+    }
   }
   return HRFD_OK;
 }
@@ -639,6 +640,17 @@ extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
     return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 6");
   }
   h->expire_once = where;
+  return HRFD_OK;
+}
+
+// test hook: 0 = the kernels of a bank of several modes run one after the other instead of the flow kernel beside the rest
+extern "C" int hrfd_rx_debug_set_split(hrfd_rx *h, int on)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL");
+  }
+  h->split_modes = on ? 1 : 0;
   return HRFD_OK;
 }
 
@@ -804,7 +816,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   }
 
   // configuration snapshot
-  uint32_t sub_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t sub_count[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<uint32_t> sub_lists;
   std::vector<std::pair<uint32_t, int>> resets;
   {
@@ -812,8 +824,8 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     resets.swap(h->pending_resets);
     if (h->cfg_dirty)
     {
-      std::vector<uint32_t> lists((size_t)8 * h->n_channels);
-      uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      std::vector<uint32_t> lists((size_t)9 * h->n_channels);
+      uint32_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       for (uint32_t c = 0; c < h->n_channels; c++)
       {
         const int m = h->h_cfg[c].mode;
@@ -827,6 +839,16 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
           lists[(size_t)7 * h->n_channels + cnt[7]++] = c;
         }
       }
+
+      // list 8: the AM and SSB channels (their 8 kS/s tails run beside what follows), then the FM channels
+      for (uint32_t i = 0; i < cnt[7]; i++)
+      {
+        lists[(size_t)8 * h->n_channels + cnt[8]++] = lists[(size_t)7 * h->n_channels + i];
+      }
+      for (uint32_t i = 0; i < cnt[HRFD_MODE_FM]; i++)
+      {
+        lists[(size_t)8 * h->n_channels + cnt[8]++] = lists[(size_t)HRFD_MODE_FM * h->n_channels + i];
+      }
       memcpy(h->list_count, cnt, sizeof(cnt));
       // synchronous uploads: the host vectors are only valid under the lock
       HIP_TRY(hipStreamSynchronize(s));
@@ -837,7 +859,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     if (opt.subset != nullptr)
     {
       // per-mode lists of the subset (list 6: the subset itself); only the modes are read under the lock
-      sub_lists.resize((size_t)8 * h->n_channels);
+      sub_lists.resize((size_t)9 * h->n_channels);
       for (uint32_t c : *opt.subset)
       {
         const int m = h->h_cfg[c].mode;
@@ -970,13 +992,12 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.fin = E;
   P.self_finish = 0;
   P.sticky = h->d_counters;
-  bool flow_ran = false;
 
-  const size_t ev_slots = h->ev.size() / 3;
+  const size_t ev_slots = h->ev.size() / 4;
   const size_t ev_slot = ev_slots ? (h->ev_launches % ev_slots) : 0;
   if (ev_slots)
   {
-    HIP_TRY(hipEventRecord(h->ev[3 * ev_slot], s));
+    HIP_TRY(hipEventRecord(h->ev[4 * ev_slot], s));
     h->ev_side_used[ev_slot] = 0;
   }
   auto side_stamp = [&]() -> hipError_t {               // behind every kernel that goes to the side stream
@@ -984,81 +1005,48 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     {
       return hipSuccess;
     }
-    h->ev_side_used[ev_slot] = 1;
-    return hipEventRecord(h->ev[3 * ev_slot + 2], h->side);
+    h->ev_side_used[ev_slot] |= 1;
+    return hipEventRecord(h->ev[4 * ev_slot + 2], h->side);
   };
-  // per-mode dispatch (BASELINE config 3): AM, SSB, FM first, WBFM / NONE last.  The 8 kS/s
-  // recurrences of AM and SSB are one workgroup per channel (a quarter of the chip for a 64-channel
-  // quarter of the bank): they go to a side stream behind their mode's front kernel and run beside
-  // the next mode's; the launch stream joins them before the epilogue.
+  // per-mode dispatch (BASELINE config 3).
+  //
+  // A bank of WBFM channels alone is one launch of k_rx_wbfm_flow on the caller's stream.  A bank of several modes
+  // runs in TWO PARTS SIDE BY SIDE (`split`): the flow kernel goes out first, one persistent workgroup per WBFM
+  // channel (it holds a whole CU: 157 KB of LDS, 16 waves x 124 VGPRs, so nothing else is ever placed beside it), and
+  // the other modes' kernels -- the FIR front kernel of the AM / SSB / FM channels, the 8 kS/s recurrences, mode NONE,
+  // the finisher of all channels that are not WBFM -- follow on the handle's side stream and fill the CUs the flow
+  // kernel left.  The launch stream joins the side stream at the end.  (Submitted the other way round, or as equals
+  // between a fork and a join, the FIR workgroups take the CUs first and the whole-CU workgroups wait: 0.35 ms
+  // against 0.26 serial)  Without a flow kernel in the launch everything is serial on the caller's
+  // stream, the recurrences on the side stream beside the next mode's front kernel.
   P.dbg = nullptr;
-  int n_side = 0;
-  // AM and SSB: one launch for both kinds (k_rx_fir<14>: the same three decimators), their 8 kS/s recurrences likewise
-  // (k_rx_post<14>, one workgroup per channel)
-  if (list_count[7] != 0)
-  {
-    const uint32_t n = list_count[7];
-    P.chan_list = d_lists + (size_t)7 * h->n_channels;
-    P.n_list = n;
-    const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
-    if (opt.src256)
-    {
-      hipLaunchKernelGGL((k_rx_fir<14, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
-    }
-    else
-    {
-      hipLaunchKernelGGL((k_rx_fir<14, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
-    }
-    HIP_TRY(hipEventRecord(h->ev_fir[0], s));
-    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fir[0], 0));
-    hipLaunchKernelGGL(k_rx_post<14>, dim3(n), dim3(256), 0, h->side, P);
-    HIP_TRY(hipEventRecord(h->ev_post[0], h->side));
-    HIP_TRY(side_stamp());
-    n_side |= 1;
-    HIP_TRY(hipGetLastError());
-  }
-  if (list_count[HRFD_MODE_FM] != 0)
-  {
-    const uint32_t n = list_count[HRFD_MODE_FM];
-    P.chan_list = d_lists + (size_t)HRFD_MODE_FM * h->n_channels;
-    P.n_list = n;
-    const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
-    if (opt.src256)
-    {
-      hipLaunchKernelGGL((k_rx_fir<2, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
-    }
-    else if (h->arith_ok && h->atan_mode != 0)
-    {
-      hipLaunchKernelGGL((k_rx_fir<2, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
-    }
-    else
-    {
-      hipLaunchKernelGGL((k_rx_fir<2, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
-    }
-    HIP_TRY(hipGetLastError());
-  }
+  const uint32_t n_wb = list_count[HRFD_MODE_WBFM];
+  const bool streaming = n_wb != 0 && h->use_stream && n_blocks > 1 && !opt.serial && !opt.src256;
+  // k_rx_wbfm_flow: whole units of two 4 KiB pieces, no iq dump, the first-octant-table atan2
+  const bool flow = streaming && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 && d_iq256 == nullptr &&
+                    (n256 % 512u) == 0 && n256 >= 2048u;
+  const bool split = flow && opt.subset == nullptr && list_count[6] != 0 && h->split_modes;
+  hipStream_t fs = split ? h->side : s;                    // where the kernels of the other modes go
+  hipStream_t ws = s;                                      // ... and the flow kernel: first in line, on the caller's stream
 
-  for (int m : {HRFD_MODE_NONE, HRFD_MODE_WBFM})
-  {
+  auto launch_wbfm_or_none = [&](int m, hipStream_t ks) -> int {
     const uint32_t n = list_count[m];
     if (n == 0)
     {
-      continue;
+      return HRFD_OK;
     }
     P.chan_list = d_lists + (size_t)m * h->n_channels;
     P.n_list = n;
     // runs of consecutive blocks per workgroup (only a run's first block re-produces the history
     // in front of it): as long as possible while the launch still fills the chip --
-    // k_rx_wbfm_stream holds one workgroup per CU (256), k_rx_wbfm two (512)
+    // the streaming kernels hold one workgroup per CU (256), k_rx_wbfm two (512).  Beside the other modes' kernels
+    // (split) the chip is filled by them: one run per channel.
     const uint32_t groups = 8u * ((n + 7u) / 8u);
-    const bool streaming = (m == HRFD_MODE_WBFM) && h->use_stream && n_blocks > 1 && !opt.serial && !opt.src256;
-    // k_rx_wbfm_flow: whole units of two 4 KiB pieces, no iq dump, the arithmetic atan2
-    const bool flow = streaming && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 && d_iq256 == nullptr &&
-                      (n256 % 512u) == 0 && n256 >= 2048u;
-    const uint32_t fill = streaming ? 256u : 512u;
-    uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : (streaming ? 16u : 8u);
+    const bool strm = (m == HRFD_MODE_WBFM) && streaming;
+    const uint32_t fill = strm ? 256u : 512u;
+    uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : (strm ? 16u : 8u);
     run_len = std::min(run_len, n_blocks);
-    while (h->run_len <= 0 && run_len > 1 && groups * ((n_blocks + run_len - 1) / run_len) < fill)
+    while (!(split && m == HRFD_MODE_WBFM) && h->run_len <= 0 && run_len > 1 && groups * ((n_blocks + run_len - 1) / run_len) < fill)
     {
       run_len--;
     }
@@ -1072,113 +1060,167 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     P.dbg = (h->d_dbg != nullptr && (size_t)grid * kDbgSlots <= h->dbg_cap && m == HRFD_MODE_WBFM) ? h->d_dbg : nullptr;
     if (m == HRFD_MODE_NONE)
     {
-      hipLaunchKernelGGL((k_rx_wbfm<0, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
+      hipLaunchKernelGGL((k_rx_wbfm<0, false, false>), dim3(grid), dim3(kThreads), 0, ks, P);
     }
-    else
+    else if (opt.src256)
     {
-      if (opt.src256)
+      hipLaunchKernelGGL((k_rx_wbfm<3, true, false>), dim3(grid), dim3(kThreads), 0, ks, P);
+    }
+    else if (flow)
+    {
+      P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here
+      P.self_finish = 1;                                 // the last workgroup of a channel finishes it (finish_channel)
+      P.dbg_flags |= h->expire_once << 16;
+      h->expire_once = 0;
+      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC>), dim3(grid), dim3(kThreads), 0, ks, P);
+      P.dbg_flags &= 0xffff;
+      P.self_finish = 0;
+      P.warm_tiles = warm_tiles;
+    }
+    else if (strm)
+    {
+      if (h->arith_ok && h->atan_mode != 0)
       {
-        hipLaunchKernelGGL((k_rx_wbfm<3, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
-      }
-      else if (flow)
-      {
-        if (opt.subset == nullptr && list_count[6] != 0)
-        {
-          // A bank of several modes: k_rx_wbfm_flow finishes its own channels; the others' finisher goes to the side
-          // stream behind everything submitted so far (the AM / SSB recurrences are there already) and runs in the
-          // shadow of this kernel instead of behind it.
-          HIP_TRY(hipEventRecord(h->ev_rest, s));
-          HIP_TRY(hipStreamWaitEvent(h->side, h->ev_rest, 0));
-          EpilogueParams F = E;
-          F.chan_list = d_lists + (size_t)6 * h->n_channels;
-          F.n_channels = list_count[6];
-          hipLaunchKernelGGL(k_rx_finish, dim3(F.n_channels), dim3(64), 0, h->side, F);
-          HIP_TRY(hipEventRecord(h->ev_fin, h->side));
-          HIP_TRY(side_stamp());
-          n_side = 4;                                      // the side stream is in order: this event covers the others
-        }
-        P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here
-        P.self_finish = 1;                                 // the last workgroup of a channel finishes it (finish_channel)
-        flow_ran = true;
-        P.dbg_flags |= h->expire_once << 16;
-        h->expire_once = 0;
-        hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC>), dim3(grid), dim3(kThreads), 0, s, P);
-        P.dbg_flags &= 0xffff;
-        P.self_finish = 0;
-      }
-      else if (streaming)
-      {
-        if (h->arith_ok && h->atan_mode != 0)
-        {
-          hipLaunchKernelGGL((k_rx_wbfm_stream<true>), dim3(grid), dim3(kThreads), 0, s, P);
-        }
-        else
-        {
-          hipLaunchKernelGGL((k_rx_wbfm_stream<false>), dim3(grid), dim3(kThreads), 0, s, P);
-        }
-      }
-      else if (h->arith_ok && h->atan_mode != 0)
-      {
-        hipLaunchKernelGGL((k_rx_wbfm<3, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
+        hipLaunchKernelGGL((k_rx_wbfm_stream<true>), dim3(grid), dim3(kThreads), 0, ks, P);
       }
       else
       {
-        hipLaunchKernelGGL((k_rx_wbfm<3, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
+        hipLaunchKernelGGL((k_rx_wbfm_stream<false>), dim3(grid), dim3(kThreads), 0, ks, P);
       }
     }
+    else if (h->arith_ok && h->atan_mode != 0)
+    {
+      hipLaunchKernelGGL((k_rx_wbfm<3, false, true>), dim3(grid), dim3(kThreads), 0, ks, P);
+    }
+    else
+    {
+      hipLaunchKernelGGL((k_rx_wbfm<3, false, false>), dim3(grid), dim3(kThreads), 0, ks, P);
+    }
+    P.dbg = nullptr;
     HIP_TRY(hipGetLastError());
+    return HRFD_OK;
+  };
+
+  if (split)
+  {
+    // everything submitted to the launch stream so far (resets, the previous launch) is in front of both parts
+    HIP_TRY(hipEventRecord(h->ev_rest, s));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_rest, 0));
+    if ((rc = launch_wbfm_or_none(HRFD_MODE_WBFM, ws)) != HRFD_OK) return rc;
+  }
+  // AM, SSB and FM.
+  //  * beside the flow kernel (split): ONE grid for all of them (k_rx_fir<15>: the mode is read per workgroup; list 8
+  //    holds the AM and SSB channels in front of the FM channels) that finishes its own channels;
+  //  * else AM and SSB as one launch for both kinds (k_rx_fir<14>: the same three decimators) and their 8 kS/s
+  //    recurrences as the next (k_rx_post<14>, one workgroup per channel, which also finishes the channel), then FM
+  //    (k_rx_fir<2>, whose workgroups finish their own channels);
+  //  * the inner demodulator API and the replay of a subset (single blocks, latency paths): the same kernels with a
+  //    finisher kernel at the end.
+  const bool fir_self = !opt.src256 && opt.subset == nullptr;
+  if (split && list_count[8] != 0)
+  {
+    P.chan_list = d_lists + (size_t)8 * h->n_channels;
+    P.n_list = list_count[8];
+    P.self_finish = 1;
+    const uint32_t grid = 8u * ((P.n_list + 7u) / 8u) * n_blocks;
+    if (h->arith_ok && h->atan_mode != 0)
+    {
+      hipLaunchKernelGGL((k_rx_fir<15, false, true>), dim3(grid), dim3(kThreads), 0, fs, P);
+    }
+    else
+    {
+      hipLaunchKernelGGL((k_rx_fir<15, false, false>), dim3(grid), dim3(kThreads), 0, fs, P);
+    }
+    P.self_finish = 0;
+    HIP_TRY(hipGetLastError());
+  }
+  else
+  {
+    if (list_count[7] != 0)
+    {
+      const uint32_t n = list_count[7];
+      P.chan_list = d_lists + (size_t)7 * h->n_channels;
+      P.n_list = n;
+      const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+      if (opt.src256)
+      {
+        hipLaunchKernelGGL((k_rx_fir<14, true, false>), dim3(grid), dim3(kThreads), 0, fs, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_fir<14, false, false>), dim3(grid), dim3(kThreads), 0, fs, P);
+      }
+      P.self_finish = fir_self ? 1 : 0;
+      hipLaunchKernelGGL(k_rx_post<14>, dim3(n), dim3(256), 0, fs, P);
+      P.self_finish = 0;
+      HIP_TRY(hipGetLastError());
+    }
+    if (list_count[HRFD_MODE_FM] != 0)
+    {
+      const uint32_t n = list_count[HRFD_MODE_FM];
+      P.chan_list = d_lists + (size_t)HRFD_MODE_FM * h->n_channels;
+      P.n_list = n;
+      P.self_finish = fir_self ? 1 : 0;
+      const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+      if (opt.src256)
+      {
+        hipLaunchKernelGGL((k_rx_fir<2, true, false>), dim3(grid), dim3(kThreads), 0, fs, P);
+      }
+      else if (h->arith_ok && h->atan_mode != 0)
+      {
+        hipLaunchKernelGGL((k_rx_fir<2, false, true>), dim3(grid), dim3(kThreads), 0, fs, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_fir<2, false, false>), dim3(grid), dim3(kThreads), 0, fs, P);
+      }
+      P.self_finish = 0;
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  if ((rc = launch_wbfm_or_none(HRFD_MODE_NONE, fs)) != HRFD_OK) return rc;
+  if (!split)
+  {
+    if ((rc = launch_wbfm_or_none(HRFD_MODE_WBFM, s)) != HRFD_OK) return rc;
+  }
+  // the channels that no kernel finished by itself
+  auto finish_list = [&](const uint32_t *list, uint32_t n, hipStream_t ks) -> int {
+    if (n != 0)
+    {
+      EpilogueParams G = E;
+      G.chan_list = list;
+      G.n_channels = n;
+      hipLaunchKernelGGL(k_rx_finish, dim3(n), dim3(64), 0, ks, G);
+      HIP_TRY(hipGetLastError());
+    }
+    return HRFD_OK;
+  };
+  if (opt.subset != nullptr)
+  {
+    if ((rc = finish_list(d_lists + (size_t)6 * h->n_channels, list_count[6], s)) != HRFD_OK) return rc;   // the subset itself
+  }
+  else if (!fir_self)
+  {
+    if ((rc = finish_list(nullptr, h->n_channels, s)) != HRFD_OK) return rc;
+  }
+  else
+  {
+    if ((rc = finish_list(d_lists + (size_t)HRFD_MODE_NONE * h->n_channels, list_count[HRFD_MODE_NONE], fs)) != HRFD_OK) return rc;
+    if (!flow)
+    {
+      if ((rc = finish_list(d_lists + (size_t)HRFD_MODE_WBFM * h->n_channels, list_count[HRFD_MODE_WBFM], s)) != HRFD_OK) return rc;
+    }
   }
   if (ev_slots)
   {
-    HIP_TRY(hipEventRecord(h->ev[3 * ev_slot + 1], s));    // behind the launch stream's last kernel, in front of the join
+    HIP_TRY(hipEventRecord(h->ev[4 * ev_slot + 1], ws));   // behind the launch stream's last kernel, in front of the join
     h->ev_launches++;
   }
-  for (int i = 0; i < 2; i++)
+  if (split)
   {
-    if (n_side & (1 << i))
-    {
-      HIP_TRY(hipStreamWaitEvent(s, h->ev_post[i], 0));
-    }
-  }
-  if (n_side & 4)
-  {
+    HIP_TRY(hipEventRecord(h->ev_fin, h->side));
+    HIP_TRY(side_stamp());
     HIP_TRY(hipStreamWaitEvent(s, h->ev_fin, 0));
-  }
-
-  // the channels that no kernel finished by itself (finish_channel): everything but the WBFM channels when
-  // k_rx_wbfm_flow ran, else all of them
-  {
-    EpilogueParams F = E;
-    if (flow_ran)
-    {
-      F.chan_list = d_lists + (size_t)6 * h->n_channels;
-      F.n_channels = 0u;                                   // (the whole bank's list 6 was finished on the side stream)
-      if (opt.subset != nullptr)
-      {
-        // the subset's list 6 holds all its channels: finish those that are not WBFM through their mode lists
-        for (int m : {HRFD_MODE_NONE, HRFD_MODE_AM, HRFD_MODE_FM, HRFD_MODE_LSB, HRFD_MODE_USB})
-        {
-          if (list_count[m] != 0)
-          {
-            EpilogueParams G = E;
-            G.chan_list = d_lists + (size_t)m * h->n_channels;
-            G.n_channels = list_count[m];
-            hipLaunchKernelGGL(k_rx_finish, dim3(G.n_channels), dim3(64), 0, s, G);
-            HIP_TRY(hipGetLastError());
-          }
-        }
-      }
-    }
-    else if (opt.subset != nullptr)
-    {
-      F.chan_list = d_lists + (size_t)6 * h->n_channels;
-      F.n_channels = list_count[6];
-    }
-    if (F.n_channels != 0)
-    {
-      hipLaunchKernelGGL(k_rx_finish, dim3(F.n_channels), dim3(64), 0, s, F);
-      HIP_TRY(hipGetLastError());
-    }
   }
   h->last_stream = s;
   return HRFD_OK;

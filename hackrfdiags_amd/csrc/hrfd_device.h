@@ -168,7 +168,7 @@ struct RxParams
   uint32_t *counters;          // kCnt* of this launch
   uint32_t *sticky;            // the handle's totals (kCntTotRepair ...)
   EpilogueParams fin;          // k_rx_wbfm_flow finishes its own channels (the launch's finish parameters) ...
-  int32_t self_finish;         // ... when this is set
+  int32_t self_finish;         // ... when this is set (also k_rx_fir<FM> and k_rx_post: they finish their channels themselves)
   int32_t flow_hal;            // k_rx_wbfm_flow: history samples in front of a run that does not start the call (multiple of 512)
   float flow_seed_ct;          // k_rx_wbfm_flow: (-a1)^64
   unsigned long long *dbg;     // optional [grid][kDbgSlots] s_memtime stamps at phase boundaries (diagnostic builds of bench only)

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/tl_mixed
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --workload mixed --steps 30 --warmup 20 --no-cpu --no-extras > $O/bench.json 2> $O/log.txt
+rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --workload mixed --steps 30 --warmup 20 --no-cpu --no-extras "$@" > $O/bench.json 2> $O/log.txt
 python3 - "$O" <<'PY'
 import csv, glob, sys
 rows = []
@@ -15,14 +15,17 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         if "hrfd::" in r["Kernel_Name"] and "build_atan" not in r["Kernel_Name"]:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void hrfd::", "").replace("hrfd::", ""), r.get("Queue_Id", "?")))
 rows.sort()
-# a step starts with k_rx_fir<14, ...>
-starts = [i for i, r in enumerate(rows) if r[2].startswith("k_rx_fir<14")]
-for s in starts[-3:]:
-    e = starts[starts.index(s) + 1] if s != starts[-1] else len(rows)
-    t0 = rows[s][0]
+# a step of the mixed bank is PER kernels (2: k_rx_wbfm_flow and k_rx_fir<15>), whatever their order
+import os
+per = int(os.environ.get("PER", "2"))
+n_steps = len(rows) // per
+for k in range(max(0, n_steps - 3), n_steps):
+    chunk = rows[len(rows) - (n_steps - k) * per: len(rows) - (n_steps - k - 1) * per]
+    t0 = chunk[0][0]
+    nxt = len(rows) - (n_steps - k - 1) * per
     print("step:")
-    for a, b, n, q in rows[s:e]:
+    for a, b, n, q in chunk:
         print("   %-28s queue %-3s start %8.1f us  end %8.1f us  (%.1f us)" % (n, q, (a - t0) / 1e3, (b - t0) / 1e3, (b - a) / 1e3))
-    print("   step span %.1f us; next step's first kernel starts at %s" % ((max(r[1] for r in rows[s:e]) - t0) / 1e3, ("%.1f us" % ((rows[e][0] - t0) / 1e3)) if e < len(rows) else "-"))
+    print("   step span %.1f us; next step's first kernel starts at %s" % ((max(r[1] for r in chunk) - t0) / 1e3, ("%.1f us" % ((rows[nxt][0] - t0) / 1e3)) if nxt < len(rows) else "-"))
 PY
 rm -rf $O
