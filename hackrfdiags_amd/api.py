@@ -132,6 +132,10 @@ class Rx:
         2 = k_rx_wbfm_flow where it applies (the default)"""
         check(self.L.hrfd_rx_debug_set_stream(self.h, int(kernel)), "hrfd_rx_debug_set_stream")
 
+    def debug_set_gated(self, on: bool):
+        """test hook: False = no gated second pass on the device (closed gates in a batch go back to the host's replay)"""
+        check(self.L.hrfd_rx_debug_set_gated(self.h, int(bool(on))), "hrfd_rx_debug_set_gated")
+
     def debug_set_split(self, on: bool):
         """test hook: False = the kernels of a bank of several modes run one after the other"""
         check(self.L.hrfd_rx_debug_set_split(self.h, int(bool(on))), "hrfd_rx_debug_set_split")

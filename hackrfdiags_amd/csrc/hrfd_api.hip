@@ -205,6 +205,8 @@ struct hrfd_rx
   int stagger = 4;
   int run_len = 0;                     // test hook: blocks per workgroup run of k_rx_wbfm (0 = automatic)
   int use_stream = 2;                  // test hook: WBFM batches on 0 = k_rx_wbfm, 1 = k_rx_wbfm_stream, 2 = k_rx_wbfm_flow (where it applies)
+  int32_t wbfm_max_threshold = -200;   // the highest squelch threshold among the WBFM channels (can a gate close at all?)
+  int gated_pass = 1;                  // test hook: 0 = no gated second pass on the device (closed gates go back to the host's replay)
   int split_modes = 1;                 // test hook: 0 = a bank of several modes runs its kernels one after the other
   int expire_once = 0;                 // test hook: the next k_rx_wbfm_flow launch treats this wait (1..6) of workgroup 0 as expired
   uint32_t last_counters[kNumCounters] = {0};
@@ -643,6 +645,17 @@ extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
   return HRFD_OK;
 }
 
+// test hook: 0 = no gated second pass on the device; a channel with a closed gate in a batch stays failed (the host replays it)
+extern "C" int hrfd_rx_debug_set_gated(hrfd_rx *h, int on)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL");
+  }
+  h->gated_pass = on ? 1 : 0;
+  return HRFD_OK;
+}
+
 // test hook: 0 = the kernels of a bank of several modes run one after the other instead of the flow kernel beside the rest
 extern "C" int hrfd_rx_debug_set_split(hrfd_rx *h, int on)
 {
@@ -850,6 +863,14 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
         lists[(size_t)8 * h->n_channels + cnt[8]++] = lists[(size_t)HRFD_MODE_FM * h->n_channels + i];
       }
       memcpy(h->list_count, cnt, sizeof(cnt));
+      h->wbfm_max_threshold = INT32_MIN;
+      for (uint32_t c = 0; c < h->n_channels; c++)
+      {
+        if (h->h_cfg[c].mode == HRFD_MODE_WBFM)
+        {
+          h->wbfm_max_threshold = std::max(h->wbfm_max_threshold, h->h_cfg[c].threshold);
+        }
+      }
       // synchronous uploads: the host vectors are only valid under the lock
       HIP_TRY(hipStreamSynchronize(s));
       HIP_TRY(hipMemcpy(h->d_cfg, h->h_cfg.data(), sizeof(ChanCfg) * h->n_channels, hipMemcpyHostToDevice));
@@ -1022,8 +1043,8 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.dbg = nullptr;
   const uint32_t n_wb = list_count[HRFD_MODE_WBFM];
   const bool streaming = n_wb != 0 && h->use_stream && n_blocks > 1 && !opt.serial && !opt.src256;
-  // k_rx_wbfm_flow: whole units of two 4 KiB pieces, no iq dump, the first-octant-table atan2
-  const bool flow = streaming && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 && d_iq256 == nullptr &&
+  // k_rx_wbfm_flow: whole units of two 4 KiB pieces, the first-octant-table atan2
+  const bool flow = streaming && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 &&
                     (n256 % 512u) == 0 && n256 >= 2048u;
   const bool split = flow && opt.subset == nullptr && list_count[6] != 0 && h->split_modes;
   hipStream_t fs = split ? h->side : s;                    // where the kernels of the other modes go
@@ -1072,8 +1093,28 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       P.self_finish = 1;                                 // the last workgroup of a channel finishes it (finish_channel)
       P.dbg_flags |= h->expire_once << 16;
       h->expire_once = 0;
-      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC>), dim3(grid), dim3(kThreads), 0, ks, P);
+      if (d_iq256 != nullptr)
+      {
+        hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true>), dim3(grid), dim3(kThreads), 0, ks, P);
+      }
+      else
+      {
+        hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false>), dim3(grid), dim3(kThreads), 0, ks, P);
+      }
       P.dbg_flags &= 0xffff;
+      // Squelch (Squelch.cc:227-273, IqDataProcessor.cc:961-1034).  The detector's lowest level is 0 - 42 - gain_db dBFS
+      // (DbfsCalculator.cc:111-147): with a threshold at or below it -- the reference's default is -200 -- no gate of
+      // the bank can ever close and the batch launch is all there is.  Otherwise the gated pass follows: its
+      // workgroups redo the channels that failed on a closed gate, exactly, and the others leave at once.
+      if (h->gated_pass && n_blocks <= 64u && (int64_t)h->wbfm_max_threshold > -42 - (int64_t)gain_db)
+      {
+        const uint32_t run_len_b = P.run_len, n_runs_b = P.n_runs;
+        P.run_len = n_blocks;
+        P.n_runs = 1;
+        hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>), dim3(groups), dim3(kThreads), 0, ks, P);
+        P.run_len = run_len_b;
+        P.n_runs = n_runs_b;
+      }
       P.self_finish = 0;
       P.warm_tiles = warm_tiles;
     }

@@ -187,6 +187,7 @@ constexpr int kCntTotViol = 5; // channel-launches whose state was NOT committed
 constexpr int kCntTotLaunch = 6;
 constexpr int kCntScratch = 7;  // k_build_atan_corr's violation count (hrfd_rx_create only)
 constexpr int kNumCounters = 8;   // counters visible through hrfd_rx_debug_counters
+constexpr int kCntTotGated = 8;  // channel-launches redone on the device by the gated pass (k_rx_wbfm_flow<GATED>)
 constexpr int kNumDevCounters = 10;
 constexpr int kDbgSlots = 48;      // RxParams::dbg: per workgroup 0..5 phase stamps of thread 0, 6 placement, 8..23 per wave, 24..31 recurrence / stream-loop probes, 32..47 service-loop probes (k_rx_wbfm_flow)
 

@@ -234,7 +234,15 @@ __device__ __forceinline__ void flow_tile_u(const uint32_t *tp, float y, FlowTil
 
 constexpr int kFinWords = 168;
 
-template <int SVC>
+// GATED: the exact second pass over channels whose squelch gate closed inside the batch.  The batch launch (GATED ==
+// false) speculates every gate open; a channel with a closed gate fails ITS verdict (kFailGate, nothing committed) and
+// this variant, launched behind it with one workgroup per WBFM channel, redoes only those channels: the stream of the
+// blocks the tracker ALLOWS (Squelch.cc:227-273: present now or in the block before), from the committed state -- the
+// demodulator does not see the squelched blocks at all (IqDataProcessor.cc:961-1034: acceptIqData is not called, its
+// state is frozen), while the front end runs over everything (a block's 16 bytes of history are its physical
+// predecessor's last).  Squelched blocks get zero PCM and n_pcm = 0.  Every other channel's workgroup leaves at once.
+// DUMP: the 256 kS/s stream of `enable iqdump` (IqDataProcessor.cc:953-957) goes out as well, 8 bytes per lane and piece.
+template <int SVC, bool GATED, bool DUMP>
 __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
 {
   __shared__ __attribute__((aligned(16))) uint32_t ring[kFRingTiles * kFStride];
@@ -260,6 +268,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   __shared__ uint32_t finl[kFinWords];     // a channel that is ONE workgroup's is finished from here (no memory round trip behind
                                            // the last sample): 0..63 y in front of block b, 128..159 the pending WBFM state
                                            // section, 160 tracking, 161 poison, 162..165 the pending fe_tail
+  __shared__ uint8_t blist[GATED ? 64 : 4];  // GATED: the blocks of the stream, in order (the allowed ones)
+  __shared__ uint32_t gctl[4];             // GATED: 0 number of allowed blocks, 1 `present` of the call's last block
   static_assert(sizeof(uint32_t) * (kFRingTiles * kFStride + kFUDw + kFVDw + 5 * kFEdges + kFPRing + 1024 + 48 + kFinWords) + 5 * kCorrBytes <= 163840, "LDS");
 
   uint32_t ci, run;
@@ -269,13 +279,55 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   }
   const uint32_t c = P.chan_list[ci];
   const int n256 = (int)P.n256;
-  const uint32_t b_first = run * P.run_len;
-  const uint32_t b_end = min(P.n_blocks, b_first + P.run_len);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t n_stream_blocks = 0;                          // GATED: blocks of the stream
+  if (GATED)
+  {
+    // only the channels whose one and only failure in the batch launch was a closed gate (the host launches this
+    // variant with one run per channel and at most 64 blocks)
+    if (P.fin.chan_fail[c] != kFailGate)
+    {
+      return;
+    }
+    if (wave == 0)
+    {
+      const uint32_t nb = P.n_blocks;
+      const uint32_t pres = ((uint32_t)lane < nb) ? (uint32_t)(P.present[(size_t)c * nb + lane] != 0) : 0u;
+      const uint32_t prev = shr1(pres, (P.state[c].tracking != 0) ? 1u : 0u);
+      const bool allowed = (uint32_t)lane < nb && (pres | prev) != 0u;
+      const unsigned long long m = __ballot(allowed);
+      if (allowed)
+      {
+        blist[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+      }
+      if (lane == 0)
+      {
+        gctl[0] = (uint32_t)__popcll(m);
+        gctl[1] = (uint32_t)__builtin_amdgcn_readlane((int)pres, (int)nb - 1);
+      }
+      // squelched blocks hand back silence, not what the batch launch left there
+      const uint32_t npcm2 = (uint32_t)n256 >> 6;        // PCM pairs per block
+      uint32_t *pz = reinterpret_cast<uint32_t *>(P.pcm + ((size_t)c * P.out_blocks + P.out_b0) * (size_t)(n256 >> 5));
+      for (uint32_t b = 0; b < nb; b++)
+      {
+        if (!((m >> b) & 1ull))
+        {
+          for (uint32_t i = (uint32_t)lane; i < npcm2; i += 64u)
+          {
+            pz[(size_t)b * npcm2 + i] = 0u;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    n_stream_blocks = gctl[0];
+  }
+  const uint32_t b_first = GATED ? 0u : run * P.run_len;
+  const uint32_t b_end = GATED ? n_stream_blocks : min(P.n_blocks, b_first + P.run_len);
   const bool first = (b_first == 0);                     // the stream continues from the carried state: exact start
-  const bool local = P.self_finish != 0 && P.n_runs == 1u && P.n_blocks <= 64u;   // the channel is this workgroup's alone
+  const bool local = GATED || (P.self_finish != 0 && P.n_runs == 1u && P.n_blocks <= 64u);   // the channel is this workgroup's alone
   const int hal = first ? 0 : P.flow_hal;                // history re-derived in front of the run (samples)
   const int L = hal + (int)(b_end - b_first) * n256;     // samples of the stream
   const int n_units = L >> 9, n_tiles = L >> 6, n_gens = (n_tiles + 63) >> 6;
@@ -334,7 +386,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     finl[160] = st->tracking;
     finl[161] = P.fin.chan_poison[c];
   }
-  else if (tid >= 908 && tid < 912 && b_end == P.n_blocks)
+  else if (tid >= 908 && tid < 912 && (GATED || b_end == P.n_blocks))
   {
     // front-end carry for the next call: the last 16 raw bytes of the channel's input (pending, like the rest of state_out)
     const int8_t *endp = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)P.n_blocks * P.block_bytes;
@@ -373,6 +425,21 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     X.lane = lane;
     const uint32_t base_off = b_first * P.block_bytes - (uint32_t)hal * 16u;   // byte offset of stream sample 0
     const uint32_t dead = 0xffff0000u;                   // outside the descriptor: zeros, no memory traffic
+    // byte offset of unit u's input.  GATED: the stream is a list of blocks (units are taken in ascending order, so a
+    // wave follows the list with a cursor)
+    int cur_bu0 = 0, cur_blk = 0;
+    auto unit_off = [&](const int uu) -> uint32_t {
+      if (!GATED)
+      {
+        return base_off + (uint32_t)uu * 8192u;
+      }
+      while (uu >= cur_bu0 + (n256 >> 9))
+      {
+        cur_bu0 += n256 >> 9;
+        cur_blk++;
+      }
+      return (uint32_t)blist[cur_blk & 63] * P.block_bytes + (uint32_t)(uu - cur_bu0) * 8192u;
+    };
     auto grab = [&]() -> int {
       uint32_t g = 0;
       if (lane == 0)
@@ -394,14 +461,33 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     desc.z = __builtin_amdgcn_readfirstlane((int)(P.n_blocks * P.block_bytes));
     desc.w = 0x00020000;
     const int lane_off = lane * 64;
+    // DUMP: the run's part of the 256 kS/s output, 2 bytes per sample, as a second buffer (lane l of a piece holds
+    // samples 4l .. 4l + 3: eight contiguous bytes)
+    i32x4 ddesc = desc;
+    const int lane_off8 = lane * 8;
+    if (DUMP)
+    {
+      const uint64_t dbase = (uint64_t)(P.iq256 + ((size_t)c * P.out_blocks + P.out_b0 + b_first) * (size_t)(2 * n256));
+      ddesc.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)dbase);
+      ddesc.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(dbase >> 32) & 0xffffu));
+      ddesc.z = __builtin_amdgcn_readfirstlane((int)((b_end - b_first) * (uint32_t)(2 * n256)));
+    }
+    auto store_dump = [&](const uint32_t (&w)[2], const int uu, const int half) {
+      // stream sample 512 uu + 256 half (+ 4 lane) minus the history in front of the run; history is not dumped
+      const int pos = 512 * uu + 256 * half - hal;
+      const uint32_t soff = (pos >= 0) ? (uint32_t)(2 * pos) : dead;
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 d = {w[0], w[1]};
+      asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" : : "v"(d), "v"(lane_off8), "s"(ddesc), "s"(soff) : "memory");
+    };
     // `dep`: stage-1 outputs that between them have read every raw register of the piece being refilled -- the asm
     // names them as inputs, so no read of the old contents can be scheduled behind the load
-    auto load_piece = [&](u32x4 (&q)[4], const int piece, const bool live, const uint32_t (&dep)[4][4]) {
-      const uint32_t soff = live ? base_off + (uint32_t)piece * 4096u : dead;
+    auto load_piece = [&](u32x4 (&q)[4], const uint32_t uoff, const int half, const bool live, const uint32_t (&dep)[4][4]) {
+      const uint32_t soff = live ? uoff + (uint32_t)half * 4096u : dead;
 #if (HRFD_ABLATE & 128)
       for (int j = 0; j < 4; j++)
       {
-        q[j] = u32x4{lane * 0x01010101u + piece, lane * 0x3010501u + j, piece * 0x10101u, lane ^ (piece + soff)};   // TIMING EXPERIMENT ONLY: no HBM reads
+        q[j] = u32x4{lane * 0x01010101u + half, lane * 0x3010501u + j, half * 0x10101u, lane ^ (half + soff)};   // TIMING EXPERIMENT ONLY: no HBM reads
       }
       return;
 #endif
@@ -415,8 +501,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
                    : "memory");
     };
     // the 16 bytes in front of a unit: its front-end carries depend on nothing else
-    auto load_c16 = [&](u32x4 &q, const int u, const bool live) {
-      const uint32_t soff = (live && !(first && u == 0)) ? base_off + (uint32_t)u * 8192u - 16u : dead;
+    // (uoff == 0: the call's very first bytes -- what is in front of them is the carried fe_tail)
+    auto load_c16 = [&](u32x4 &q, const uint32_t uoff, const bool live) {
+      const uint32_t soff = (live && !(first && uoff == 0u)) ? uoff - 16u : dead;
 #if (HRFD_ABLATE & 128)
       q = u32x4{0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
       return;
@@ -481,11 +568,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     }
     c16 = u32x4{0u, 0u, 0u, 0u};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // nothing of the prologue's is in flight: the counts below are exact
-    load_c16(c16, u, u < n_units);
+    uint32_t uoff = (u < n_units) ? unit_off(u) : 0u, uoff_n = 0u;   // byte offsets of unit u and of the next one
+    load_c16(c16, uoff, u < n_units);
     {
       const uint32_t nodep[4][4] = {};
-      load_piece(qa, 2 * u, u < n_units, nodep);
-      load_piece(qb, 2 * u + 1, u < n_units, nodep);
+      load_piece(qa, uoff, 0, u < n_units, nodep);
+      load_piece(qb, uoff, 1, u < n_units, nodep);
     }
     while (u < n_units)
     {
@@ -495,7 +583,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       QuadCarry cy;
       VM_WAIT(8, "+v"(c16));
       {
-        const bool st0 = first && u == 0;                // "the 16 bytes in front" of a continued stream are the carried ones
+        const bool st0 = first && uoff == 0u;            // "the 16 bytes in front" of a continued stream are the carried ones
         cy.fe = carry_from_16(make_uint4(st0 ? tail_in[0] : c16.x, st0 ? tail_in[1] : c16.y, st0 ? tail_in[2] : c16.z,
                                          st0 ? tail_in[3] : c16.w));
       }
@@ -524,6 +612,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       const int slot0 = ring_slot(8 * u);                // NT is a multiple of 8: a unit never wraps
       uint32_t *dst = ring + slot0 * kFStride + lane_dw;
       uint32_t v[4], mag4, magsum;
+      uint32_t iqb[2] = {0u, 0u};
       float theta[4];
 #if HRFD_FLOW_EARLY_GRAB
       uint32_t un_v = 0;
@@ -566,12 +655,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
 #else
           un = grab();
 #endif
-          load_c16(c16, un, un < n_units);
-          load_piece(qa, 2 * un, un < n_units, y1);
-        });
+          uoff_n = (un < n_units) ? unit_off(un) : 0u;
+          load_c16(c16, uoff_n, un < n_units);
+          load_piece(qa, uoff_n, 0, un < n_units, y1);
+        }, DUMP ? iqb : nullptr);
       }
       reinterpret_cast<uint2 *>(dst)[0] = make_uint2(v[0], v[1]);
       reinterpret_cast<uint2 *>(dst)[1] = make_uint2(v[2], v[3]);
+      if (DUMP)
+      {
+        store_dump(iqb, u, 0);
+      }
       magsum = mag4;
       const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[0]), 0);
       const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[1]), 0);
@@ -581,10 +675,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       {
         const uint4 rb[4] = {make_uint4(qb[0].x, qb[0].y, qb[0].z, qb[0].w), make_uint4(qb[1].x, qb[1].y, qb[1].z, qb[1].w),
                              make_uint4(qb[2].x, qb[2].y, qb[2].z, qb[2].w), make_uint4(qb[3].x, qb[3].y, qb[3].z, qb[3].w)};
-        quad_piece<2>(rb, cy, X, v, theta, mag4, [&](const uint32_t (&y1)[4][4]) { load_piece(qb, 2 * un + 1, un < n_units, y1); });
+        quad_piece<2>(rb, cy, X, v, theta, mag4, [&](const uint32_t (&y1)[4][4]) { load_piece(qb, uoff_n, 1, un < n_units, y1); },
+                      DUMP ? iqb : nullptr);
       }
       reinterpret_cast<uint2 *>(dst + 4 * kFStride)[0] = make_uint2(v[0], v[1]);
       reinterpret_cast<uint2 *>(dst + 4 * kFStride)[1] = make_uint2(v[2], v[3]);
+      if (DUMP)
+      {
+        store_dump(iqb, u, 1);
+      }
       magsum += mag4;
       const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[2]), 63);
       const uint32_t e3 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[3]), 63);
@@ -593,7 +692,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       {
         edges[u & (kFEdges - 1)][lane] = (lane == 0) ? e0 : (lane == 1) ? e1 : (lane == 2) ? e2 : e3;
       }
-      const bool counted = u >= (hal >> 9);              // history in front of the run is not in any block's squelch sum
+      const bool counted = !GATED && u >= (hal >> 9);    // history in front of the run is not in any block's squelch sum (GATED: the batch launch's sums stand)
       int slot = 0;
       if (counted)
       {
@@ -621,6 +720,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       pend_slot = slot;
       pend_blk = blk;
       u = un;
+      uoff = uoff_n;
       FLOW_MARK(7)
     }
     // The last prefetches (pointed outside the buffer) are still in flight, and the compiler does not know: their
@@ -631,7 +731,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
                  : "memory");
     finish_block();
     FLOW_TIME_MAX(44)
-    if (wave == SVC)
+    if (wave == SVC && !GATED)
     {
       // every stream wave is through its units by now or about to be: wait for the last blocks, then the
       // squelch inputs of the whole run go out
@@ -948,14 +1048,23 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
           acc1 = dot2(next, kRevD40.p[j], acc1);
           prev = next;
         }
-        if ((uint32_t)pp >= pcm_off)
+        if (GATED)
+        {
+          // the stream is a list of blocks: PCM pair pp / 2 of the stream is pair (pp mod npcm) / 2 of block blist[pp / npcm]
+          const uint32_t npcm = (uint32_t)n256 >> 5;
+          const uint32_t k = (uint32_t)pp / npcm;
+          pcm32[((uint32_t)blist[k & 63u] * npcm + ((uint32_t)pp - k * npcm)) >> 1] =
+              ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+        }
+        else if ((uint32_t)pp >= pcm_off)
         {
           pcm32[((uint32_t)pp - pcm_off) >> 1] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
         }
       }
       SVC_MARK(8)
       // 10. cross-block check values: y at block-relative position -705 = the end of the tile [-768, -704)
-      if (have)
+      //     (GATED: one exact stream from the committed state, nothing to check)
+      if (have && !GATED)
       {
         const int x = 64 * t + 768 - hal;                // = (number of blocks completed) * n256 when this is such a tile
         if (x >= 0)
@@ -985,7 +1094,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       }
       // 11. hand over to the next generation
       {
-        if (g + 1 == n_gens && b_end == P.n_blocks)
+        if (g + 1 == n_gens && (GATED || b_end == P.n_blocks))
         {
           // the carried state for the next call (pending: k_rx_commit copies it when the launch verified clean)
           const uint32_t *el = edges[(n_units - 1) & (kFEdges - 1)];
@@ -1056,7 +1165,68 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   // The last wave of the last workgroup of a channel finishes the channel (finish_channel: squelch tracker, checks
   // of both speculations, n_pcm / allowed outputs, commit of the pending state): no kernel behind this one.
   // Release / acquire at agent scope around the two counters (MI355X_MICROARCH, "Workgroup dispatch ... visibility").
-  if (local)
+  if (GATED)
+  {
+    // The exact pass over the allowed blocks is through.  The channel's last wave writes the squelch outputs of every
+    // block, commits the pending state -- the demodulator's section when any block was demodulated (it is the state
+    // behind the LAST ALLOWED block: a closed gate freezes it), the front end's 16 bytes and the tracker always --
+    // and takes the channel's failure back: nothing is left for the host to replay.  A wait that expired keeps it.
+    if (fail_code != 0u && lane == 0)
+    {
+      lds_st(&ctl[6], 1u);
+    }
+    uint32_t prev = 0;
+    if (lane == 0)
+    {
+      prev = atomicAdd(&ctl[5], 1u);
+    }
+    if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
+    {
+      lds_order();
+      if (lds_ld(&ctl[6]) == 0u)
+      {
+        const uint32_t nb = P.n_blocks;
+        const EpilogueParams &E = P.fin;
+        ChanState *dst = P.state + c;
+        // allowed[b]: b is in the list
+        bool allowed = false;
+        for (uint32_t k = 0; k < n_stream_blocks; k++)
+        {
+          allowed = allowed || (uint32_t)blist[k] == (uint32_t)lane;
+        }
+        if ((uint32_t)lane < nb)
+        {
+          const size_t ounit = (size_t)c * E.out_blocks + E.out_b0 + lane;
+          if (E.allowed != nullptr)
+          {
+            E.allowed[ounit] = allowed ? 1 : 0;
+          }
+          if (E.n_pcm != nullptr)
+          {
+            E.n_pcm[ounit] = allowed ? E.n_pcm_per_block : 0u;
+          }
+        }
+        if (lane < 4)
+        {
+          reinterpret_cast<uint32_t *>(dst->fe_tail)[lane] = lds_ld(&finl[162 + lane]);
+        }
+        if (n_stream_blocks != 0u && lane < 30)
+        {
+          reinterpret_cast<uint32_t *>(&dst->wb_theta)[lane] = lds_ld(&finl[128 + lane]);
+        }
+        if (lane == 0)
+        {
+          dst->tracking = lds_ld(&gctl[1]) != 0u ? 1u : 0u;
+          E.chan_fail[c] = 0u;
+          E.chan_poison[c] = 0u;
+          atomicSub(&E.counters[kCntFail], 1u);
+          atomicSub(&E.sticky[kCntTotViol], 1u);
+          atomicAdd(&E.sticky[kCntTotGated], 1u);
+        }
+      }
+    }
+  }
+  else if (local)
   {
     // the channel was this workgroup's alone: every input of the verdict is in LDS, nothing is read back from memory
     // (no wait for this wave's stores either: the end of the kernel is their fence)
@@ -1151,6 +1321,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   }
 }
 
-template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC>(const RxParams);
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false>(const RxParams);
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true>(const RxParams);
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>(const RxParams);
 
 } // namespace hrfd

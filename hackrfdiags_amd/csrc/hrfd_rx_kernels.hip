@@ -1853,9 +1853,11 @@ struct NoHook
 };
 // `raw_free` is called once the raw registers are dead (behind stage 1, whose outputs it gets so that it can make
 // whatever it does depend on them): the caller may refill the registers there
+// iqb (optional): the lane's four mixed samples as the eight bytes i0 q0 i1 q1 i2 q2 i3 q3 of the 256 kS/s stream
 template <int ARITH, class Hook = NoHook>
 __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, const StreamCtx &X,
-                                           uint32_t (&vout)[4], float (&theta)[4], uint32_t &mag4, Hook &&raw_free = NoHook())
+                                           uint32_t (&vout)[4], float (&theta)[4], uint32_t &mag4, Hook &&raw_free = NoHook(),
+                                           uint32_t *iqb = nullptr)
 {
   uint32_t r[4][4];
 #pragma unroll
@@ -1912,6 +1914,12 @@ __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, 
     mixed[1] = mix_fs4_const<1>(y31);
     mixed[2] = mix_fs4_const<2>(y32);
     mixed[3] = mix_fs4_const<3>(y33);
+  }
+  if (iqb != nullptr)
+  {
+    // (q_idx << 16 | i_idx) in offset binary -> signed bytes i, q of two samples per dword
+    iqb[0] = __builtin_amdgcn_perm(mixed[1], mixed[0], 0x06040200u) ^ 0x80808080u;
+    iqb[1] = __builtin_amdgcn_perm(mixed[3], mixed[2], 0x06040200u) ^ 0x80808080u;
   }
   mag4 = 0;
 #pragma unroll

@@ -257,12 +257,13 @@ def test_one_quiet_channel_does_not_stop_the_bank(oracle, run_len):
             assert (pcm[c, b, :n_pcm[c, b]] == want[b][0]).all(), (c, b)
             assert (pcm[c, b, n_pcm[c, b]:] == 0).all(), (c, b)
     assert (n_pcm[quiet_c] == 0).sum() == 2
-    # device entry: one launch, per-channel verdict
+    # device entry without the gated second pass (test hook): one launch, per-channel verdict
     dev = torch.device("cuda:0")
     rx2 = api.Rx(C)
     rx2.set_mode(api.WBFM)
     rx2.set_threshold(-30)
     rx2.debug_set_run_len(run_len)
+    rx2.debug_set_gated(False)
     x = torch.from_numpy(xs).to(dev)
     out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
     torch.cuda.synchronize()
@@ -284,6 +285,56 @@ def test_one_quiet_channel_does_not_stop_the_bank(oracle, run_len):
     for c in range(C):
         if c != quiet_c:
             assert (got2[c] == pcm2[c]).all(), c
+
+
+@pytest.mark.parametrize("run_len", [0, 16], ids=["several_runs_per_channel", "one_workgroup_per_channel"])
+def test_closed_gates_are_redone_on_the_device(oracle, run_len):
+    """Squelch inside a batch without the host (IqDataProcessor.cc:961-1034, Squelch.cc:227-273, SignalTracker.cc:104-146):
+    the batch launch speculates every gate open; the gated pass behind it (k_rx_wbfm_flow<GATED>) redoes, on the
+    device, the channels whose gates closed -- the stream of the ALLOWED blocks only, from the committed state,
+    squelched blocks zero -- so hrfd_rx_sync reports no failed channel and every output is the oracle's: PCM, n_pcm,
+    signal_allowed, magnitude, and the state a second batch continues from (the tracker's tail block included).
+    Gate patterns: never open, closing and reopening, open only at the end, the tracker's tail across the call
+    boundary, always open."""
+    import torch
+    patterns = ["0000000", "1100110", "0000011", "1000000", "0101010", "1111111", "0011100", "1110001"]
+    C, B = len(patterns), len(patterns[0])
+    loud = [synth.make_input("fmtone", 80 + c, 2 * B).reshape(2 * B, BLK) for c in range(C)]
+    xs = np.stack(loud)
+    for c, pat in enumerate(patterns):
+        for b, ch in enumerate(pat):
+            if ch == "0":
+                xs[c, b] = 0 if (b + c) % 2 else synth.make_input("lcg", 5, 1).reshape(BLK) // 64   # silence, or noise of +-1
+        for b, ch in enumerate(pat[::-1]):                 # the second batch: the pattern backwards
+            if ch == "0":
+                xs[c, B + b] = 0
+    want = [_oracle_stream(oracle, WBFM, xs[c], 2 * B, threshold=-30) for c in range(C)]
+    dev = torch.device("cuda:0")
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    rx.set_threshold(-30)
+    rx.debug_set_run_len(run_len)
+    out = torch.full((C, B, 512), 777, dtype=torch.int16, device=dev)
+    npcm = torch.zeros((C, B), dtype=torch.int32, device=dev)
+    mag = torch.zeros((C, B), dtype=torch.int32, device=dev)
+    alw = torch.zeros((C, B), dtype=torch.uint8, device=dev)
+    for half in range(2):
+        x = torch.from_numpy(xs[:, half * B:(half + 1) * B].copy()).to(dev)
+        out.fill_(777)
+        torch.cuda.synchronize()
+        rx.process_device(x.data_ptr(), B * BLK, BLK, B, out.data_ptr(), d_n_pcm=npcm.data_ptr(), d_magnitude=mag.data_ptr(),
+                          d_allowed=alw.data_ptr())
+        assert rx.sync() == 0, rx.failed_channels()
+        got, gn, gm, ga = out.cpu().numpy(), npcm.cpu().numpy(), mag.cpu().numpy(), alw.cpu().numpy()
+        for c in range(C):
+            for b in range(B):
+                p, m, a, _ = want[c][half * B + b]
+                assert gn[c, b] == len(p) and bool(ga[c, b]) == a and gm[c, b] == m, (half, c, b)
+                if len(p):
+                    assert (got[c, b] == p).all(), (half, c, b)
+                elif patterns[c] != "1111111":
+                    assert (got[c, b] == 0).all(), (half, c, b)      # a channel the gated pass redid: silence
+    assert any(len(want[c][b][0]) == 0 for c in range(C) for b in range(2 * B))
 
 
 @pytest.mark.parametrize("run_len", [0, 16], ids=["several_runs_per_channel", "one_workgroup_per_channel"])
