@@ -109,6 +109,17 @@ def load() -> C.CDLL:
     L.hrfd_ingest_submit.argtypes = [_vp, C.c_uint32]
     L.hrfd_ingest_collect.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]
     L.hrfd_ingest_replayed.argtypes = [_vp, C.POINTER(C.c_uint64)]
+    L.hrfd_fanout_channel_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p]
+    L.hrfd_fanout_create.argtypes = [C.c_uint32, C.POINTER(C.c_int), C.c_uint32, C.POINTER(_vp)]
+    L.hrfd_fanout_destroy.argtypes = [_vp]
+    L.hrfd_fanout_shards.argtypes = [_vp, _u32p]
+    L.hrfd_fanout_set_mode.argtypes = [_vp, C.c_uint32, C.c_int]
+    L.hrfd_fanout_set_gain.argtypes = [_vp, C.c_uint32, C.c_int, C.c_float]
+    L.hrfd_fanout_set_threshold.argtypes = [_vp, C.c_uint32, C.c_int32]
+    L.hrfd_fanout_scatter.argtypes = [_vp, C.c_int, _vp, C.c_uint32, C.c_uint32, _vp]
+    L.hrfd_fanout_input.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_vp), _u32p, _u32p]
+    L.hrfd_fanout_process.argtypes = [_vp, C.c_uint32]
+    L.hrfd_fanout_collect.argtypes = [_vp, C.c_int, _vp, _vp, _u32p]
     L.hrfd_txring_create.argtypes = [C.c_uint32, C.POINTER(_vp)]
     L.hrfd_txring_destroy.argtypes = [_vp]
     L.hrfd_txring_set_running.argtypes = [_vp, C.c_uint32, C.c_int]

@@ -279,6 +279,57 @@ class Ingest:
         return int(n.value)
 
 
+def fanout_channel_range(n_channels: int, n_shards: int, shard: int):
+    """(first, count) of a shard: hrfd_fanout_channel_range (pure arithmetic, needs no GPU)"""
+    L = _lib.load()
+    first, count = C.c_uint32(0), C.c_uint32(0)
+    check(L.hrfd_fanout_channel_range(int(n_channels), int(n_shards), int(shard), C.byref(first), C.byref(count)),
+          "hrfd_fanout_channel_range")
+    return int(first.value), int(count.value)
+
+
+class Fanout:
+    """One process, several devices: n_channels receive chains sharded over `devices` (hrfd_fanout_*)."""
+
+    def __init__(self, n_channels: int, devices):
+        self.L = _lib.load()
+        self.n = int(n_channels)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        check(self.L.hrfd_fanout_create(self.n, devs, len(devices), C.byref(h)), "hrfd_fanout_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.hrfd_fanout_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_mode(self, mode, channel=ALL):
+        check(self.L.hrfd_fanout_set_mode(self.h, channel, mode), "hrfd_fanout_set_mode")
+
+    def set_gain(self, mode, gain, channel=ALL):
+        check(self.L.hrfd_fanout_set_gain(self.h, channel, mode, C.c_float(gain)), "hrfd_fanout_set_gain")
+
+    def set_threshold(self, threshold, channel=ALL):
+        check(self.L.hrfd_fanout_set_threshold(self.h, channel, threshold), "hrfd_fanout_set_threshold")
+
+    def scatter(self, src_device: int, d_iq_all, block_bytes: int, n_blocks: int, src_stream=None):
+        check(self.L.hrfd_fanout_scatter(self.h, int(src_device), _ptr(d_iq_all), int(block_bytes), int(n_blocks),
+                                         _ptr(src_stream)), "hrfd_fanout_scatter")
+
+    def process(self, gain_db: int = 0):
+        check(self.L.hrfd_fanout_process(self.h, int(gain_db)), "hrfd_fanout_process")
+
+    def collect(self, dst_device: int, d_pcm_all, d_n_pcm_all=None) -> int:
+        """waits, repairs, gathers; returns the number of channels that were replayed on the exact path"""
+        n = C.c_uint32(0)
+        check(self.L.hrfd_fanout_collect(self.h, int(dst_device), _ptr(d_pcm_all), _ptr(d_n_pcm_all), C.byref(n)),
+              "hrfd_fanout_collect")
+        return int(n.value)
+
+
 class Mod:
     """n_channels SSB modulators / interpolateSignal cascades (hrfd_mod_*)."""
 

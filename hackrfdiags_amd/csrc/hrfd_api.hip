@@ -204,7 +204,7 @@ struct hrfd_rx
   int warm = kWarm;
   int stagger = 4;
   int run_len = 0;                     // test hook: blocks per workgroup run of k_rx_wbfm (0 = automatic)
-  int use_stream = 2;                  // test hook: WBFM batches on 0 = k_rx_wbfm, 1 = k_rx_wbfm_stream, 2 = k_rx_wbfm_flow (where it applies)
+  int use_stream = 2;                  // test hook: 0 = WBFM batches on k_rx_wbfm (runs of blocks, phases in sequence) instead of k_rx_wbfm_flow
   int32_t wbfm_max_threshold = -200;   // the highest squelch threshold among the WBFM channels (can a gate close at all?)
   int gated_pass = 1;                  // test hook: 0 = no gated second pass on the device (closed gates go back to the host's replay)
   int split_modes = 1;                 // test hook: 0 = a bank of several modes runs its kernels one after the other
@@ -621,14 +621,14 @@ extern "C" int hrfd_rx_debug_set_run_len(hrfd_rx *h, int blocks)
 }
 
 // test hook: 0 = WBFM batches run on k_rx_wbfm (phases in sequence, two workgroups per CU) instead of
-// k_rx_wbfm_stream (one workgroup per CU, phases overlapped)
+// k_rx_wbfm_flow (one persistent workgroup per CU, a continuous stream); any other value: the default
 extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
 {
   if (h == nullptr)
   {
     return fail(HRFD_EINVAL, "NULL");
   }
-  h->use_stream = (on < 0 || on > 2) ? 2 : on;
+  h->use_stream = (on == 0) ? 0 : 2;
   return HRFD_OK;
 }
 
@@ -1063,7 +1063,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     // the streaming kernels hold one workgroup per CU (256), k_rx_wbfm two (512).  Beside the other modes' kernels
     // (split) the chip is filled by them: one run per channel.
     const uint32_t groups = 8u * ((n + 7u) / 8u);
-    const bool strm = (m == HRFD_MODE_WBFM) && streaming;
+    const bool strm = (m == HRFD_MODE_WBFM) && flow;
     const uint32_t fill = strm ? 256u : 512u;
     uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : (strm ? 16u : 8u);
     run_len = std::min(run_len, n_blocks);
@@ -1117,17 +1117,6 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       }
       P.self_finish = 0;
       P.warm_tiles = warm_tiles;
-    }
-    else if (strm)
-    {
-      if (h->arith_ok && h->atan_mode != 0)
-      {
-        hipLaunchKernelGGL((k_rx_wbfm_stream<true>), dim3(grid), dim3(kThreads), 0, ks, P);
-      }
-      else
-      {
-        hipLaunchKernelGGL((k_rx_wbfm_stream<false>), dim3(grid), dim3(kThreads), 0, ks, P);
-      }
     }
     else if (h->arith_ok && h->atan_mode != 0)
     {

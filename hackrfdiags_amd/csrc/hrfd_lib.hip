@@ -8,5 +8,6 @@
 #include "hrfd_tx_kernels.hip"
 #include "hrfd_api.hip"
 #include "hrfd_ingest.hip"
+#include "hrfd_fanout.hip"
 #include "hrfd_txring.hip"
 #include "hrfd_play.hip"

@@ -1,8 +1,8 @@
 // hackrfdiags_amd/csrc/hrfd_rx_flow.hip -- k_rx_wbfm_flow: the WBFM chain of a batch as ONE continuous
 // stream per workgroup, without workgroup barriers (gfx950).
 //
-// k_rx_wbfm_stream (hrfd_rx_kernels.hip) keeps two whole blocks in LDS and meets at a workgroup
-// barrier once per block.  Measured on MI355X (gpurun_out/r2_ab*.log): its phases B and C are
+// Its predecessor (round 1's k_rx_wbfm_stream, removed in round 3) kept two whole blocks in LDS and met at a
+// workgroup barrier once per block.  Measured on MI355X (gpurun_out/r2_ab*.log): its phases B and C were
 // hidden already (removing them buys 3 %) and so is HBM; what costs is phase A running at ~60 % of
 // its issue-bound rate -- every wave starts a run right behind the barrier (two dependent memory
 // latencies each, all at the same time), and waves that finish early leave their SIMD to a lone

@@ -36,9 +36,6 @@
 #ifndef HRFD_IIR_U
 #define HRFD_IIR_U 10   /* divides kTile and the warm-up: no scalar tail */
 #endif
-#ifndef HRFD_PRIO_ROTATE
-#define HRFD_PRIO_ROTATE 0   /* experiment: rotating issue priority among the waves of a SIMD -- evens out the waves, 5 % slower */
-#endif
 #ifdef HRFD_ABLATE
 #define HRFD_ABLATE_EARLY HRFD_ABLATE
 #else
@@ -674,7 +671,6 @@ struct StreamCtx
   const float *ati;              //   (quad_piece<2>: of the first-octant table T0)
   uint4 tab;                     // this thread's 16 bytes of them, loaded at kernel entry (in flight)
   bool publish;                  // ... and still to be published to LDS by this produce_stream call
-  int prio_phase;                // produce_quads: wave id / 4, the phase of the rotating issue priority
   bool first;
 };
 
@@ -1126,8 +1122,7 @@ __device__ __forceinline__ float deemph_pow(int n)
 }
 
 // ---- phase B: the de-emphasis recurrence of one block, in place (v -> y) ------------------------
-// Shared by k_rx_wbfm (every wave of the workgroup calls it, `sync` is the workgroup barrier) and
-// k_rx_wbfm_stream (the four service waves call it, `sync` is their counter barrier); the waves
+// Every wave of k_rx_wbfm's workgroup calls it (`sync` is the workgroup barrier); the waves
 // 0..kBWaves-1 own the tiles.  See the comment in k_rx_wbfm for the scheme (partial sums, seeds,
 // warm-up, tiles, verification, repair).  hoff = index of position 0 in lds[].
 struct RecurShared
@@ -1807,7 +1802,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 }
 
 // =============================================================================
-//  phase A, "quad" layout (k_rx_wbfm_stream only): a lane owns FOUR consecutive groups
+//  phase A, "quad" layout (k_rx_wbfm_flow): a lane owns FOUR consecutive groups
 // =============================================================================
 // produce_stream gives lane L of a wave the 16-byte group L of each 1 KiB chunk, so every value a
 // stage needs from the previous group comes from the neighbouring lane: 10 DPP moves per chunk
@@ -1955,590 +1950,6 @@ __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, 
   vout[3] = f2u(p[3] + p[2]);
 }
 
-// pieces [q0, q1) of 256 samples (piece q covers positions vstart + 256 q ..); wave-uniform arguments
-template <bool ARITH>
-__device__ __forceinline__ void produce_quads(const StreamCtx &X, const int q0, const int q1, uint32_t &magsum,
-                                              uint32_t (&edge)[4])
-{
-  const int lane = X.lane;
-  if (q0 >= q1)
-  {
-    return;
-  }
-  QuadCarry c;
-  c.fe = {0x80808080u, 0x00800080u, 0x00800080u};
-  c.theta = 0u;
-  c.p = 0u;
-  if (X.first && q0 == 0)
-  {
-    c.fe = carry_from_16(*reinterpret_cast<const uint4 *>(X.st->fe_tail));
-    c.theta = f2u(X.st->wb_theta);
-    c.p = f2u(X.st->wb_p);
-  }
-  else
-  {
-    const uint32_t soff = X.blk_off + (uint32_t)((X.vstart + 256 * q0) * 16 - 16);
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, 0, soff, 0);
-    c.fe = carry_from_16(make_uint4(t.x, t.y, t.z, t.w));
-  }
-  const int nskipq = (-X.vstart) >> 8;                   // pieces of history in front of the block: not in the squelch sum
-  auto load_piece = [&](uint4 (&q)[4], const int piece) {
-    // pieces past the end of the run are pointed outside the buffer: zeros, no memory traffic
-    const uint32_t soff = (piece < q1) ? X.blk_off + (uint32_t)((X.vstart + 256 * piece) * 16) : 0xffff0000u;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-    {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(X.rsrc, lane * 64 + 16 * j, soff, HRFD_STREAM_AUX);
-      q[j] = make_uint4(v.x, v.y, v.z, v.w);
-    }
-  };
-  uint4 qa[4], qb[4];
-  load_piece(qa, q0);
-  load_piece(qb, q0 + 1);
-  float th_first[2] = {0.0f, 0.0f}, th_last[2] = {0.0f, 0.0f};
-  auto step = [&](uint4 (&q)[4], const int piece) {
-#if HRFD_PRIO_ROTATE
-    // The arbiter serves the oldest wave of a SIMD first: without this the youngest wave of
-    // each SIMD is still working while the others wait at the block barrier.  The four waves of a
-    // SIMD (ids w, w+4, w+8, w+12) hold four different priorities that rotate with every piece.
-    switch ((piece + X.prio_phase) & 3)
-    {
-      case 0: __builtin_amdgcn_s_setprio(0); break;
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      default: __builtin_amdgcn_s_setprio(3); break;
-    }
-#endif
-    uint32_t v[4], mag4;
-    float theta[4];
-    quad_piece<ARITH>(q, c, X, v, theta, mag4);
-    load_piece(q, piece + 2);                            // refill this slot
-    magsum += (piece >= nskipq) ? mag4 : 0u;
-    *reinterpret_cast<uint4 *>(X.lds + (X.vstart + 256 * piece + 4 * lane + X.hal)) = make_uint4(v[0], v[1], v[2], v[3]);
-    if (piece == q0)
-    {
-      th_first[0] = theta[0];
-      th_first[1] = theta[1];
-    }
-    th_last[0] = theta[2];
-    th_last[1] = theta[3];
-  };
-  int piece = q0;
-  for (; piece + 2 <= q1; piece += 2)
-  {
-    step(qa, piece);
-    step(qb, piece + 1);
-  }
-  if (piece < q1)
-  {
-    step(qa, piece);
-  }
-#if HRFD_PRIO_ROTATE
-  __builtin_amdgcn_s_setprio(0);
-#endif
-  edge[0] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_first[0]), 0);
-  edge[1] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_first[1]), 0);
-  edge[2] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last[0]), 63);
-  edge[3] = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last[1]), 63);
-}
-
-// =============================================================================
-//  WBFM, batches (n_blocks > 1): one persistent workgroup per CU, phases overlapped
-// =============================================================================
-// k_rx_wbfm above runs the phases of a block one after the other, and the two workgroups of a
-// CU overlap them only by luck of the wave arbiter (measured: a second workgroup per CU buys
-// 12 %).  Here ONE workgroup owns the CU, keeps TWO blocks in its 160 KB of LDS and splits
-// its waves by role:
-//   waves 4..15 ("stream")   phase A of block b + 1: raw IQ -> v, into the other buffer
-//   waves 0..3  ("service")  phase B (the recurrence, one wave per SIMD) and phase C (the
-//                            integer stages) of block b
-// with one workgroup barrier per block.  The service waves synchronise among themselves with
-// a monotonic LDS counter (svc_barrier): the hardware barrier spans the whole workgroup.
-// Four waves per SIMD leave 128 VGPRs per wave.  Arithmetic, tiles, seeds, verification and
-// the cross-block checks are those of k_rx_wbfm; a run's first block (the one that may have
-// to re-derive kMaxHal samples of history) always lands in buffer 0.
-constexpr int kSvcWaves = kBWaves;
-constexpr int kStreamWaves = kWaves - kSvcWaves;
-constexpr int kSvcThreads = 64 * kSvcWaves;
-constexpr int kHoff0 = kMaxHal;                          // index of position 0 in buffer 0 / buffer 1
-constexpr int kHoff1 = (kKeepMax + 63) / 64 * 64;
-// The stream waves do not get equal shares of a block: the wave arbiter serves the oldest wave of a
-// SIMD first, so equal shares finish as a staircase and the youngest wave ends alone (measured:
-// 54 / 72 / 91 % busy).  They take runs of kRunChunks chunks from an LDS counter instead.
-#ifndef HRFD_STREAM_DEPTH
-#define HRFD_STREAM_DEPTH 8
-#endif
-#ifndef HRFD_STREAM_FENCE
-#define HRFD_STREAM_FENCE 2
-#endif
-constexpr int kStreamDepth = HRFD_STREAM_DEPTH;          // raw chunks in flight per stream wave (128 VGPRs per wave)
-constexpr int kStreamFence = HRFD_STREAM_FENCE;          // chunks the scheduler may interleave
-#ifndef HRFD_RUN_CHUNKS
-#define HRFD_RUN_CHUNKS 16  /* four 4 KiB pieces of the quad layout */
-#endif
-#ifndef HRFD_RUN_BIG
-#define HRFD_RUN_BIG 12    /* this many runs of kRunChunks ... */
-#endif
-#ifndef HRFD_RUN_SMALL
-#define HRFD_RUN_SMALL 16  /* ... then runs of this many chunks for the late joiners */
-#endif
-constexpr int kRunChunks = HRFD_RUN_CHUNKS;
-constexpr int kRunBig = HRFD_RUN_BIG, kRunSmall = HRFD_RUN_SMALL;
-// run g of a block: first chunk
-__device__ __forceinline__ int run_start(const int g)
-{
-  return (g < kRunBig) ? g * kRunChunks : kRunBig * kRunChunks + (g - kRunBig) * kRunSmall;
-}
-__device__ __forceinline__ int run_count(const int nch)
-{
-  return (nch <= kRunBig * kRunChunks) ? (nch + kRunChunks - 1) / kRunChunks
-                                       : kRunBig + (nch - kRunBig * kRunChunks + kRunSmall - 1) / kRunSmall;
-}
-constexpr int kMaxRuns = 64;                             // one lane of wave 0 patches each run boundary
-static_assert(kRunBig + ((kMaxN256 + kMaxHal) / 64 - kRunBig * kRunChunks + kRunSmall - 1) / kRunSmall <= kMaxRuns, "runs per block");
-
-__device__ __forceinline__ void svc_barrier(uint32_t *ctr, uint32_t &target, const int lane)
-{
-  target += (uint32_t)kSvcWaves;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0)
-  {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
-  {
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <bool ARITH>
-__global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_stream(const RxParams P)
-{
-  __shared__ __attribute__((aligned(16))) uint32_t buf0[kHoff0 + kMaxN256];
-  __shared__ __attribute__((aligned(16))) uint32_t buf1[kHoff1 + kMaxN256];
-  __shared__ __attribute__((aligned(16))) uint8_t atcorr[ARITH ? kCorrBytes : 16];
-  __shared__ __attribute__((aligned(16))) float atinv[ARITH ? kInvEntries : 4];
-  __shared__ __attribute__((aligned(16))) uint32_t ubuf[(kMaxN256 / 4 + kUHist) / 2];       // U[-kUHist ..)
-  __shared__ __attribute__((aligned(16))) uint32_t vbuf[(kMaxN256 / 16 + kVHist) / 2 + 1];  // V[-kVHist ..)
-  __shared__ uint32_t magtot[2];        // sum of the sample magnitudes of the block in buffer 0 / 1
-  __shared__ int8_t dbfs8[128];
-  __shared__ float tailcarry[2];
-  __shared__ uint32_t edges[2][kMaxRuns][4];
-  __shared__ uint32_t grab[2];          // next run of the block being streamed into buffer 0 / 1
-  __shared__ float parr[kMaxTiles + 8];
-  __shared__ float wfin[kBWaves];
-  __shared__ unsigned long long badmask[kBWaves];
-  __shared__ uint32_t anybad, svc_ctr;
-  __shared__ float yanchor, chk_prev;
-  __shared__ __attribute__((aligned(4))) int16_t ctail[kWbS + kWbU + kWbV + 2];
-  static_assert(sizeof(uint32_t) * (kHoff0 + kHoff1 + 2 * kMaxN256) + kCorrBytes + sizeof(float) * kInvEntries +
-                        sizeof(uint32_t) * ((kMaxN256 / 4 + kUHist) / 2 + (kMaxN256 / 16 + kVHist) / 2 + 1) + 3960 <= 163840,
-                "one workgroup per CU: 160 KiB of LDS");
-
-  uint32_t ci, run;
-  if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
-  {
-    return;
-  }
-  const uint32_t c = P.chan_list[ci];
-  const int n256 = (int)P.n256;
-  const uint32_t b_first = run * P.run_len;
-  const uint32_t b_end = min(P.n_blocks, b_first + P.run_len);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool svc = wave < kSvcWaves;
-
-  // the atan2 tables and the dBFS table go to LDS once
-  if (ARITH)
-  {
-    if (tid < kCorrBytes / 16)
-    {
-      reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr)[tid];
-    }
-    else if (tid < kCorrBytes / 16 + kInvEntries / 4)
-    {
-      reinterpret_cast<uint4 *>(atinv)[tid - kCorrBytes / 16] = reinterpret_cast<const uint4 *>(P.at_inv)[tid - kCorrBytes / 16];
-    }
-  }
-  if (tid >= 640 && tid < 768)
-  {
-    dbfs8[tid - 640] = (int8_t)P.dbfs[tid - 640];
-  }
-  if (tid == 0)
-  {
-    svc_ctr = 0u;
-    anybad = 0u;
-    grab[0] = 0u;
-    magtot[0] = 0u;
-    magtot[1] = 0u;
-  }
-  __syncthreads();
-
-  const int hal = P.hal;
-  constexpr int T = kTile;
-  const int wt = P.warm_tiles, M = P.seed_terms;
-  const int W = wt * T;
-  const int nkeep = (wt + M + 1) * T;
-  const int origin = P.origin;
-  const int j0 = (-origin) / T;
-  const ChanState *st = P.state + c;
-  ChanState *so = P.state_out + c;
-  const ChanCfg cfg = P.cfg[c];
-  float kgain = cfg.gain_wbfm / 75000.0f;                // K = (gain/75000)*32767 in float, that order
-  kgain = kgain * 32767.0f;
-  const bool small_y = fabsf(kgain) * 3.3f < 2147483000.0f;   // NaN gain: false
-  uint32_t svc_target = 0;
-  // the quad layout of phase A needs whole 4 KiB pieces everywhere and has no iq-dump variant
-#ifndef HRFD_NO_QUADS
-  const bool quads = (n256 & 255) == 0 && (hal & 255) == 0 && P.iq256 == nullptr && (kRunChunks & 3) == 0 && (kRunSmall & 3) == 0;
-#else
-  const bool quads = false;
-#endif
-  // diagnostics (hrfd_rx_debug_stamps): cycles each wave spent working (not waiting at the block barrier)
-  unsigned long long busy = 0, t_enter = 0;
-  const unsigned long long t_kernel = __builtin_readcyclecounter();
-
-  // everything a (re)production of v needs; `bsel` is the block's buffer
-  auto make_ctx = [&](const uint32_t b, uint32_t *lds, const int hoff) {
-    StreamCtx X;
-    X.P = &P;
-    X.rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int8_t *>(P.iq + (uint64_t)c * P.ch_stride), 0,
-        (int)(P.n_blocks * P.block_bytes), 0x00020000);
-    X.blk_off = b * P.block_bytes;
-    X.st = st;
-    X.lds = lds;
-    X.ounit = (size_t)c * P.out_blocks + P.out_b0 + b;
-    X.kgain = kgain;
-    X.hal = hoff;
-    X.vstart = (b == 0 || b > b_first) ? 0 : -hal;
-    X.n256 = n256;
-    X.lane = lane;
-    X.qoff = 0;
-    X.first = (b == 0);
-    X.atc = atcorr;
-    X.ati = atinv;
-    X.tab = make_uint4(0u, 0u, 0u, 0u);
-    X.publish = false;
-    X.prio_phase = wave >> 2;
-    return X;
-  };
-
-  for (uint32_t step = b_first; step <= b_end; step++)
-  {
-    t_enter = __builtin_readcyclecounter();
-    if (tid == 0)
-    {
-      grab[(step + 1 - b_first) & 1u] = 0u;              // the next step's counter: idle since the barrier before last
-    }
-    if (svc && step > b_first)
-    {
-      // --------------------------------------------------------------- service: phases B and C of block `step - 1`
-#if HRFD_PRIO_ROTATE
-      __builtin_amdgcn_s_setprio(3);                     // long dependent chains, few issue slots: never behind the streaming waves
-#endif
-      const uint32_t b = step - 1;
-      const int bi = (int)((b - b_first) & 1u);
-      uint32_t *lds = bi ? buf1 : buf0;
-      const int hoff = bi ? kHoff1 : kHoff0;
-      const bool first = (b == 0);
-      const bool cont = (b > b_first);
-      const bool last = (b + 1 == P.n_blocks);
-      const size_t unit = (size_t)c * P.n_blocks + b;
-      const StreamCtx X = make_ctx(b, lds, hoff);
-      const int nch = (n256 - X.vstart) >> 6;
-      if (wave == 0)
-      {
-        // the two provisional samples at the start of every run (see k_rx_wbfm)
-        const int nruns = run_count(nch);
-        if (cont && lane == 0)
-        {
-          const float tm1 = tailcarry[0], pm1 = tailcarry[1];
-          const float t0 = u2f(edges[bi][0][0]), t1 = u2f(edges[bi][0][1]);
-          const float p0 = numerator_p(t0, tm1, kgain);
-          const float p1 = numerator_p(t1, t0, kgain);
-          lds[0 + hoff] = f2u(p0 + pm1);
-          lds[1 + hoff] = f2u(p1 + p0);
-        }
-        if (lane >= 1 && lane < nruns)
-        {
-          const int w = lane;
-          const int sw = X.vstart + 64 * run_start(w);
-          const float tm2 = u2f(edges[bi][w - 1][2]), tm1 = u2f(edges[bi][w - 1][3]);
-          const float t0 = u2f(edges[bi][w][0]), t1 = u2f(edges[bi][w][1]);
-          const float pm1 = numerator_p(tm1, tm2, kgain);
-          const float p0 = numerator_p(t0, tm1, kgain);
-          const float p1 = numerator_p(t1, t0, kgain);
-          lds[sw + hoff] = f2u(p0 + pm1);
-          lds[sw + 1 + hoff] = f2u(p1 + p0);
-        }
-        if (lane == 0)
-        {
-          const float tl2 = u2f(edges[bi][nruns - 1][2]), tl1 = u2f(edges[bi][nruns - 1][3]);
-          tailcarry[0] = tl1;
-          tailcarry[1] = numerator_p(tl1, tl2, kgain);
-          anybad = 0u;
-        }
-      }
-      svc_barrier(&svc_ctr, svc_target, lane);           // v is complete
-      if (b + 1 < b_end)
-      {
-        // the next block of the run continues from this one: its history slot gets the tail of v
-        // (the chains below, behind the next barrier, overwrite it with y)
-        uint32_t *nl = bi ? buf0 : buf1;
-        const int nh = bi ? kHoff0 : kHoff1;
-        for (int i = tid; i < nkeep; i += kSvcThreads)
-        {
-          nl[nh - nkeep + i] = lds[n256 - nkeep + i + hoff];
-        }
-      }
-      {
-        const RecurShared R = {parr, wfin, badmask, &anybad, &yanchor};
-        recurrence_phase<3, false, ARITH, false>(P, X, lds, hoff, R, first, cont, wave, lane,
-                                                 [&] { svc_barrier(&svc_ctr, svc_target, lane); });
-      }
-      if (tid == 0)
-      {
-        const int chk = -kHist + 59;
-        const float pub = u2f(lds[n256 + chk + hoff]);
-        P.chk_spec[unit] = first ? 0.0f : (cont ? chk_prev : u2f(lds[chk + hoff]));
-        P.chk_pub[unit] = pub;
-        chk_prev = pub;
-        if (b + 1 < b_end)
-        {
-          yanchor = u2f(lds[n256 + (origin + j0 * T) - W - 1 + hoff]);
-        }
-      }
-      // ----------------------------------------------------------------- phase C on the service waves
-      // C1+C2 fused: U[m] = D(8,4)((int16_t)y), two outputs per thread straight from the float stream
-      // (WbFmDemodulator.cc:468-476); the integer stages' histories are carried (ctail / state)
-      // unless this block re-derived its history.
-      const bool carried = first || cont;
-      uint16_t *U16 = reinterpret_cast<uint16_t *>(ubuf);
-      uint16_t *V16 = reinterpret_cast<uint16_t *>(vbuf);
-      const int16_t *hs = first ? st->wb_s : ctail;
-      const int16_t *hu = first ? st->wb_u : ctail + kWbS;
-      const int16_t *hv = first ? st->wb_v : ctail + kWbS + kWbU;
-      if (carried)
-      {
-        if (tid < kWbU)
-        {
-          U16[kUHist - kWbU + tid] = (uint16_t)hu[tid];
-        }
-        if (tid >= 64 && tid < 64 + kWbV)
-        {
-          V16[kVHist - kWbV + tid - 64] = (uint16_t)hv[tid - 64];
-        }
-      }
-      {
-        const int mmin = carried ? 0 : -kUHist;
-        const int nq = ((n256 >> 2) - mmin) >> 1;
-        auto d8 = [&](auto fixtag) {
-          constexpr bool FIX = decltype(fixtag)::value;
-          for (int q = tid; q < nq; q += kSvcThreads)
-          {
-            const int m = mmin + 2 * q;
-            // y[4m-4 .. 4m+7]: three 16-byte reads
-            const uint4 *yq = reinterpret_cast<const uint4 *>(lds + (4 * m - 4 + hoff));
-            const uint4 a = yq[0], bq = yq[1], cq = yq[2];
-            uint32_t s0 = pack_s16<FIX>(u2f(a.x), u2f(a.y)), s1 = pack_s16<FIX>(u2f(a.z), u2f(a.w));
-            const uint32_t s2 = pack_s16<FIX>(u2f(bq.x), u2f(bq.y)), s3 = pack_s16<FIX>(u2f(bq.z), u2f(bq.w));
-            const uint32_t s4 = pack_s16<FIX>(u2f(cq.x), u2f(cq.y)), s5 = pack_s16<FIX>(u2f(cq.z), u2f(cq.w));
-            if (carried && m == 0)
-            {
-              s0 = reinterpret_cast<const uint32_t *>(hs)[0];   // S[-4 .. -1]: the previous block's last samples
-              s1 = reinterpret_cast<const uint32_t *>(hs)[1];
-            }
-            int acc0 = 1 << 14, acc1 = 1 << 14;
-            acc0 = dot2(s0, kRevWbD1.p[0], acc0);
-            acc0 = dot2(s1, kRevWbD1.p[1], acc0);
-            acc0 = dot2(s2, kRevWbD1.p[2], acc0);
-            acc0 = dot2(s3, kRevWbD1.p[3], acc0);
-            acc1 = dot2(s2, kRevWbD1.p[0], acc1);
-            acc1 = dot2(s3, kRevWbD1.p[1], acc1);
-            acc1 = dot2(s4, kRevWbD1.p[2], acc1);
-            acc1 = dot2(s5, kRevWbD1.p[3], acc1);
-            ubuf[(m + kUHist) >> 1] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
-          }
-        };
-        // |d| <= pi after the wrap, x = K d, and the de-emphasis filter has unit DC gain with positive
-        // impulse response: |y| <= |K| pi (1 + rounding).  Below 2^31 the cast cannot overflow.
-        if (small_y)
-        {
-          d8(std::false_type{});
-        }
-        else
-        {
-          d8(std::true_type{});
-        }
-      }
-      // the last four S samples and the last y, before anybody may overwrite anything
-      uint32_t stail = 0u;
-      if (tid < kWbS / 2)
-      {
-        stail = pack_s16(u2f(lds[n256 - kWbS + 2 * tid + hoff]), u2f(lds[n256 - kWbS + 2 * tid + 1 + hoff]));
-      }
-      svc_barrier(&svc_ctr, svc_target, lane);
-      stage_d12(ubuf, vbuf, carried ? 0 : -kVHist, n256 >> 4, tid, kSvcThreads);
-      svc_barrier(&svc_ctr, svc_target, lane);
-      stage_d40(vbuf, n256 >> 5, reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)(n256 >> 5)), tid, kSvcThreads);
-      // carried histories: for the next call, and for the next block of the run
-      if (last)
-      {
-        if (tid < kWbS / 2)
-        {
-          reinterpret_cast<uint32_t *>(so->wb_s)[tid] = stail;
-        }
-        if (tid < kWbU)
-        {
-          so->wb_u[tid] = (int16_t)U16[kUHist + (n256 >> 2) - kWbU + tid];
-        }
-        if (tid >= 64 && tid < 64 + kWbV)
-        {
-          so->wb_v[tid - 64] = (int16_t)V16[kVHist + (n256 >> 4) - kWbV + tid - 64];
-        }
-        if (tid == 128)
-        {
-          so->wb_y = u2f(lds[n256 - 1 + hoff]);
-          so->wb_theta = tailcarry[0];
-          so->wb_p = tailcarry[1];
-        }
-      }
-      if (b + 1 < b_end)
-      {
-        // (every read of ctail of this block lies before the two barriers above)
-        if (tid < kWbS / 2)
-        {
-          reinterpret_cast<uint32_t *>(ctail)[tid] = stail;
-        }
-        if (tid < kWbU)
-        {
-          ctail[kWbS + tid] = (int16_t)U16[kUHist + (n256 >> 2) - kWbU + tid];
-        }
-        if (tid >= 64 && tid < 64 + kWbV)
-        {
-          ctail[kWbS + kWbU + tid - 64] = (int16_t)V16[kVHist + (n256 >> 4) - kWbV + tid - 64];
-        }
-      }
-    }
-    {
-      if (step < b_end)
-      {
-        // ------------------------------------------------------------- stream: phase A of block `step`
-        // (every wave: the service waves join as soon as they are done with block `step - 1`)
-        const uint32_t b = step;
-        const int bi = (int)((b - b_first) & 1u);
-        uint32_t *lds = bi ? buf1 : buf0;
-        const int hoff = bi ? kHoff1 : kHoff0;
-        const int stid = tid - kSvcThreads;
-        if (b == 0 && stid >= 0 && stid < nkeep)
-        {
-          lds[hoff - nkeep + stid] = 0u;                 // nothing precedes the stream start: the seeds sum zeros
-        }
-        const StreamCtx X = make_ctx(b, lds, hoff);
-        const int nch = (n256 - X.vstart) >> 6;
-        uint32_t magsum = 0;
-        for (;;)
-        {
-          uint32_t g = 0;
-          if (lane == 0)
-          {
-            g = atomicAdd(&grab[bi], 1u);
-          }
-          g = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-          const int c0 = run_start((int)g);
-          if (c0 >= nch)
-          {
-            break;
-          }
-          const int c1 = min(run_start((int)g + 1), nch);
-          uint32_t e[4] = {0u, 0u, 0u, 0u};
-          if (quads)
-          {
-            produce_quads<ARITH>(X, c0 >> 2, c1 >> 2, magsum, e);
-          }
-          else if (P.iq256 != nullptr)
-          {
-            produce_stream<3, false, true, false, ARITH, kStreamDepth, kStreamFence>(X, c0, c1, X.vstart, n256, magsum, e);
-          }
-          else
-          {
-            produce_stream<3, false, false, false, ARITH, kStreamDepth, kStreamFence>(X, c0, c1, X.vstart, n256, magsum, e);
-          }
-          if (lane < 4)
-          {
-            edges[bi][g][lane] = (lane == 0) ? e[0] : (lane == 1) ? e[1] : (lane == 2) ? e[2] : e[3];
-          }
-        }
-        for (int off = 32; off > 0; off >>= 1)
-        {
-          magsum += __shfl_down(magsum, off);
-        }
-        if (lane == 0)
-        {
-          atomicAdd(&magtot[bi], magsum);
-        }
-        if (b + 1 == P.n_blocks && stid >= 0 && stid < 4)
-        {
-          // front-end carry for the next call: the last 16 raw bytes of this block
-          const int8_t *blk = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)b * P.block_bytes;
-          reinterpret_cast<uint32_t *>(so->fe_tail)[stid] =
-              reinterpret_cast<const uint32_t *>(blk + P.block_bytes - 16)[stid];
-        }
-      }
-    }
-    busy += __builtin_readcyclecounter() - t_enter;
-    __syncthreads();
-    if (step < b_end)
-    {
-      // block `step` has been streamed: block-mean magnitude, squelch detector (k_rx_wbfm)
-      const uint32_t b = step;
-      const int bi = (int)((b - b_first) & 1u);
-      // only the call's first block is gated here (a batch speculates "open" for the others and
-      // k_rx_epilogue checks): everybody needs the verdict for b == 0, one wave otherwise
-      bool allowed = true;
-      if (b == 0 || wave == 0)
-      {
-        const uint32_t total = magtot[bi];
-        const uint32_t mean_mag = total / (uint32_t)n256;
-        int32_t dbfs = (int32_t)dbfs8[min(mean_mag, 127u)] - 42;
-        dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
-        const bool present = dbfs >= cfg.threshold;
-        allowed = (b == 0) ? (present || st->tracking != 0) : true;
-        if (tid == 0)
-        {
-          P.magnitude[(size_t)c * P.out_blocks + P.out_b0 + b] = mean_mag;
-          P.present[(size_t)c * P.n_blocks + b] = present ? 1 : 0;
-        }
-      }
-      if (b == 0)
-      {
-        __syncthreads();                                 // every wave has read the sum (once per call)
-      }
-      if (tid == 0)
-      {
-        magtot[bi] = 0u;                                 // ready for the block after next
-      }
-      if (!allowed)
-      {
-        break;                                           // gate violation of a batch: not committed, replayed by the host
-      }
-    }
-  }
-  if (P.dbg != nullptr && lane == 0)
-  {
-    P.dbg[(size_t)blockIdx.x * kDbgSlots + 8 + wave] = busy;
-    if (tid == 0)
-    {
-      P.dbg[(size_t)blockIdx.x * kDbgSlots + 0] = __builtin_readcyclecounter() - t_kernel;
-    }
-  }
-}
-
-template __global__ void k_rx_wbfm_stream<false>(const RxParams);
-template __global__ void k_rx_wbfm_stream<true>(const RxParams);
 
 // =============================================================================
 //  finish: per channel -- squelch tracker over the batch, verification of both speculations,

@@ -176,6 +176,41 @@ int hrfd_ingest_collect(hrfd_ingest *g, const int16_t **pcm, const uint32_t **n_
 int hrfd_ingest_replayed(hrfd_ingest *g, uint64_t *n_batches);
 
 /* ------------------------------------------------------------------------------
+ * One host process, several devices.  The reference wires its whole receive path into one process
+ * (src_diags/Radio.cc:164-237: one IqDataProcessor, its demodulators, one DataConsumer thread); a host that drives many
+ * channels on the GPUs of a node stays one process too.  Channels share nothing, so n_devices devices are n_devices
+ * contiguous channel shards -- shard g owns channels [first, first + count) of hrfd_fanout_channel_range: sizes differ
+ * by at most one -- each an hrfd_rx of its own on its device, state pinned there.  No collective: IQ that lands on one
+ * device leaves it as one peer copy per shard, every copy on the receiving shard's stream (xGMI is point to point: the
+ * links out of the source work at the same time; in-process, no RCCL bootstrap), and the PCM comes back the same way.
+ * devices[] may name a device more than once (several shards on one GPU).
+ *   hrfd_fanout_scatter   d_iq_all [n_channels][n_blocks][block_bytes] on src_device -> the shards' input buffers;
+ *                         src_stream: the stream that produced d_iq_all (awaited on the devices), NULL = complete
+ *   hrfd_fanout_input     instead of scatter: the shard's own input buffer, for a host that feeds every device itself
+ *   hrfd_fanout_process   IqDataProcessor::acceptIqData (IqDataProcessor.cc:926-1038) for every channel, n_blocks
+ *                         blocks each, all devices at once, asynchronous
+ *   hrfd_fanout_collect   waits, replays exactly what failed its speculation (as hrfd_rx_process_block does), gathers
+ *                         pcm [n_channels][n_blocks][block_bytes/512] and n_pcm [n_channels][n_blocks] (may be NULL)
+ *                         into buffers on dst_device; *n_replayed (may be NULL) = channels replayed
+ * The setters take channel numbers of the whole bank (HRFD_ALL_CHANNELS: every shard).
+ * (The multi-process counterpart -- one rank per GPU, RCCL -- is hackrfdiags_amd/shard.py, used by bench.py --gpus N.)
+ */
+typedef struct hrfd_fanout hrfd_fanout;
+int hrfd_fanout_channel_range(uint32_t n_channels, uint32_t n_shards, uint32_t shard, uint32_t *first, uint32_t *count);
+int hrfd_fanout_create(uint32_t n_channels, const int *devices, uint32_t n_devices, hrfd_fanout **out);
+int hrfd_fanout_destroy(hrfd_fanout *f);
+int hrfd_fanout_shards(hrfd_fanout *f, uint32_t *n_shards);
+int hrfd_fanout_set_mode(hrfd_fanout *f, uint32_t channel, int mode);
+int hrfd_fanout_set_gain(hrfd_fanout *f, uint32_t channel, int mode, float gain);
+int hrfd_fanout_set_threshold(hrfd_fanout *f, uint32_t channel, int32_t threshold);
+int hrfd_fanout_scatter(hrfd_fanout *f, int src_device, const int8_t *d_iq_all, uint32_t block_bytes, uint32_t n_blocks,
+                        void *src_stream);
+int hrfd_fanout_input(hrfd_fanout *f, uint32_t shard, uint32_t block_bytes, uint32_t n_blocks, int8_t **d_iq,
+                      uint32_t *first_channel, uint32_t *n_shard_channels);
+int hrfd_fanout_process(hrfd_fanout *f, uint32_t gain_db);
+int hrfd_fanout_collect(hrfd_fanout *f, int dst_device, int16_t *d_pcm_all, uint32_t *d_n_pcm_all, uint32_t *n_replayed);
+
+/* ------------------------------------------------------------------------------
  * Transmit: PCM -> int8 IQ through the 8-stage x256 half-band interpolator.
  * kind HRFD_MOD_SSB replaces SsbModulator::acceptData (SsbModulator.cc:455-470)
  * incl. set{Lsb,Usb}ModulationMode / resetModulator (SsbModulator.h:23-35);

@@ -42,7 +42,7 @@ def test_wbfm_512_and_1024_channels(oracle, C):
     rx.set_mode(api.WBFM)
     ref_other = api.Rx(C)
     ref_other.set_mode(api.WBFM)
-    ref_other.debug_set_stream(1)                        # k_rx_wbfm_stream
+    ref_other.debug_set_stream(0)                        # k_rx_wbfm: runs of blocks, phases in sequence
     for half in range(2):
         for c in range(C):
             x[c] = torch.from_numpy(base[c % NBASE][half * B:(half + 1) * B]).to(dev)

@@ -662,14 +662,14 @@ def test_odd_shapes_mixed_modes_and_runs(oracle):
             assert (pcm[c, b, :len(want)] == want).all(), (c, m, b)
 
 
-@pytest.mark.parametrize("stream", [True, False], ids=["stream_kernel", "per_block_kernel"])
-@pytest.mark.parametrize("bb,dump", [(262144, False), (262144, True), (36864, False), (21504, False), (21504, True)],
-                         ids=["full", "full_iqdump", "n256_2304_quads", "n256_1344_no_quads", "n256_1344_iqdump"])
+@pytest.mark.parametrize("stream", [True, False], ids=["flow_kernel_where_it_applies", "per_block_kernel"])
+@pytest.mark.parametrize("bb,dump", [(262144, False), (262144, True), (65536, True), (36864, False), (21504, False), (21504, True)],
+                         ids=["full", "full_iqdump", "n256_4096_iqdump", "n256_2304", "n256_1344", "n256_1344_iqdump"])
 def test_wbfm_batches_on_both_kernels_and_layouts(oracle, stream, bb, dump):
-    """WBFM batches through k_rx_wbfm_stream (default) and k_rx_wbfm (hook): the quad layout of phase A
-    (n256 a multiple of 256, no iq dump), its chunk-layout fallbacks, block sizes down to the shortest
-    a batch may have, runs that start with re-derived history (run_len 2 and 3) -- PCM, magnitudes and
-    the 256 kS/s dump bit-exact, every launch committed."""
+    """WBFM batches through k_rx_wbfm_flow (the default where the block is whole units of 512 samples at 256 kS/s,
+    with and without the iq dump: k_rx_wbfm_flow<DUMP>) and through k_rx_wbfm (the hook, and the default for the
+    other block sizes): block sizes down to the shortest a batch may have, runs that start with re-derived history
+    (run_len 2 and 3) -- PCM, magnitudes and the 256 kS/s dump bit-exact, every launch committed."""
     C, B = 3, 6
     n = C * B * bb
     raw = np.concatenate([synth.make_input("fmtone" if c else "lcg", 120 + c, (B * bb + BLK - 1) // BLK)[: B * bb]
