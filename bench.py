@@ -462,7 +462,7 @@ def rx_workload_text(workload, C, B, world, signal, scatter, quiet_fraction=0.0,
 
 
 def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmup, settle, rank, world,
-               scatter=False, quiet_fraction=0.0, threshold=None, iqdump=False, idle_s=0.0, serial_modes=False):
+               scatter=False, quiet_fraction=0.0, threshold=None, iqdump=False, idle_s=0.0, serial_modes=False, stride_pad=0):
     """K timed steps of the receive path over one resident batch [C][B][262144]; returns the figures of a bench line.
     The dominant kernels' time comes from HIP events the library records on its launch stream(s) around the
     demodulator kernels of every launch (hrfd_rx_debug_enable_timing)."""
@@ -476,6 +476,11 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
         q = make_quiet_batch(n_quiet, B, device, first_channel=rank * C)
         iq[torch.tensor(quiet, device=device)] = q
         del q
+    stride = B * BLOCK + stride_pad
+    if stride_pad:
+        padded = torch.zeros((C, stride), dtype=torch.int8, device=device)
+        padded[:, :B * BLOCK] = iq.reshape(C, B * BLOCK)
+        iq = padded
     pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=device)
     n_pcm = torch.zeros((C, B), dtype=torch.int32, device=device)
     iq256 = torch.zeros((C, B, BLOCK // 8), dtype=torch.int8, device=device) if iqdump else None
@@ -504,7 +509,7 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
         if scatter:
             with torch.cuda.stream(stream):
                 shard.scatter_iq(iq_root, iq, world * C)     # one group of sends out of rank 0, straight into `iq`
-        rx.process_device(iq.data_ptr(), B * BLOCK, BLOCK, B, pcm.data_ptr(), d_n_pcm=n_pcm.data_ptr(),
+        rx.process_device(iq.data_ptr(), stride, BLOCK, B, pcm.data_ptr(), d_n_pcm=n_pcm.data_ptr(),
                           d_iq256=None if iq256 is None else iq256.data_ptr(), stream=stream.cuda_stream)
 
     if idle_s > 0:
@@ -626,6 +631,8 @@ def main():
     ap.add_argument("--iqdump", action="store_true", help="also write the 256 kS/s stream (`enable iqdump`)")
     ap.add_argument("--serial-modes", action="store_true",
                     help="mixed bank: the modes' kernels one after the other (test hook; default: the WBFM flow kernel beside the rest)")
+    ap.add_argument("--stride-pad", type=int, default=0,
+                    help="experiment: extra bytes between the channels' input buffers (channel_stride = blocks * 262144 + pad)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -673,7 +680,7 @@ def main():
     r = measure_rx(api, shard, device, dist, workload=args.workload, C=C, B=B, signal=args.signal, steps=args.steps,
                    warmup=args.warmup, settle=settle, rank=rank, world=world, scatter=args.scatter,
                    quiet_fraction=args.quiet_fraction, threshold=args.threshold, iqdump=args.iqdump,
-                   serial_modes=args.serial_modes)
+                   serial_modes=args.serial_modes, stride_pad=args.stride_pad)
     counters = r["counters"]
     assert r["pcm_produced"] == r["pcm_expected"], f"PCM samples produced {r['pcm_produced']} != {r['pcm_expected']}"
     traffic, ptag = pmc_traffic_bytes(args, C, B)

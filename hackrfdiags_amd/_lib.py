@@ -92,6 +92,7 @@ def load() -> C.CDLL:
     L.hrfd_rx_debug_expire.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_set_split.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_set_gated.argtypes = [_vp, C.c_int]
+    L.hrfd_rx_debug_set_fir_flow.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_set_stream.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_set_run_len.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_stamps.argtypes = [_vp, C.c_uint32, _vp]

@@ -132,6 +132,10 @@ class Rx:
         2 = k_rx_wbfm_flow where it applies (the default)"""
         check(self.L.hrfd_rx_debug_set_stream(self.h, int(kernel)), "hrfd_rx_debug_set_stream")
 
+    def debug_set_fir_flow(self, mode: int):
+        """test hook: AM / SSB / FM batches on the flow kernel's FIR modes: -1 automatic, 0 never, 1 always"""
+        check(self.L.hrfd_rx_debug_set_fir_flow(self.h, int(mode)), "hrfd_rx_debug_set_fir_flow")
+
     def debug_set_gated(self, on: bool):
         """test hook: False = no gated second pass on the device (closed gates in a batch go back to the host's replay)"""
         check(self.L.hrfd_rx_debug_set_gated(self.h, int(bool(on))), "hrfd_rx_debug_set_gated")

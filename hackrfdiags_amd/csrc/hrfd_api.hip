@@ -162,9 +162,10 @@ struct hrfd_rx
   uint32_t *d_counters = nullptr;       // [kNumDevCounters] + a second set of the per-launch counters [kCntSticky]
   uint32_t *d_local = nullptr;          // the per-launch counters of the latest launch (set 0 = d_counters, set 1 behind it)
   int parity = 0;
-  uint32_t *d_lists = nullptr;         // [9][n_channels] channel ids grouped by mode; list 6: every channel that is not WBFM,
-                                       // list 7: the AM and SSB channels, list 8: those followed by the FM channels
-  uint32_t list_count[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t *d_lists = nullptr;         // [10][n_channels] channel ids grouped by mode; list 6: every channel that is not WBFM,
+                                       // list 7: the AM and SSB channels, list 8: those followed by the FM channels,
+                                       // list 9: every channel but those in mode NONE
+  uint32_t list_count[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t *d_sub_lists = nullptr;     // the same for a launch over a subset of the channels (replay of failed channels);
                                        // list 6 there: the subset itself
   uint32_t *d_chan = nullptr;          // [4][n_channels]: chan_fail, chan_poison, chan_expired, chan_arrived (EpilogueParams)
@@ -206,6 +207,7 @@ struct hrfd_rx
   int run_len = 0;                     // test hook: blocks per workgroup run of k_rx_wbfm (0 = automatic)
   int use_stream = 2;                  // test hook: 0 = WBFM batches on k_rx_wbfm (runs of blocks, phases in sequence) instead of k_rx_wbfm_flow
   int32_t wbfm_max_threshold = -200;   // the highest squelch threshold among the WBFM channels (can a gate close at all?)
+  int fir_flow = -1;                   // test hook: AM / SSB / FM batches on the flow kernel's FIR modes: -1 when the bank is large enough, 0 never, 1 always
   int gated_pass = 1;                  // test hook: 0 = no gated second pass on the device (closed gates go back to the host's replay)
   int split_modes = 1;                 // test hook: 0 = a bank of several modes runs its kernels one after the other
   int expire_once = 0;                 // test hook: the next k_rx_wbfm_flow launch treats this wait (1..6) of workgroup 0 as expired
@@ -305,8 +307,8 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && alloc((void **)&h->d_att0, sizeof(float) * kCorrBytes);
   ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
   ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * (kNumDevCounters + kCntSticky));
-  ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 9 * n_channels);
-  ok = ok && alloc((void **)&h->d_sub_lists, sizeof(uint32_t) * 9 * n_channels);
+  ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 10 * n_channels);
+  ok = ok && alloc((void **)&h->d_sub_lists, sizeof(uint32_t) * 10 * n_channels);
   ok = ok && alloc((void **)&h->d_chan, sizeof(uint32_t) * 4 * n_channels);
   if (!ok)
   {
@@ -645,6 +647,17 @@ extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
   return HRFD_OK;
 }
 
+// test hook: AM / SSB / FM batches on the flow kernel's FIR modes: -1 automatic (banks of 48 channels or more per kind), 0 never, 1 always
+extern "C" int hrfd_rx_debug_set_fir_flow(hrfd_rx *h, int mode)
+{
+  if (h == nullptr || mode < -1 || mode > 1)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_set_fir_flow: -1, 0 or 1");
+  }
+  h->fir_flow = mode;
+  return HRFD_OK;
+}
+
 // test hook: 0 = no gated second pass on the device; a channel with a closed gate in a batch stays failed (the host replays it)
 extern "C" int hrfd_rx_debug_set_gated(hrfd_rx *h, int on)
 {
@@ -829,7 +842,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   }
 
   // configuration snapshot
-  uint32_t sub_count[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t sub_count[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<uint32_t> sub_lists;
   std::vector<std::pair<uint32_t, int>> resets;
   {
@@ -837,8 +850,8 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     resets.swap(h->pending_resets);
     if (h->cfg_dirty)
     {
-      std::vector<uint32_t> lists((size_t)9 * h->n_channels);
-      uint32_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      std::vector<uint32_t> lists((size_t)10 * h->n_channels);
+      uint32_t cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       for (uint32_t c = 0; c < h->n_channels; c++)
       {
         const int m = h->h_cfg[c].mode;
@@ -851,8 +864,11 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
         {
           lists[(size_t)7 * h->n_channels + cnt[7]++] = c;
         }
+        if (m != HRFD_MODE_NONE)
+        {
+          lists[(size_t)9 * h->n_channels + cnt[9]++] = c;   // list 9: every channel that has a demodulator (k_rx_flow_bank)
+        }
       }
-
       // list 8: the AM and SSB channels (their 8 kS/s tails run beside what follows), then the FM channels
       for (uint32_t i = 0; i < cnt[7]; i++)
       {
@@ -880,7 +896,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     if (opt.subset != nullptr)
     {
       // per-mode lists of the subset (list 6: the subset itself); only the modes are read under the lock
-      sub_lists.resize((size_t)9 * h->n_channels);
+      sub_lists.resize((size_t)10 * h->n_channels);
       for (uint32_t c : *opt.subset)
       {
         const int m = h->h_cfg[c].mode;
@@ -1046,7 +1062,11 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   // k_rx_wbfm_flow: whole units of two 4 KiB pieces, the first-octant-table atan2
   const bool flow = streaming && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 &&
                     (n256 % 512u) == 0 && n256 >= 2048u;
-  const bool split = flow && opt.subset == nullptr && list_count[6] != 0 && h->split_modes;
+  // A bank of several modes as ONE launch (k_rx_flow_bank: one persistent workgroup per channel, the mode read per
+  // workgroup): whole-bank batches of whole units without the iq dump, up to 16 blocks, channels enough to fill the chip
+  const bool bank = flow && opt.subset == nullptr && d_iq256 == nullptr && n_blocks <= 16u && h->fir_flow != 0 && h->split_modes &&
+                    (list_count[7] + list_count[HRFD_MODE_FM]) != 0 && (h->fir_flow > 0 || list_count[9] >= 48u);
+  const bool split = flow && !bank && opt.subset == nullptr && list_count[6] != 0 && h->split_modes;
   hipStream_t fs = split ? h->side : s;                    // where the kernels of the other modes go
   hipStream_t ws = s;                                      // ... and the flow kernel: first in line, on the caller's stream
 
@@ -1131,6 +1151,30 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     return HRFD_OK;
   };
 
+  if (bank)
+  {
+    P.chan_list = d_lists + (size_t)9 * h->n_channels;
+    P.n_list = list_count[9];
+    P.run_len = n_blocks;
+    P.n_runs = 1;
+    P.self_finish = 1;
+    P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);
+    P.dbg_flags |= h->expire_once << 16;
+    h->expire_once = 0;
+    hipLaunchKernelGGL((k_rx_flow_bank<HRFD_FLOW_SVC>), dim3(8u * ((P.n_list + 7u) / 8u)), dim3(kThreads), 0, s, P);
+    P.dbg_flags &= 0xffff;
+    HIP_TRY(hipGetLastError());
+    if (n_wb != 0 && h->gated_pass && (int64_t)h->wbfm_max_threshold > -42 - (int64_t)gain_db)
+    {
+      // the gated second pass over the WBFM channels whose gates closed (see launch_wbfm_or_none)
+      P.chan_list = d_lists + (size_t)HRFD_MODE_WBFM * h->n_channels;
+      P.n_list = n_wb;
+      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>), dim3(8u * ((n_wb + 7u) / 8u)), dim3(kThreads), 0, s, P);
+      HIP_TRY(hipGetLastError());
+    }
+    P.self_finish = 0;
+    P.warm_tiles = warm_tiles;
+  }
   if (split)
   {
     // everything submitted to the launch stream so far (resets, the previous launch) is in front of both parts
@@ -1147,7 +1191,56 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   //  * the inner demodulator API and the replay of a subset (single blocks, latency paths): the same kernels with a
   //    finisher kernel at the end.
   const bool fir_self = !opt.src256 && opt.subset == nullptr;
-  if (split && list_count[8] != 0)
+  // The flow kernel's FIR modes (k_rx_wbfm_flow<.., 2> FM, <.., 14> AM / SSB): one persistent workgroup per channel,
+  // the whole call as one stream, everything finished inside.  For whole-bank batches of whole units without the iq
+  // dump, when there are channels enough to fill the chip that way.
+  auto fir_flow_ok = [&](uint32_t n, bool needs_tab) -> bool {
+    if (!fir_self || h->fir_flow == 0 || n_blocks < 2u || n_blocks > 64u || (n256 % 512u) != 0 || n256 < 2048u || d_iq256 != nullptr)
+    {
+      return false;
+    }
+    if (needs_tab && (!h->tab_ok || h->atan_mode == 0))
+    {
+      return false;
+    }
+    return h->fir_flow > 0 || n >= 48u;
+  };
+  auto launch_fir_flow = [&](int list, uint32_t n, bool fm) -> int {
+    P.chan_list = d_lists + (size_t)list * h->n_channels;
+    P.n_list = n;
+    P.run_len = n_blocks;
+    P.n_runs = 1;
+    P.self_finish = 1;
+    P.warm_tiles = 1;                                      // ring tiles a generation reads below its own
+    const uint32_t grid = 8u * ((n + 7u) / 8u);
+    if (fm)
+    {
+      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 2>), dim3(grid), dim3(kThreads), 0, fs, P);
+    }
+    else
+    {
+      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 14>), dim3(grid), dim3(kThreads), 0, fs, P);
+    }
+    P.self_finish = 0;
+    P.warm_tiles = warm_tiles;
+    HIP_TRY(hipGetLastError());
+    return HRFD_OK;
+  };
+  const bool amssb_flow = !bank && list_count[7] != 0 && fir_flow_ok(list_count[7], false);
+  const bool fm_flow = !bank && list_count[HRFD_MODE_FM] != 0 && fir_flow_ok(list_count[HRFD_MODE_FM], true);
+  if (amssb_flow)
+  {
+    if ((rc = launch_fir_flow(7, list_count[7], false)) != HRFD_OK) return rc;
+  }
+  if (fm_flow)
+  {
+    if ((rc = launch_fir_flow(HRFD_MODE_FM, list_count[HRFD_MODE_FM], true)) != HRFD_OK) return rc;
+  }
+  if (bank)
+  {
+    // (everything with a demodulator went out in the bank launch)
+  }
+  else if (split && list_count[8] != 0 && !amssb_flow && !fm_flow)
   {
     P.chan_list = d_lists + (size_t)8 * h->n_channels;
     P.n_list = list_count[8];
@@ -1166,7 +1259,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   }
   else
   {
-    if (list_count[7] != 0)
+    if (list_count[7] != 0 && !amssb_flow)
     {
       const uint32_t n = list_count[7];
       P.chan_list = d_lists + (size_t)7 * h->n_channels;
@@ -1185,7 +1278,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       P.self_finish = 0;
       HIP_TRY(hipGetLastError());
     }
-    if (list_count[HRFD_MODE_FM] != 0)
+    if (list_count[HRFD_MODE_FM] != 0 && !fm_flow)
     {
       const uint32_t n = list_count[HRFD_MODE_FM];
       P.chan_list = d_lists + (size_t)HRFD_MODE_FM * h->n_channels;
@@ -1209,7 +1302,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     }
   }
   if ((rc = launch_wbfm_or_none(HRFD_MODE_NONE, fs)) != HRFD_OK) return rc;
-  if (!split)
+  if (!split && !bank)
   {
     if ((rc = launch_wbfm_or_none(HRFD_MODE_WBFM, s)) != HRFD_OK) return rc;
   }

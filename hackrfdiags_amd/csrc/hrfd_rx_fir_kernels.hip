@@ -23,10 +23,6 @@
 
 namespace hrfd {
 
-__constant__ constexpr RevTaps<N_FM_TUNER_D32> kRevTuner(Q_FM_TUNER_D32);
-__constant__ constexpr RevTaps<N_AM_D1> kRevAmD1(Q_AM_D1);
-__constant__ constexpr RevTaps<N_AM_D2> kRevAmD2(Q_AM_D2);
-__constant__ constexpr RevTaps<N_AM_D3> kRevAmD3(Q_AM_D3);
 
 constexpr int kFirRailI16 = kFmTail + kMaxN256 + 8;            // int16 per rail (FM is the larger)
 constexpr int kFirDwords = kFirRailI16;                         // two rails of int16 = kFirRailI16 dwords

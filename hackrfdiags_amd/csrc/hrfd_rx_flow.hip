@@ -242,35 +242,93 @@ constexpr int kFinWords = 168;
 // state is frozen), while the front end runs over everything (a block's 16 bytes of history are its physical
 // predecessor's last).  Squelched blocks get zero PCM and n_pcm = 0.  Every other channel's workgroup leaves at once.
 // DUMP: the 256 kS/s stream of `enable iqdump` (IqDataProcessor.cc:953-957) goes out as well, 8 bytes per lane and piece.
-template <int SVC, bool GATED, bool DUMP>
-__global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
+//
+// MODE: 3 WBFM (everything above).  2 (FM) and 14 (AM or SSB, read from the channel's configuration) run the FIR
+// demodulators in the same shape -- one persistent workgroup per channel, the whole call as ONE stream: the stream
+// waves stop behind the Fs/4 mixer and put the 256 kS/s samples into the ring as two rails of int16 PAIRS (offset
+// binary: the first decimator's rounding constant absorbs the 128), the service waves run the channel's decimators on
+// tiles straight out of the ring (fir_service_*, below).  Nothing of that has a time-parallel speculation in it: the
+// 8 kS/s dc-removal recurrence of AM / SSB runs sequentially, 128 steps per generation, in generation order, so these
+// modes need no tail kernel, no verification and no cross-workgroup hand-over.  One unit of history (512 samples)
+// sits in front of the stream, filled from the carried input tail.  One run per channel only (the host sees to it).
+// LDS of the kernel, as dword offsets into one array (the arrays of the three modes differ in size, and
+// k_rx_flow_bank runs all three bodies over one allocation)
+template <int MODE>
+struct FlowLds
 {
-  __shared__ __attribute__((aligned(16))) uint32_t ring[kFRingTiles * kFStride];
-  __shared__ __attribute__((aligned(16))) uint8_t atcorr[kCorrBytes];   // theta_tab: correction bytes ...
-  __shared__ __attribute__((aligned(16))) float att0[kCorrBytes];       // ... and the first-octant table
-  __shared__ __attribute__((aligned(16))) uint32_t uring[kFUDw];
-  __shared__ __attribute__((aligned(16))) uint32_t vring[kFVDw];
-  __shared__ uint32_t edges[kFEdges][4];   // per unit: theta of its first two and last two samples
-  __shared__ uint32_t uflag[kFEdges];      // unit u is complete in the ring: u + 1
-  __shared__ float parr[kFPRing];          // per tile: geometric partial sum of v
-  __shared__ uint32_t pflag[8];            // partial sums of generation g are in parr: g + 1
-  __shared__ uint32_t ctl[24];             // 0 next unit, 1 generations verified (their v is released), 2 generations complete (U, V, PCM), 3 blocks finished,
-                                           // 4 next generation, 5 waves of the workgroup that are through,
-                                           // 8..23 units done (per block, mod 16)
-  __shared__ uint32_t magl[16][64];        // per block (mod 16: more blocks than the ring can span) and lane: sum of the sample
-                                           // magnitudes.  One word per lane: a
+  static constexpr bool kAtan = (MODE != 14);            // theta_tab: WBFM and FM
+  static constexpr int kRails = (MODE == 14) ? 2 : 1;    // AM / SSB keep both rails through all three decimators
+  static constexpr int kVDw = (MODE == 14) ? 2 * kFVDw : kFVDw;   // V ring per rail (AM / SSB: four generations, fir service c)
+  static constexpr int k8k = (MODE == 14) ? 512 : 4;     // AM / SSB: int16 per rail of the 8 kS/s rings (four generations)
+  static constexpr int oRing = 0;
+  static constexpr int oAtcorr = oRing + kFRingTiles * kFStride;
+  static constexpr int oAtt0 = oAtcorr + (kAtan ? kCorrBytes / 4 : 4);
+  static constexpr int oUring = oAtt0 + (kAtan ? kCorrBytes : 4);
+  static constexpr int oVring = oUring + kRails * kFUDw;
+  static constexpr int oR8k = oVring + kRails * kVDw;
+  static constexpr int oXs = oR8k + k8k;                  // (two rails of int16 = k8k dwords)
+  static constexpr int oYs = oXs + ((MODE == 14) ? 128 : 4);
+  static constexpr int oRcar = oYs + ((MODE == 14) ? 128 : 4);
+  static constexpr int oThfin = oRcar + 4;
+  static constexpr int oEdges = oThfin + 4;
+  static constexpr int oUflag = oEdges + 4 * kFEdges;
+  static constexpr int oParr = oUflag + kFEdges;
+  static constexpr int oPflag = oParr + kFPRing;
+  static constexpr int oCtl = oPflag + 8;
+  static constexpr int oMagl = oCtl + 24;
+  static constexpr int oDbfs = oMagl + 16 * 64;
+  static constexpr int oBlkout = oDbfs + 32;
+  static constexpr int oWfin = oBlkout + 64;
+  static constexpr int oFinl = oWfin + 4;
+  static constexpr int oBlist = oFinl + kFinWords;
+  static constexpr int oGctl = oBlist + 16;
+  static constexpr int kTotal = oGctl + 4;
+  static_assert(kTotal * 4 <= 163840, "LDS");
+  static_assert((oAtcorr % 4) == 0 && (oAtt0 % 4) == 0 && (oUring % 4) == 0 && (oVring % 4) == 0 && (oXs % 4) == 0 && (oYs % 4) == 0 &&
+                (kFinWords % 4) == 0, "16-byte alignment of what is accessed as 128-bit words");
+};
+
+template <int SVC, bool GATED, bool DUMP, int MODE>
+__device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds)
+{
+  static_assert(MODE == 3 || MODE == 2 || MODE == 14, "WBFM, FM, AM / SSB");
+  static_assert(MODE == 3 || (!GATED && !DUMP), "the gated pass and the iq dump are WBFM's");
+  typedef FlowLds<MODE> Lds;
+  constexpr bool kWb = (MODE == 3);
+  constexpr bool kAtan = Lds::kAtan;
+  constexpr int kRails = Lds::kRails;
+  constexpr int kVDw = Lds::kVDw;
+  uint32_t *const ring = lds + Lds::oRing;                  // kFRingTiles * kFStride
+  uint8_t *const atcorr = reinterpret_cast<uint8_t *>(lds + Lds::oAtcorr);   // theta_tab: correction bytes ...
+  float *const att0 = reinterpret_cast<float *>(lds + Lds::oAtt0);           // ... and the first-octant table
+  uint32_t *const uring = lds + Lds::oUring;                // kRails * kFUDw
+  uint32_t *const vring = lds + Lds::oVring;                // kRails * kVDw
+  // AM / SSB at 8 kS/s: four generations of the last decimator's outputs per rail (SSB: the Hilbert transformer reads 30
+  // back), a generation's recurrence input and output, and the recurrence's carried x[n-1], y[n-1]
+  int16_t (*const r8k)[Lds::k8k] = reinterpret_cast<int16_t (*)[Lds::k8k]>(lds + Lds::oR8k);
+  float *const xs8k = reinterpret_cast<float *>(lds + Lds::oXs), *const ys8k = reinterpret_cast<float *>(lds + Lds::oYs);
+  float *const rcar = reinterpret_cast<float *>(lds + Lds::oRcar);
+  uint32_t *const thfin = lds + Lds::oThfin;                // FM: theta of the last four 64 kS/s samples of the last finished generation
+  uint32_t (*const edges)[4] = reinterpret_cast<uint32_t (*)[4]>(lds + Lds::oEdges);   // per unit: theta of its first two and last two samples
+  uint32_t *const uflag = lds + Lds::oUflag;                // unit u is complete in the ring: u + 1
+  float *const parr = reinterpret_cast<float *>(lds + Lds::oParr);   // per tile: geometric partial sum of v
+  uint32_t *const pflag = lds + Lds::oPflag;                // partial sums of generation g are in parr: g + 1
+  uint32_t *const ctl = lds + Lds::oCtl;                    // 0 next unit, 1 generations verified (their v is released), 2 generations complete (U, V, PCM), 3 blocks finished,
+                                                          // 4 next generation, 5 waves of the workgroup that are through,
+                                                          // 8..23 units done (per block, mod 16)
+  uint32_t (*const magl)[64] = reinterpret_cast<uint32_t (*)[64]>(lds + Lds::oMagl);   // per block (mod 16: more blocks than the ring
+                                           // can span) and lane: sum of the sample magnitudes.  One word per lane: a
                                            // same-address atomic from 64 lanes becomes a 64-step scalar loop (LLVM's atomic
                                            // optimizer), measured at half of the kernel's time
-  __shared__ int8_t dbfs8[128];            // the reachable part of the dBFS table
-  __shared__ uint32_t blkout[64];          // per block of the run: mean magnitude | present << 31 (written out at the end:
+  int8_t *const dbfs8 = reinterpret_cast<int8_t *>(lds + Lds::oDbfs);   // the reachable part of the dBFS table
+  uint32_t *const blkout = lds + Lds::oBlkout;              // per block of the run: mean magnitude | present << 31 (written out at the end:
                                            // a global store inside the unit loop costs the loop its counted vmcnt waits)
-  __shared__ uint32_t wfin[4];             // the last finished generation's last lane: y, its last two S pairs
-  __shared__ uint32_t finl[kFinWords];     // a channel that is ONE workgroup's is finished from here (no memory round trip behind
+  uint32_t *const wfin = lds + Lds::oWfin;                  // the last finished generation's last lane: y, its last two S pairs
+  uint32_t *const finl = lds + Lds::oFinl;                  // a channel that is ONE workgroup's is finished from here (no memory round trip behind
                                            // the last sample): 0..63 y in front of block b, 128..159 the pending WBFM state
                                            // section, 160 tracking, 161 poison, 162..165 the pending fe_tail
-  __shared__ uint8_t blist[GATED ? 64 : 4];  // GATED: the blocks of the stream, in order (the allowed ones)
-  __shared__ uint32_t gctl[4];             // GATED: 0 number of allowed blocks, 1 `present` of the call's last block
-  static_assert(sizeof(uint32_t) * (kFRingTiles * kFStride + kFUDw + kFVDw + 5 * kFEdges + kFPRing + 1024 + 48 + kFinWords) + 5 * kCorrBytes <= 163840, "LDS");
+  uint8_t *const blist = reinterpret_cast<uint8_t *>(lds + Lds::oBlist);   // GATED: the blocks of the stream, in order (the allowed ones)
+  uint32_t *const gctl = lds + Lds::oGctl;                  // GATED: 0 number of allowed blocks, 1 `present` of the call's last block; AM / SSB: 2 generations through their 8 kS/s part
 
   uint32_t ci, run;
   if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
@@ -327,8 +385,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   const uint32_t b_first = GATED ? 0u : run * P.run_len;
   const uint32_t b_end = GATED ? n_stream_blocks : min(P.n_blocks, b_first + P.run_len);
   const bool first = (b_first == 0);                     // the stream continues from the carried state: exact start
-  const bool local = GATED || (P.self_finish != 0 && P.n_runs == 1u && P.n_blocks <= 64u);   // the channel is this workgroup's alone
-  const int hal = first ? 0 : P.flow_hal;                // history re-derived in front of the run (samples)
+  const bool local = GATED || (kWb && P.self_finish != 0 && P.n_runs == 1u && P.n_blocks <= 64u);   // the channel is this workgroup's alone
+  // history in front of the run (samples): WBFM re-derives it from the input when the run does not start the call; the
+  // FIR modes always have one unit, from the carried tail (their runs start the call)
+  const int hal = kWb ? (first ? 0 : P.flow_hal) : 512;
   const int L = hal + (int)(b_end - b_first) * n256;     // samples of the stream
   const int n_units = L >> 9, n_tiles = L >> 6, n_gens = (n_tiles + 63) >> 6;
   const int upb = n256 >> 9;                             // units per block
@@ -346,11 +406,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
 
   // tables and control words
   magl[0][tid] = 0u;
-  for (int i = tid; i < kCorrBytes / 4; i += kThreads)
+  if (kAtan)
   {
-    reinterpret_cast<uint4 *>(att0)[i] = reinterpret_cast<const uint4 *>(P.at_t0)[i];
+    for (int i = tid; i < kCorrBytes / 4; i += kThreads)
+    {
+      reinterpret_cast<uint4 *>(att0)[i] = reinterpret_cast<const uint4 *>(P.at_t0)[i];
+    }
   }
-  if (tid < kCorrBytes / 16)
+  if (kAtan && tid < kCorrBytes / 16)
   {
     reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr2)[tid];
   }
@@ -371,13 +434,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   {
     reinterpret_cast<uint32_t *>(dbfs8)[tid - 840] = 0u;
   }
-  else if (tid >= 832 && tid < 836 && first)
+  else if (kWb && tid >= 832 && tid < 836 && first)
   {
     // what the lane in front of tile 0 would have left: the carried y and the last four S samples
     wfin[tid - 832] = (tid == 832) ? f2u(st->wb_y) : (tid == 833) ? reinterpret_cast<const uint32_t *>(st->wb_s)[0]
                                                    : (tid == 834) ? reinterpret_cast<const uint32_t *>(st->wb_s)[1] : 0u;
   }
-  else if (tid >= 896 && tid < 900 && first)
+  else if (kWb && tid >= 896 && tid < 900 && first)
   {
     uring[kFUDw - 4 + (tid - 896)] = reinterpret_cast<const uint32_t *>(st->wb_u)[tid - 896];     // U[-8 .. -1]
   }
@@ -394,11 +457,62 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
     reinterpret_cast<uint32_t *>(so->fe_tail)[tid - 908] = w;
     finl[162 + (tid - 908)] = w;
   }
-  else if (tid >= 960 && tid < 979 && first)
+  else if (kWb && tid >= 960 && tid < 979 && first)
   {
     vring[kFVDw - 19 + (tid - 960)] = reinterpret_cast<const uint32_t *>(st->wb_v)[tid - 960];    // V[-38 .. -1]
   }
   __syncthreads();
+  if (!kWb)
+  {
+    // The FIR modes' stream begins with one unit of HISTORY (tiles 0 .. 7 = positions -512 .. -1): the tail of the
+    // 256 kS/s stream this demodulator consumed last (ChanState: offset-binary bytes i, q per sample -- the ring's own
+    // number format), zeros (0x80) in front of it.  The decimators warm up over it (they reach 260 samples back,
+    // FM's tuner 28); what they produce there is discarded.  Stage pipelines that carry samples scaled with the gain
+    // of their time (FM: U, V) and the 8 kS/s histories come from the state instead, as in the reference's objects.
+    const bool am = (MODE == 14) && cfg.mode == 1;
+    const uint8_t *tail = (MODE == 2) ? st->fm_tail + 2 * (kFmTail - 512) : am ? st->am_tail : st->ssb_tail;
+    constexpr int kHave = (MODE == 2) ? 512 : kAmTail;   // samples of history the state holds (of the 512)
+    if (tid < 256)
+    {
+      // pair k = samples 2k, 2k + 1 of the history unit
+      const int k0 = tid - (512 - kHave) / 2;
+      uint32_t ip = 0x00800080u, qp = 0x00800080u;
+      if (k0 >= 0)
+      {
+        const uint32_t w = reinterpret_cast<const uint32_t *>(tail)[k0];   // i0 q0 i1 q1
+        ip = (w & 0xffu) | ((w & 0x00ff0000u));
+        qp = ((w >> 8) & 0xffu) | ((w >> 8) & 0x00ff0000u);
+      }
+      ring[(tid >> 5) * kFStride + (tid & 31)] = ip;
+      ring[(tid >> 5) * kFStride + 32 + (tid & 31)] = qp;
+    }
+    else if (MODE == 2 && tid >= 256 && tid < 260)
+    {
+      uring[8 * 8 - 4 + (tid - 256)] = reinterpret_cast<const uint32_t *>(st->fm_u)[tid - 256];          // U[-8 .. -1] (tile 8 is position 0)
+    }
+    else if (MODE == 2 && tid >= 320 && tid < 339)
+    {
+      vring[(2 * 8 - 19 + (tid - 320)) & (kFVDw - 1)] = reinterpret_cast<const uint32_t *>(st->fm_v)[tid - 320];   // V[-38 .. -1]
+    }
+    else if (MODE == 14 && tid >= 384 && tid < 400 && !am)
+    {
+      // SSB: the last 32 samples of the 8 kS/s rails in front of sample 0 (index 16 here: the history unit yields 16)
+      reinterpret_cast<uint32_t *>(r8k[0])[(tid - 384 + 248) & 255] = reinterpret_cast<const uint32_t *>(st->ssb_i)[tid - 384];
+      reinterpret_cast<uint32_t *>(r8k[1])[(tid - 384 + 248) & 255] = reinterpret_cast<const uint32_t *>(st->ssb_q)[tid - 384];
+    }
+    else if (MODE == 14 && tid == 448)
+    {
+      rcar[0] = am ? st->am_x1 : st->ssb_x1;
+      rcar[1] = am ? st->am_y1 : st->ssb_y1;
+    }
+    else if (tid == 512)
+    {
+      gctl[2] = 0u;                                       // AM / SSB: generations through their 8 kS/s part
+      ctl[0] = 1u;                                        // the stream waves start with unit 1
+      uflag[0] = 1u;                                      // unit 0, the history, is in the ring
+      thfin[0] = thfin[1] = thfin[2] = thfin[3] = 0u;
+    }
+  }
   if (tid < 128)
   {
     dbfs8[tid] = (int8_t)P.dbfs[tid];
@@ -524,7 +638,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       tail_in[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t *>(st->fe_tail)[i]);
     }
     // lane constant: where this lane's four samples of a piece go (tile lane / 16 of the piece, 4 (lane % 16) inside)
-    const int lane_dw = kFStride * (lane >> 4) + ((4 * lane) & 63);
+    const int lane_dw = kWb ? kFStride * (lane >> 4) + ((4 * lane) & 63)    // one dword per sample
+                            : kFStride * (lane >> 4) + ((2 * lane) & 31);   // FIR modes: one dword per PAIR, I rail at 0, Q rail at 32
     int bu0 = hal >> 9, blk = 0;                         // first unit and index (in the run) of the block a unit belongs to
     unsigned long long probe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
     (void)probe; (void)tprev;
@@ -625,70 +740,105 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       //  almost two pieces of lead without a register more)
       int un = 0;
       VM_WAIT(4, "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]));
+      // what happens at the point where a piece's raw registers are free: the next unit's first loads
+      auto refill_a = [&](const uint32_t (&y1)[4][4]) {
+#if HRFD_FLOW_EARLY_GRAB
+        lds_landed(un_v);
+        un = __builtin_amdgcn_readfirstlane((int)un_v);
+#if HRFD_FLOW_STREAM_PRIO == 3
+        // fairness: the arbiter serves the oldest wave of a SIMD first, so the young ones fall behind, hold the
+        // ring's completed frontier back and the old ones run into the ring limit.  A wave that sees more units
+        // taken since its own than there are stream waves is late: it gets priority until its next unit.
+        {
+          const int lag = un - u;
+          if (lag > 16)
+          {
+            __builtin_amdgcn_s_setprio(2);
+          }
+          else if (lag > 13)
+          {
+            __builtin_amdgcn_s_setprio(1);
+          }
+          else
+          {
+            __builtin_amdgcn_s_setprio(0);
+          }
+        }
+#endif
+#else
+        un = grab();
+#endif
+        uoff_n = (un < n_units) ? unit_off(un) : 0u;
+        load_c16(c16, uoff_n, un < n_units);
+        load_piece(qa, uoff_n, 0, un < n_units, y1);
+      };
+      // FIR modes: the lane's four mixed samples as int16 pairs per rail (offset binary), two 8-byte stores
+      auto store_rails = [&](const uint32_t (&mx)[4], uint32_t *d) {
+        const uint32_t i01 = __builtin_amdgcn_perm(mx[1], mx[0], 0x05040100u), i23 = __builtin_amdgcn_perm(mx[3], mx[2], 0x05040100u);
+        const uint32_t q01 = __builtin_amdgcn_perm(mx[1], mx[0], 0x07060302u), q23 = __builtin_amdgcn_perm(mx[3], mx[2], 0x07060302u);
+        reinterpret_cast<uint2 *>(d)[0] = make_uint2(i01, i23);
+        reinterpret_cast<uint2 *>(d + 32)[0] = make_uint2(q01, q23);
+        mag4 = magnitude(mx[0]) + magnitude(mx[1]) + magnitude(mx[2]) + magnitude(mx[3]);
+      };
+      if (kWb)
       {
         const uint4 ra[4] = {make_uint4(qa[0].x, qa[0].y, qa[0].z, qa[0].w), make_uint4(qa[1].x, qa[1].y, qa[1].z, qa[1].w),
                              make_uint4(qa[2].x, qa[2].y, qa[2].z, qa[2].w), make_uint4(qa[3].x, qa[3].y, qa[3].z, qa[3].w)};
-        quad_piece<2>(ra, cy, X, v, theta, mag4, [&](const uint32_t (&y1)[4][4]) {
-#if HRFD_FLOW_EARLY_GRAB
-          lds_landed(un_v);
-          un = __builtin_amdgcn_readfirstlane((int)un_v);
-#if HRFD_FLOW_STREAM_PRIO == 3
-          // fairness: the arbiter serves the oldest wave of a SIMD first, so the young ones fall behind, hold the
-          // ring's completed frontier back and the old ones run into the ring limit.  A wave that sees more units
-          // taken since its own than there are stream waves is late: it gets priority until its next unit.
-          {
-            const int lag = un - u;
-            if (lag > 16)
-            {
-              __builtin_amdgcn_s_setprio(2);
-            }
-            else if (lag > 13)
-            {
-              __builtin_amdgcn_s_setprio(1);
-            }
-            else
-            {
-              __builtin_amdgcn_s_setprio(0);
-            }
-          }
-#endif
-#else
-          un = grab();
-#endif
-          uoff_n = (un < n_units) ? unit_off(un) : 0u;
-          load_c16(c16, uoff_n, un < n_units);
-          load_piece(qa, uoff_n, 0, un < n_units, y1);
-        }, DUMP ? iqb : nullptr);
+        quad_piece<2>(ra, cy, X, v, theta, mag4, refill_a, DUMP ? iqb : nullptr);
+        reinterpret_cast<uint2 *>(dst)[0] = make_uint2(v[0], v[1]);
+        reinterpret_cast<uint2 *>(dst)[1] = make_uint2(v[2], v[3]);
       }
-      reinterpret_cast<uint2 *>(dst)[0] = make_uint2(v[0], v[1]);
-      reinterpret_cast<uint2 *>(dst)[1] = make_uint2(v[2], v[3]);
+      else
+      {
+        const uint4 ra[4] = {make_uint4(qa[0].x, qa[0].y, qa[0].z, qa[0].w), make_uint4(qa[1].x, qa[1].y, qa[1].z, qa[1].w),
+                             make_uint4(qa[2].x, qa[2].y, qa[2].z, qa[2].w), make_uint4(qa[3].x, qa[3].y, qa[3].z, qa[3].w)};
+        uint32_t mx[4];
+        quad_front(ra, cy.fe, mx, refill_a);
+        store_rails(mx, dst);
+      }
       if (DUMP)
       {
         store_dump(iqb, u, 0);
       }
       magsum = mag4;
-      const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[0]), 0);
-      const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[1]), 0);
+      uint32_t e0 = 0u, e1 = 0u, e2 = 0u, e3 = 0u;
+      if (kWb)
+      {
+        e0 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[0]), 0);
+        e1 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[1]), 0);
+      }
       FLOW_MARK(4)
       FLOW_MARK(5)
       VM_WAIT(5, "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+      auto refill_b = [&](const uint32_t (&y1)[4][4]) { load_piece(qb, uoff_n, 1, un < n_units, y1); };
+      if (kWb)
       {
         const uint4 rb[4] = {make_uint4(qb[0].x, qb[0].y, qb[0].z, qb[0].w), make_uint4(qb[1].x, qb[1].y, qb[1].z, qb[1].w),
                              make_uint4(qb[2].x, qb[2].y, qb[2].z, qb[2].w), make_uint4(qb[3].x, qb[3].y, qb[3].z, qb[3].w)};
-        quad_piece<2>(rb, cy, X, v, theta, mag4, [&](const uint32_t (&y1)[4][4]) { load_piece(qb, uoff_n, 1, un < n_units, y1); },
-                      DUMP ? iqb : nullptr);
+        quad_piece<2>(rb, cy, X, v, theta, mag4, refill_b, DUMP ? iqb : nullptr);
+        reinterpret_cast<uint2 *>(dst + 4 * kFStride)[0] = make_uint2(v[0], v[1]);
+        reinterpret_cast<uint2 *>(dst + 4 * kFStride)[1] = make_uint2(v[2], v[3]);
       }
-      reinterpret_cast<uint2 *>(dst + 4 * kFStride)[0] = make_uint2(v[0], v[1]);
-      reinterpret_cast<uint2 *>(dst + 4 * kFStride)[1] = make_uint2(v[2], v[3]);
+      else
+      {
+        const uint4 rb[4] = {make_uint4(qb[0].x, qb[0].y, qb[0].z, qb[0].w), make_uint4(qb[1].x, qb[1].y, qb[1].z, qb[1].w),
+                             make_uint4(qb[2].x, qb[2].y, qb[2].z, qb[2].w), make_uint4(qb[3].x, qb[3].y, qb[3].z, qb[3].w)};
+        uint32_t mx[4];
+        quad_front(rb, cy.fe, mx, refill_b);
+        store_rails(mx, dst + 4 * kFStride);
+      }
       if (DUMP)
       {
         store_dump(iqb, u, 1);
       }
       magsum += mag4;
-      const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[2]), 63);
-      const uint32_t e3 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[3]), 63);
+      if (kWb)
+      {
+        e2 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[2]), 63);
+        e3 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[3]), 63);
+      }
       FLOW_MARK(6)
-      if (lane < 4)
+      if (kWb && lane < 4)
       {
         edges[u & (kFEdges - 1)][lane] = (lane == 0) ? e0 : (lane == 1) ? e1 : (lane == 2) ? e2 : e3;
       }
@@ -762,6 +912,446 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   }
   else
   {
+    if constexpr (!kWb)
+    {
+    // =================================================================== service waves, FIR modes: rails -> PCM
+    // Generations of 64 tiles as for WBFM, one tile (64 samples of both rails) per lane:
+    //   a. the lane's tile through the FIRST decimator, straight out of the ring with the few samples of the tile in
+    //      front -- AM / SSB: D(8,4) on both rails (AmDemodulator.cc:339-408, SsbDemodulator.cc:462-529); FM: the
+    //      tuner D(32,4) on both rails, the table lookup on the low bytes and the "differentiator"
+    //      theta[n-2] - theta[n-4] with its wrap and gain (FmDemodulator.cc:395-529);
+    //   b. generations hand over in order (ctl[1]: the ring below is released; FM: the last four thetas go along);
+    //   c. in order again (ctl[2]): the second decimator through the U and V rings -- FM: D(12,4), then D(40,2) and the
+    //      PCM (FmDemodulator.cc:551-585); AM / SSB: D(12,4) per rail, and the generation is released: the third
+    //      decimator D(16,2) needs nothing but V (its own and the last of the generation in front, written by then),
+    //      so it runs beside the next generation's part c (the V ring holds four generations for that);
+    //   d. AM / SSB, in order once more (gctl[2]), the 8 kS/s part: the envelope (AM) or the negating delay line, the
+    //      Hilbert transformer and I -/+ Q (SSB), and the dc-removal recurrence y = (x - x1) - a1 y1
+    //      (IirFilter.cc:161-176) SEQUENTIALLY over the generation's 128 samples on one lane, from the y the
+    //      generation in front left: exact, nothing to verify -- then gain, (int16_t), PCM (AmDemodulator.cc:434-471,
+    //      SsbDemodulator.cc:563-598).  Only this part is a chain through all generations: ~2 us of 3 per generation.
+    __builtin_amdgcn_s_setprio(HRFD_FLOW_SVC_PRIO);
+    const uint32_t pcm_off = (uint32_t)(hal >> 5);       // PCM samples that the history in front would yield
+    uint32_t *pcm32 = reinterpret_cast<uint32_t *>(P.pcm + ((size_t)c * P.out_blocks + P.out_b0 + b_first) * (size_t)(n256 >> 5));
+    const bool am = (MODE == 14) && cfg.mode == 1;
+    const float gain8k = am ? cfg.gain_am : cfg.gain_ssb;
+    float kg_fm = cfg.gain_fm / 15000.0f;                // K = (gain/15000)*32767 in float, that order (FmDemodulator.cc:487-490)
+    kg_fm = kg_fm * 32767.0f;
+    constexpr int kHalTiles = 8;                         // tiles of history in front of position 0
+    auto grab_gen = [&]() -> int {
+      uint32_t v = 0;
+      if (lane == 0)
+      {
+        v = atomicAdd(&ctl[4], 1u);
+      }
+      return __builtin_amdgcn_readfirstlane((int)v);
+    };
+    auto wait_for = [&](const uint32_t *word, const uint32_t want, const uint32_t where) {
+      FlowSpin sp;
+      while (lds_ld(word) != want && !sp.expired(P, ctl, fail_code, where))
+      {
+        __builtin_amdgcn_s_sleep(2);
+      }
+      lds_order();
+    };
+    for (int g = grab_gen(); g < n_gens; g = grab_gen())
+    {
+      const int t0 = 64 * g;
+      const int ntl = min(64, n_tiles - t0);             // tiles of this generation (a multiple of 8)
+      const int t = t0 + lane;
+      const bool have = lane < ntl;
+      // the generation's units, and the one in front (its last samples), are in the ring
+      {
+        const int ulo = max(8 * g - 1, 0), uhi = 8 * g + (ntl >> 3);
+        const int uu = ulo + lane;
+        FlowSpin sp;
+        for (;;)
+        {
+          const bool ok = (uu >= uhi) || lds_ld(&uflag[uu & (kFEdges - 1)]) == (uint32_t)uu + 1u;
+          if (__all(ok) || sp.expired(P, ctl, fail_code, 3))
+          {
+            break;
+          }
+          __builtin_amdgcn_s_sleep(6);
+        }
+        lds_order();
+      }
+      if (fail_code != 0u)
+      {
+        break;
+      }
+      const uint32_t *tp = ring + ring_slot(t) * kFStride;
+      const uint32_t *hp = ring + ring_slot(t > 0 ? t - 1 : 0) * kFStride;
+      uint32_t ud[kRails][8];                            // the lane's 16 first-decimator outputs per rail, packed pairs
+      float th[16];                                      // FM: theta of the lane's 16 samples at 64 kS/s
+#pragma unroll
+      for (int r = 0; r < kRails; r++)
+      {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+          ud[r][i] = 0u;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+      {
+        th[i] = 0.0f;
+      }
+      // ---- a. the first decimator
+      if (have)
+      {
+        if constexpr (MODE == 14)
+        {
+          constexpr int kC0 = q15_bias_init(Q_AM_D1);
+#pragma unroll
+          for (int r = 0; r < 2; r++)
+          {
+            uint32_t x[34];                              // pairs: samples -4 .. -1 of the tile, then the tile
+            const uint2 h2 = (t > 0) ? *reinterpret_cast<const uint2 *>(hp + 32 * r + 30) : make_uint2(0x00800080u, 0x00800080u);
+            x[0] = h2.x;
+            x[1] = h2.y;
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+            {
+              const uint2 w = *reinterpret_cast<const uint2 *>(tp + 32 * r + 2 * j);
+              x[2 + 2 * j] = w.x;
+              x[3 + 2 * j] = w.y;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+            {
+              int acc = kC0;                             // y[k] over samples 4k-4 .. 4k+3 = pairs 2k .. 2k+3 of x
+#pragma unroll
+              for (int j = 0; j < 4; j++)
+              {
+                acc = dot2(x[2 * k + j], kRevAmD1.p[j], acc);
+              }
+              const uint32_t y = (uint32_t)q15_out(acc) & 0xffffu;
+              ud[r][k >> 1] |= (k & 1) ? (y << 16) : y;
+            }
+          }
+        }
+        else
+        {
+          constexpr int kC0 = q15_bias_init(Q_FM_TUNER_D32);
+          uint32_t lowb[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // low bytes of the tuner's outputs, biased by 128 (FmDemodulator.cc:495-496)
+#pragma unroll
+          for (int r = 0; r < 2; r++)
+          {
+            uint32_t x[46];                              // pairs: samples -28 .. -1 of the tile, then the tile
+#pragma unroll
+            for (int j = 0; j < 7; j++)
+            {
+              const uint2 w = (t > 0) ? *reinterpret_cast<const uint2 *>(hp + 32 * r + 18 + 2 * j) : make_uint2(0x00800080u, 0x00800080u);
+              x[2 * j] = w.x;
+              x[2 * j + 1] = w.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+            {
+              const uint2 w = *reinterpret_cast<const uint2 *>(tp + 32 * r + 2 * j);
+              x[14 + 2 * j] = w.x;
+              x[15 + 2 * j] = w.y;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+            {
+              int acc = kC0;                             // y[k] over samples 4k-28 .. 4k+3 = pairs 2k .. 2k+15 of x
+#pragma unroll
+              for (int j = 0; j < 16; j++)
+              {
+                acc = dot2(x[2 * k + j], kRevTuner.p[j], acc);
+              }
+              const uint32_t b = ((uint32_t)q15_out(acc) & 0xffu) ^ 0x80u;
+              lowb[r][k >> 2] |= b << (8 * (k & 3));
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 16; k++)
+          {
+            const uint32_t ii = (lowb[0][k >> 2] >> (8 * (k & 3))) & 0xffu, qi = (lowb[1][k >> 2] >> (8 * (k & 3))) & 0xffu;
+            th[k] = theta_tab((qi << 16) | ii, atcorr, att0);
+          }
+        }
+      }
+      lds_order();                                       // this wave's ring reads are done
+      // ---- b. in order: the ring below this generation is released; FM: the thetas in front of the first lane
+      wait_for(&ctl[1], (uint32_t)g, 5);
+      if (fail_code != 0u)
+      {
+        break;
+      }
+      if constexpr (MODE == 2)
+      {
+        float thm[4];                                    // theta[-4 .. -1] of the lane's tile: the left lane's last four
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+          thm[j] = u2f(shr1(f2u(th[12 + j]), thfin[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+          const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th[12 + j]), ntl - 1);
+          if (lane == 0)
+          {
+            thfin[j] = v;
+          }
+        }
+        // differentiator {0,0,1,0,-1,0,0} (FmDemodulator.cc:116-125: its -1/16 and 1/16 are integer divisions), wrap,
+        // gain, (int16_t) narrowing (:567)
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+        {
+          const float a = (k >= 2) ? th[k - 2] : thm[k + 2], b = (k >= 4) ? th[k - 4] : thm[k];
+          const uint32_t y = (uint32_t)f2i16(kg_fm * wrap_pi(a - b)) & 0xffffu;
+          ud[0][k >> 1] |= (k & 1) ? (y << 16) : y;
+        }
+      }
+      asm volatile("" ::: "memory");
+      if (lane == 0)
+      {
+        lds_st(&ctl[1], (uint32_t)g + 1u);
+      }
+      // ---- c. in order: the stages behind the first decimator
+      wait_for(&ctl[2], (uint32_t)g, 6);
+      if (fail_code != 0u)
+      {
+        break;
+      }
+      // (FM: U and V in front of position 0 are the carried pipelines -- the history tiles write neither)
+      if (have && (MODE == 14 || t >= kHalTiles))
+      {
+#pragma unroll
+        for (int r = 0; r < kRails; r++)
+        {
+          uint4 *up = reinterpret_cast<uint4 *>(uring + r * kFUDw + ((8 * t) & (kFUDw - 1)));
+          up[0] = make_uint4(ud[r][0], ud[r][1], ud[r][2], ud[r][3]);
+          up[1] = make_uint4(ud[r][4], ud[r][5], ud[r][6], ud[r][7]);
+        }
+      }
+      // V[k] = D(12,4)(U), two per lane and pass
+#pragma unroll
+      for (int r = 0; r < kRails; r++)
+      {
+        for (int i = lane; i < 2 * ntl; i += 64)
+        {
+          const int k = 256 * g + 2 * i;                 // even
+          const uint4 ua = *reinterpret_cast<const uint4 *>(uring + r * kFUDw + ((2 * k - 4) & (kFUDw - 1)));
+          const uint4 ub = *reinterpret_cast<const uint4 *>(uring + r * kFUDw + ((2 * k) & (kFUDw - 1)));
+          const uint32_t uu[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};   // U[4k-8 .. 4k+7]
+          int acc0 = 1 << 14, acc1 = 1 << 14;
+#pragma unroll
+          for (int j = 0; j < 6; j++)
+          {
+            const uint32_t tap = (MODE == 14) ? kRevAmD2.p[j] : kRevD12.p[j];
+            acc0 = dot2(uu[j], tap, acc0);
+            acc1 = dot2(uu[j + 2], tap, acc1);
+          }
+          if (MODE == 14 || k >= 4 * kHalTiles)
+          {
+            vring[r * kVDw + ((k >> 1) & (kVDw - 1))] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+          }
+        }
+      }
+      if constexpr (MODE == 14)
+      {
+        // V of this generation is written: the next one may run its part c
+        asm volatile("" ::: "memory");
+        lds_order();
+        if (lane == 0)
+        {
+          lds_st(&ctl[2], (uint32_t)g + 1u);
+        }
+      }
+      const int pp = 128 * g + 2 * lane;                 // the lane's two 8 kS/s samples (even index)
+      if constexpr (MODE == 2)
+      {
+        // PCM[p] = D(40,2)(V), two per lane
+        if (have)
+        {
+          int acc0 = 1 << 14, acc1 = 1 << 14;            // V[2pp-38 .. 2pp+3] = dwords pp-19 .. pp+1
+          uint32_t prev = vring[(pp - 19) & (kFVDw - 1)];
+#pragma unroll
+          for (int j = 0; j < 20; j++)
+          {
+            const uint32_t next = vring[(pp - 18 + j) & (kFVDw - 1)];
+            acc0 = dot2(prev, kRevD40.p[j], acc0);
+            acc1 = dot2(next, kRevD40.p[j], acc1);
+            prev = next;
+          }
+          if ((uint32_t)pp >= pcm_off)
+          {
+            pcm32[((uint32_t)pp - pcm_off) >> 1] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+          }
+        }
+      }
+      else
+      {
+        // the third decimator D(16,2) on both rails: V[2pp-14 .. 2pp+3] = dwords pp-7 .. pp+1
+        int o[2][2] = {{0, 0}, {0, 0}};
+        if (have)
+        {
+#pragma unroll
+          for (int r = 0; r < 2; r++)
+          {
+            uint32_t x[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++)
+            {
+              x[j] = vring[r * kVDw + ((pp - 7 + j) & (kVDw - 1))];
+            }
+            int acc0 = 1 << 14, acc1 = 1 << 14;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+            {
+              acc0 = dot2(x[j], kRevAmD3.p[j], acc0);
+              acc1 = dot2(x[j + 1], kRevAmD3.p[j], acc1);
+            }
+            o[r][0] = q15_out(acc0);
+            o[r][1] = q15_out(acc1);
+          }
+        }
+        // ---- d. the 8 kS/s part, generation by generation
+        wait_for(&gctl[2], (uint32_t)g, 4);
+        if (fail_code != 0u)
+        {
+          break;
+        }
+        if (am)
+        {
+          // AmDemodulator::demodulateSignal (:447-461): int16 abs, compare, add with wrap
+          auto env = [](int iv, int qv) -> int {
+            const int im = (int)(short)abs(iv), qm = (int)(short)abs(qv);
+            return (im > qm) ? (int)(short)(im + (qm >> 1)) : (int)(short)(qm + (im >> 1));
+          };
+          if (have)
+          {
+            *reinterpret_cast<float2 *>(&xs8k[2 * lane]) = make_float2((float)env(o[0][0], o[1][0]), (float)env(o[0][1], o[1][1]));
+          }
+        }
+        else
+        {
+          // SSB: the rails at 8 kS/s (the samples in front of sample 0 are the carried ones), then the negating
+          // delay line (Q15 tap 1.0 narrows to -32768), the 31-tap Hilbert transformer, I -/+ Q
+          if (have && pp >= 2 * kHalTiles)
+          {
+            reinterpret_cast<uint32_t *>(r8k[0])[(pp >> 1) & 255] = ((uint32_t)o[0][0] & 0xffffu) | ((uint32_t)o[0][1] << 16);
+            reinterpret_cast<uint32_t *>(r8k[1])[(pp >> 1) & 255] = ((uint32_t)o[1][0] & 0xffffu) | ((uint32_t)o[1][1] << 16);
+          }
+          if (have)
+          {
+            float xv[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+            {
+              const int n = pp + e;
+              const int idel = q15_out((1 << 14) + (-32768) * (int)r8k[0][(n - 15) & 511]);
+              int acc = 1 << 14;
+#pragma unroll
+              for (int k = 0; k < N_SSB_HILBERT; k++)
+              {
+                acc += (int)Q_SSB_HILBERT[k] * (int)r8k[1][(n - k) & 511];
+              }
+              const int qh = q15_out(acc);
+              xv[e] = (float)(cfg.lsb ? (idel - qh) : (idel + qh));
+            }
+            *reinterpret_cast<float2 *>(&xs8k[2 * lane]) = make_float2(xv[0], xv[1]);
+          }
+        }
+        // the dc-removal recurrence over the generation's samples, one lane, groups of eight with the next group's
+        // inputs in flight (the chain per step is the multiply and the subtract)
+        if (lane == 0)
+        {
+          const int cnt = 2 * ntl;
+          int n = max(0, 2 * kHalTiles - 128 * g);       // the history in front of sample 0 is not part of the stream
+          float xp = rcar[0], y = rcar[1];
+          float4 a0 = *reinterpret_cast<const float4 *>(&xs8k[n & 127]), a1 = *reinterpret_cast<const float4 *>(&xs8k[(n + 4) & 127]);
+          for (; n < cnt; n += 8)
+          {
+            const float4 b0 = *reinterpret_cast<const float4 *>(&xs8k[(n + 8) & 127]), b1 = *reinterpret_cast<const float4 *>(&xs8k[(n + 12) & 127]);
+            const float xin[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            float yo[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+            {
+              const float v = xin[j] - xp;
+              xp = xin[j];
+              const float r = DCREM_A1 * y;
+              y = v - r;
+              yo[j] = y;
+            }
+            *reinterpret_cast<float4 *>(&ys8k[n]) = make_float4(yo[0], yo[1], yo[2], yo[3]);
+            *reinterpret_cast<float4 *>(&ys8k[n + 4]) = make_float4(yo[4], yo[5], yo[6], yo[7]);
+            a0 = b0;
+            a1 = b1;
+          }
+          rcar[0] = xp;
+          rcar[1] = y;
+        }
+        if (have && (uint32_t)pp >= pcm_off)
+        {
+          const float2 yy = *reinterpret_cast<const float2 *>(&ys8k[2 * lane]);
+          pcm32[((uint32_t)pp - pcm_off) >> 1] = ((uint32_t)f2i16(gain8k * yy.x) & 0xffffu) | ((uint32_t)f2i16(gain8k * yy.y) << 16);
+        }
+      }
+      // ---- the carried state for the next call (pending: the finisher commits it)
+      if (g + 1 == n_gens)
+      {
+        // the demodulator's input tail: the last samples of the stream as offset-binary bytes i, q (the ring's pairs)
+        constexpr int kTailPairs = (MODE == 2 ? kFmTail : kAmTail) / 2;
+        uint32_t *tail = reinterpret_cast<uint32_t *>((MODE == 2) ? so->fm_tail : am ? so->am_tail : so->ssb_tail);
+        for (int m = lane; m < kTailPairs; m += 64)
+        {
+          const int pr = 32 * n_tiles - kTailPairs + m;  // pair index in the stream
+          const uint32_t *sp = ring + ring_slot(pr >> 5) * kFStride + (pr & 31);
+          const uint32_t ip = sp[0], qp = sp[32];
+          tail[m] = (ip & 0xffu) | ((qp & 0xffu) << 8) | (ip & 0x00ff0000u) | ((qp & 0x00ff0000u) << 8);
+        }
+        if constexpr (MODE == 2)
+        {
+          if (lane < 4)
+          {
+            reinterpret_cast<uint32_t *>(so->fm_u)[lane] = uring[(8 * n_tiles - 4 + lane) & (kFUDw - 1)];
+          }
+          if (lane < 19)
+          {
+            reinterpret_cast<uint32_t *>(so->fm_v)[lane] = vring[(2 * n_tiles - 19 + lane) & (kFVDw - 1)];
+          }
+        }
+        else if (am)
+        {
+          if (lane == 0)
+          {
+            so->am_x1 = rcar[0];
+            so->am_y1 = rcar[1];
+          }
+        }
+        else
+        {
+          if (lane == 0)
+          {
+            so->ssb_x1 = rcar[0];
+            so->ssb_y1 = rcar[1];
+          }
+          if (lane < 16)
+          {
+            reinterpret_cast<uint32_t *>(so->ssb_i)[lane] = reinterpret_cast<const uint32_t *>(r8k[0])[(n_tiles - 16 + lane) & 255];
+            reinterpret_cast<uint32_t *>(so->ssb_q)[lane] = reinterpret_cast<const uint32_t *>(r8k[1])[(n_tiles - 16 + lane) & 255];
+          }
+        }
+      }
+      asm volatile("" ::: "memory");
+      lds_order();
+      if (lane == 0)
+      {
+        lds_st((MODE == 14) ? &gctl[2] : &ctl[2], (uint32_t)g + 1u);
+      }
+    }
+    }
+    else
+    {
     // =================================================================== service waves: v -> PCM
     __builtin_amdgcn_s_setprio(HRFD_FLOW_SVC_PRIO);      // long dependent chains, few issue slots
     const float a1 = DEEMPH_A1;
@@ -1161,6 +1751,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       atomicAdd(&P.counters[kCntRepair], repairs);
       atomicAdd(&P.sticky[kCntTotRepair], repairs);
     }
+    }
   }
   // The last wave of the last workgroup of a channel finishes the channel (finish_channel: squelch tracker, checks
   // of both speculations, n_pcm / allowed outputs, commit of the pending state): no kernel behind this one.
@@ -1301,7 +1892,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
       }
       if (last)
       {
-        finish_channel<3>(P.fin, c, lane);
+        finish_channel<kWb ? 3 : -1>(P.fin, c, lane);
       }
     }
   }
@@ -1321,8 +1912,48 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
   }
 }
 
+template <int SVC, bool GATED, bool DUMP, int MODE = 3>
+__global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t lds[FlowLds<MODE>::kTotal];
+  flow_body<SVC, GATED, DUMP, MODE>(P, lds);
+}
+
+// A bank of several modes (BASELINE config 3) as ONE launch: one persistent workgroup per channel whatever its mode,
+// the mode read from the channel's configuration -- no per-mode kernels, no streams to fork and join, no kernel
+// boundaries inside a step.  Every workgroup holds a whole CU and runs for about the same time (the call's blocks of
+// one channel), so a bank of as many channels as the chip has CUs is one round.
+template <int SVC>
+__global__ __launch_bounds__(kThreads, 4) void k_rx_flow_bank(const RxParams P)
+{
+  constexpr int kDw = (FlowLds<3>::kTotal > FlowLds<2>::kTotal) ? ((FlowLds<3>::kTotal > FlowLds<14>::kTotal) ? FlowLds<3>::kTotal : FlowLds<14>::kTotal)
+                                                                : ((FlowLds<2>::kTotal > FlowLds<14>::kTotal) ? FlowLds<2>::kTotal : FlowLds<14>::kTotal);
+  __shared__ __attribute__((aligned(16))) uint32_t lds[kDw];
+  uint32_t ci, run;
+  if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
+  {
+    return;
+  }
+  const int mode = __builtin_amdgcn_readfirstlane(P.cfg[P.chan_list[ci]].mode);
+  if (mode == 3)
+  {
+    flow_body<SVC, false, false, 3>(P, lds);
+  }
+  else if (mode == 2)
+  {
+    flow_body<SVC, false, false, 2>(P, lds);
+  }
+  else
+  {
+    flow_body<SVC, false, false, 14>(P, lds);
+  }
+}
+
+template __global__ void k_rx_flow_bank<HRFD_FLOW_SVC>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>(const RxParams);
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 2>(const RxParams);
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 14>(const RxParams);
 
 } // namespace hrfd

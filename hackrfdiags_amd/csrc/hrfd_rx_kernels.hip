@@ -484,6 +484,24 @@ struct RevTaps
 __constant__ constexpr RevTaps<N_WBFM_D1> kRevWbD1(Q_WBFM_D1);
 __constant__ constexpr RevTaps<N_POST_D12> kRevD12(Q_POST_D12);
 __constant__ constexpr RevTaps<N_AUDIO_D40> kRevD40(Q_AUDIO_D40);
+// the FIR demodulators' decimators (FmDemodulator.cc:17-51, AmDemodulator.cc:14-62 == SsbDemodulator.cc:14-62)
+__constant__ constexpr RevTaps<N_FM_TUNER_D32> kRevTuner(Q_FM_TUNER_D32);
+__constant__ constexpr RevTaps<N_AM_D1> kRevAmD1(Q_AM_D1);
+__constant__ constexpr RevTaps<N_AM_D2> kRevAmD2(Q_AM_D2);
+__constant__ constexpr RevTaps<N_AM_D3> kRevAmD3(Q_AM_D3);
+// A Q15 stage fed with OFFSET-BINARY samples u = x + 128 (what the ring of k_rx_wbfm_flow's FIR modes holds): the
+// sum over h (u - 128) is the sum over h u minus 128 sum h, so the rounding constant absorbs the offset (int32
+// wrap-around arithmetic: identical bits)
+template <int N>
+constexpr int q15_bias_init(const int16_t (&h)[N])
+{
+  long long sum = 0;
+  for (int i = 0; i < N; i++)
+  {
+    sum += h[i];
+  }
+  return (int)((1 << 14) - 128 * sum);
+}
 
 // ---- workgroup -> (channel, block) mapping -----------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs, so ids w and w+8 share an
@@ -1840,19 +1858,16 @@ struct QuadCarry
   uint32_t theta, p;          // lane 0: theta and b0*x of the sample before the piece
 };
 
-// one 4 KiB piece: raw[j] = the lane's group j (16 bytes) -> v[4]; returns the four thetas
-// ARITH: 0 table gather from global memory, 1 theta_arith, 2 theta_tab (X.ati is then T0)
 struct NoHook
 {
   __device__ __forceinline__ void operator()(const uint32_t (&)[4][4]) const {}
 };
-// `raw_free` is called once the raw registers are dead (behind stage 1, whose outputs it gets so that it can make
-// whatever it does depend on them): the caller may refill the registers there
-// iqb (optional): the lane's four mixed samples as the eight bytes i0 q0 i1 q1 i2 q2 i3 q3 of the 256 kS/s stream
-template <int ARITH, class Hook = NoHook>
-__device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, const StreamCtx &X,
-                                           uint32_t (&vout)[4], float (&theta)[4], uint32_t &mag4, Hook &&raw_free = NoHook(),
-                                           uint32_t *iqb = nullptr)
+// The front half of a piece: raw[j] = the lane's group j (16 bytes) -> the four mixed 256 kS/s samples of the lane,
+// (q_idx << 16) | i_idx in offset binary (three half-band stages per rail and the Fs/4 rotation: frontend() / mix_fs4()
+// in the quad layout).  `raw_free` is called once the raw registers are dead (behind stage 1, whose outputs it gets
+// so that it can make whatever it does depend on them): the caller may refill the registers there.
+template <class Hook>
+__device__ __forceinline__ void quad_front(const uint4 (&raw)[4], FeCarry &fe, uint32_t (&mixed)[4], Hook &&raw_free)
 {
   uint32_t r[4][4];
 #pragma unroll
@@ -1865,8 +1880,8 @@ __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, 
   }
   // stage 1 (bytes) and its outputs as 16-bit (I,Q) fields
   uint32_t y1[4][4];
-  const uint32_t rm1_0 = shr1(r[3][3], c.fe.x7);
-  c.fe.x7 = ror1(r[3][3]);
+  const uint32_t rm1_0 = shr1(r[3][3], fe.x7);
+  fe.x7 = ror1(r[3][3]);
 #pragma unroll
   for (int j = 0; j < 4; j++)
   {
@@ -1887,8 +1902,8 @@ __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, 
   raw_free(y1);
   // stage 2
   uint32_t y20b[4], y21[4];
-  const uint32_t y1m1_0 = shr1(y1[3][3], c.fe.y13);
-  c.fe.y13 = ror1(y1[3][3]);
+  const uint32_t y1m1_0 = shr1(y1[3][3], fe.y13);
+  fe.y13 = ror1(y1[3][3]);
 #pragma unroll
   for (int j = 0; j < 4; j++)
   {
@@ -1896,20 +1911,29 @@ __device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, 
     y20b[j] = form_b2(hb2_sum(y1m1, y1[j][0] << 1, y1[j][1]));
     y21[j] = form_ac(hb2_sum(y1[j][1], y1[j][2] << 1, y1[j][3]));
   }
-  // stage 3, mixer, magnitude, theta
-  const uint32_t y2m1_0 = shr1(y21[3], c.fe.y21);
-  c.fe.y21 = ror1(y21[3]);
+  // stage 3, mixer
+  const uint32_t y2m1_0 = shr1(y21[3], fe.y21);
+  fe.y21 = ror1(y21[3]);
+  const uint32_t y30 = hb3_sum(y2m1_0, y20b[0], y21[0]) >> 2;
+  const uint32_t y31 = hb3_sum(y21[0], y20b[1], y21[1]) >> 2;
+  const uint32_t y32 = hb3_sum(y21[1], y20b[2], y21[2]) >> 2;
+  const uint32_t y33 = hb3_sum(y21[2], y20b[3], y21[3]) >> 2;
+  mixed[0] = mix_fs4_const<0>(y30);
+  mixed[1] = mix_fs4_const<1>(y31);
+  mixed[2] = mix_fs4_const<2>(y32);
+  mixed[3] = mix_fs4_const<3>(y33);
+}
+
+// one 4 KiB piece: raw[j] = the lane's group j (16 bytes) -> v[4]; returns the four thetas
+// ARITH: 0 table gather from global memory, 1 theta_arith, 2 theta_tab (X.ati is then T0)
+// iqb (optional): the lane's four mixed samples as the eight bytes i0 q0 i1 q1 i2 q2 i3 q3 of the 256 kS/s stream
+template <int ARITH, class Hook = NoHook>
+__device__ __forceinline__ void quad_piece(const uint4 (&raw)[4], QuadCarry &c, const StreamCtx &X,
+                                           uint32_t (&vout)[4], float (&theta)[4], uint32_t &mag4, Hook &&raw_free = NoHook(),
+                                           uint32_t *iqb = nullptr)
+{
   uint32_t mixed[4];
-  {
-    const uint32_t y30 = hb3_sum(y2m1_0, y20b[0], y21[0]) >> 2;
-    const uint32_t y31 = hb3_sum(y21[0], y20b[1], y21[1]) >> 2;
-    const uint32_t y32 = hb3_sum(y21[1], y20b[2], y21[2]) >> 2;
-    const uint32_t y33 = hb3_sum(y21[2], y20b[3], y21[3]) >> 2;
-    mixed[0] = mix_fs4_const<0>(y30);
-    mixed[1] = mix_fs4_const<1>(y31);
-    mixed[2] = mix_fs4_const<2>(y32);
-    mixed[3] = mix_fs4_const<3>(y33);
-  }
+  quad_front(raw, c.fe, mixed, raw_free);
   if (iqb != nullptr)
   {
     // (q_idx << 16 | i_idx) in offset binary -> signed bytes i, q of two samples per dword

@@ -64,13 +64,18 @@ def _oracle_stream(oracle, mode, x, nb, gain=None, threshold=None):
     return [o.process(x[b]) for b in range(nb)]
 
 
+@pytest.mark.parametrize("fir_flow", [0, 1], ids=["block_kernels", "flow_kernel_fir_modes"])
 @pytest.mark.parametrize("mode", [AM, FM, LSB, USB])
 @pytest.mark.parametrize("kind", ["lcg", "amtone", "dc_neg", "impulse"])
-def test_batched_blocks_match_oracle_other_modes(oracle, mode, kind):
+def test_batched_blocks_match_oracle_other_modes(oracle, mode, kind, fir_flow):
+    """AM / FM / SSB batches on both implementations: one workgroup per channel-block (k_rx_fir, k_rx_post), and the
+    flow kernel's FIR modes (one persistent workgroup per channel, the call as one stream: what a bank of 48 channels
+    or more gets by default)"""
     C, B = 3, 4
     xs = np.stack([synth.make_input(kind, 30 + c, 2 * B) for c in range(C)]).reshape(C, 2 * B, BLK)
     rx = api.Rx(C)
     rx.set_mode(mode)
+    rx.debug_set_fir_flow(fir_flow)
     r1 = rx.process_block(xs[:, :B], B)
     r2 = rx.process_block(xs[:, B:], B)
     pcm = np.concatenate([r1[0], r2[0]], axis=1)
@@ -83,14 +88,50 @@ def test_batched_blocks_match_oracle_other_modes(oracle, mode, kind):
     assert rx.debug_counters()[5] == 0
 
 
-def test_mixed_mode_bank(oracle):
+@pytest.mark.parametrize("mode", [AM, FM, LSB, USB])
+def test_fir_modes_on_the_flow_kernel(oracle, mode):
+    """k_rx_wbfm_flow<.., 2> / <.., 14> in depth: block sizes that are whole units of 512 samples at 256 kS/s down to
+    the shortest, 17 blocks (more than four generations, ragged last one), three calls (the carried input tail, the FM
+    pipelines with the gain of their time, the SSB rails and the dc-removal filter's x[n-1], y[n-1] across calls), a
+    gain change between calls, a channel count that is not a multiple of 8, mean magnitudes and n_pcm."""
+    for bb, B in ((262144, 3), (65536, 17), (32768, 5)):
+        C = 5
+        raw = np.concatenate([synth.make_input("amtone" if c % 2 else "lcg", 210 + c, (3 * B * bb + BLK - 1) // BLK)[: 3 * B * bb]
+                              for c in range(C)]).reshape(C, 3 * B, bb)
+        rx = api.Rx(C)
+        rx.set_mode(mode)
+        rx.debug_set_fir_flow(1)
+        outs = []
+        for call in range(3):
+            if call == 2:
+                rx.set_gain(mode, 4321.0)
+            outs.append(rx.process_block(raw[:, call * B:(call + 1) * B], B))
+        for c in range(C):
+            o = oracle.rx()
+            o.set_mode(mode)
+            for call in range(3):
+                if call == 2:
+                    o.set_gain(mode, 4321.0)
+                for b in range(B):
+                    p, m, _, _ = o.process(raw[c, call * B + b])
+                    got = outs[call]
+                    assert got[1][c, b] == len(p) and int(got[2][c, b]) == m, (bb, c, call, b)
+                    assert (got[0][c, b, :len(p)] == p).all(), (bb, c, call, b)
+        assert rx.debug_counters()[5] == 0, "a launch was not committed"
+
+
+@pytest.mark.parametrize("fir_flow", [-1, 1, 0], ids=["kernels_per_mode", "one_bank_kernel", "block_kernels_beside_the_flow_kernel"])
+def test_mixed_mode_bank(oracle, fir_flow):
     """BASELINE config 3 in miniature: AM + FM + WBFM + LSB + USB + NONE channels in
-    one handle, per-mode kernel dispatch, two calls."""
+    one handle, two calls.  A bank this small is dispatched per mode by default; the hook forces what a bank of 48
+    channels or more gets: ONE launch of k_rx_flow_bank, one persistent workgroup per channel, the mode read per
+    workgroup (mode NONE keeps its own kernel) -- or, with 0, the block kernels of the FIR modes beside the flow kernel."""
     modes = [AM, FM, WBFM, LSB, USB, NONE, WBFM, AM, FM, USB]
     C, B = len(modes), 3
     xs = np.stack([synth.make_input("lcg" if c % 2 else "amtone", 60 + c, 2 * B) for c in range(C)])
     xs = xs.reshape(C, 2 * B, BLK)
     rx = api.Rx(C)
+    rx.debug_set_fir_flow(fir_flow)
     for c, m in enumerate(modes):
         rx.set_mode(m, channel=c)
     r1 = rx.process_block(xs[:, :B], B)
@@ -115,6 +156,34 @@ def test_gain_change_between_calls(oracle, mode):
             rx.set_gain(mode, gain); o.set_gain(mode, gain)
         got = rx.process_block(x[:, k:k + 1], 1)[0][0, 0]
         assert (got == o.process(x[0, k])[0]).all(), (mode, k)
+
+
+@pytest.mark.parametrize("fir_flow", [1, 0], ids=["one_bank_kernel", "block_kernels"])
+def test_mixed_bank_with_closed_gates(oracle, fir_flow):
+    """a bank of several modes under a real squelch threshold: gates that close inside the batch in a WBFM channel (the
+    device's gated pass redoes it), in FM, AM and SSB channels (their verdict fails; the blocking entry replays them on
+    the exact path), a channel that never opens, one that is always open -- every channel the oracle's, two calls"""
+    modes = [WBFM, AM, FM, LSB, WBFM, USB, AM, FM]
+    pats = ["110011", "101100", "011010", "110001", "111111", "000000", "111111", "100110"]
+    C, B = len(modes), len(pats[0])
+    xs = np.stack([synth.make_input("fmtone", 90 + c, 2 * B).reshape(2 * B, BLK) for c in range(C)])
+    for c, pat in enumerate(pats):
+        for b, ch in enumerate(pat + pat[::-1]):
+            if ch == "0":
+                xs[c, b] = 0
+    rx = api.Rx(C)
+    rx.debug_set_fir_flow(fir_flow)
+    for c, m in enumerate(modes):
+        rx.set_mode(m, channel=c)
+    rx.set_threshold(-30)
+    got = [rx.process_block(xs[:, :B], B), rx.process_block(xs[:, B:], B)]
+    for c, m in enumerate(modes):
+        want = _oracle_stream(oracle, m, xs[c], 2 * B, threshold=-30)
+        for b in range(2 * B):
+            r = got[b // B]
+            p, mg, a, _ = want[b]
+            assert r[1][c, b % B] == len(p) and bool(r[3][c, b % B]) == a and int(r[2][c, b % B]) == mg, (c, m, b)
+            assert (r[0][c, b % B, :len(p)] == p).all() and (r[0][c, b % B, len(p):] == 0).all(), (c, m, b)
 
 
 def test_mode_switch_keeps_each_demodulators_state(oracle):

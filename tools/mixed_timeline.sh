@@ -17,7 +17,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
 rows.sort()
 # a step of the mixed bank is PER kernels (2: k_rx_wbfm_flow and k_rx_fir<15>), whatever their order
 import os
-per = int(os.environ.get("PER", "2"))
+per = int(os.environ.get("PER", "1"))
 n_steps = len(rows) // per
 for k in range(max(0, n_steps - 3), n_steps):
     chunk = rows[len(rows) - (n_steps - k) * per: len(rows) - (n_steps - k - 1) * per]
