@@ -378,6 +378,11 @@ class Mod:
         assert ob.value == 512 * n
         return out if self.n > 1 else out[0]
 
+    def debug_set_sliced(self, mode: int):
+        """test hook (WBFM): 0 = the call's passes one after the other, 1 = time slices when the phase recurrence's
+        stream has CUs of its own (the default), 2 = always"""
+        check(self.L.hrfd_mod_debug_set_sliced(self.h, int(mode)), "hrfd_mod_debug_set_sliced")
+
     def process_device(self, d_pcm, n, d_out, stream=None):
         check(self.L.hrfd_mod_process_device(self.h, _ptr(d_pcm), n, _ptr(d_out), _ptr(stream)),
               "hrfd_mod_process_device")

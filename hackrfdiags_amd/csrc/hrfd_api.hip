@@ -1713,34 +1713,40 @@ struct hrfd_mod
   float *d_sin = nullptr, *d_cos = nullptr;
   uint32_t *d_wbpack = nullptr;         // the two tables x900 as int16 rail pairs (k_wb_rails)
   uint32_t *d_err = nullptr;            // k_phase_scan: waits that expired (never, unless the kernel is broken)
+  // WBFM: the call's passes run in time slices on three streams (hrfd_mod_process_device)
+  static constexpr int kMaxSlices = 32;
+  hipStream_t s_scan = nullptr, s_tail = nullptr, s_head = nullptr;
+  bool cu_masked = false;               // the recurrence's stream has CUs of its own
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_head[kMaxSlices] = {}, ev_scan[kMaxSlices] = {};
+  int sliced = 1;                        // test hook: 0 = one pass after the other on the caller's stream
   // staging for the host entry
   int16_t *d_in = nullptr;
   int8_t *d_out = nullptr;
   size_t cap_in = 0, cap_out = 0;
 };
 
-// the Nco phase recurrence over `steps` cells per channel (k_phase_scan: 16-byte pieces)
-static void phase_scan(hrfd_mod *h, uint32_t *cells, size_t steps, float *d_acc, uint32_t n_channels, hipStream_t s)
+// the Nco phase recurrence over `steps` cells per channel, rows `row_stride` cells apart (k_phase_scan: 16-byte pieces)
+static void phase_scan(hrfd_mod *h, uint32_t *cells, size_t steps, size_t row_stride, float *d_acc, uint32_t n_channels, hipStream_t s)
 {
-  if ((steps & 3) == 0)
+  if ((steps & 3) == 0 && (row_stride & 3) == 0)
   {
     // channels per workgroup: as few as still fit the chip in one round (one workgroup per CU)
     if (n_channels <= 16u * 256u)
     {
-      hipLaunchKernelGGL(k_phase_scan<16>, dim3((n_channels + 15) / 16), dim3(kPsThreads), 0, s, cells, steps, d_acc, n_channels, h->d_err);
+      hipLaunchKernelGGL(k_phase_scan<16>, dim3((n_channels + 15) / 16), dim3(kPsThreads), 0, s, cells, steps, row_stride, d_acc, n_channels, h->d_err);
     }
     else if (n_channels <= 32u * 256u)
     {
-      hipLaunchKernelGGL(k_phase_scan<32>, dim3((n_channels + 31) / 32), dim3(kPsThreads), 0, s, cells, steps, d_acc, n_channels, h->d_err);
+      hipLaunchKernelGGL(k_phase_scan<32>, dim3((n_channels + 31) / 32), dim3(kPsThreads), 0, s, cells, steps, row_stride, d_acc, n_channels, h->d_err);
     }
     else
     {
-      hipLaunchKernelGGL(k_phase_scan<64>, dim3((n_channels + 63) / 64), dim3(kPsThreads), 0, s, cells, steps, d_acc, n_channels, h->d_err);
+      hipLaunchKernelGGL(k_phase_scan<64>, dim3((n_channels + 63) / 64), dim3(kPsThreads), 0, s, cells, steps, row_stride, d_acc, n_channels, h->d_err);
     }
   }
   else
   {
-    hipLaunchKernelGGL(k_phase_scan_plain, dim3((n_channels + 63) / 64), dim3(64), 0, s, cells, steps, d_acc, n_channels);
+    hipLaunchKernelGGL(k_phase_scan_plain, dim3((n_channels + 63) / 64), dim3(64), 0, s, cells, steps, row_stride, d_acc, n_channels);
   }
 }
 
@@ -1752,6 +1758,23 @@ static int mod_free(hrfd_mod *h)
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (hipStream_t st : {h->s_scan, h->s_tail, h->s_head})
+  {
+    if (st)
+    {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
+  }
+  for (hipEvent_t e : {h->ev_fork, h->ev_join})
+  {
+    if (e) (void)hipEventDestroy(e);
+  }
+  for (int i = 0; i < hrfd_mod::kMaxSlices; i++)
+  {
+    if (h->ev_head[i]) (void)hipEventDestroy(h->ev_head[i]);
+    if (h->ev_scan[i]) (void)hipEventDestroy(h->ev_scan[i]);
+  }
   void *ptrs[] = {h->d_tail[0], h->d_tail[1], h->d_lsb, h->d_in, h->d_out, h->d_param, h->d_acc, h->d_phase, h->d_rails,
                   h->d_wb, h->d_wbtail[0], h->d_wbtail[1], h->d_sin, h->d_cos, h->d_err, h->d_wbpack};
   for (void *p : ptrs)
@@ -1830,6 +1853,58 @@ extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_m
     {
       if (e == hipSuccess) e = hipMalloc((void **)&h->d_wbtail[k], sizeof(uint32_t) * 2 * n_channels);
       if (e == hipSuccess) e = hipMemset(h->d_wbtail[k], 0, sizeof(uint32_t) * 2 * n_channels);
+    }
+    // The phase recurrence runs one workgroup per 16 channels, one per CU, and every step of it is latency: a
+    // workgroup of another kernel on the same CU slows it (measured: 276 -> 330..500 us per slice).  When the
+    // recurrence needs at most half of the chip its stream gets CUs of its own and the other streams the rest
+    // (hipExtStreamCreateWithCUMask; bit i of the mask = CU i, dealt round-robin over the XCDs by the driver).
+    if (e == hipSuccess)
+    {
+      int cus = 0;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+      const uint32_t scan_wgs = (n_channels + 15u) / 16u;
+      const uint32_t want = (scan_wgs + 7u) / 8u * 8u;
+      bool masked = false;
+      if (cus >= 64 && cus <= 1024 && n_channels <= 4096u && want * 2u <= (uint32_t)cus)
+      {
+        const uint32_t words = ((uint32_t)cus + 31u) / 32u;
+        std::vector<uint32_t> scan_mask(words, 0u), rest_mask(words, 0u);
+        for (uint32_t i = 0; i < (uint32_t)cus; i++)
+        {
+          (i < want ? scan_mask : rest_mask)[i / 32] |= 1u << (i % 32);
+        }
+        hipStream_t a = nullptr, b = nullptr, c = nullptr;
+        if (hipExtStreamCreateWithCUMask(&a, words, scan_mask.data()) == hipSuccess &&
+            hipExtStreamCreateWithCUMask(&b, words, rest_mask.data()) == hipSuccess &&
+            hipExtStreamCreateWithCUMask(&c, words, rest_mask.data()) == hipSuccess)
+        {
+          h->s_scan = a;
+          h->s_tail = b;
+          h->s_head = c;
+          masked = true;
+        }
+        else
+        {
+          (void)hipGetLastError();
+          if (a) (void)hipStreamDestroy(a);
+          if (b) (void)hipStreamDestroy(b);
+          if (c) (void)hipStreamDestroy(c);
+        }
+      }
+      if (!masked)
+      {
+        e = hipStreamCreateWithFlags(&h->s_scan, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s_tail, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s_head, hipStreamNonBlocking);
+      }
+      h->cu_masked = masked;
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    for (int k = 0; k < hrfd_mod::kMaxSlices && e == hipSuccess; k++)
+    {
+      e = hipEventCreateWithFlags(&h->ev_head[k], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_scan[k], hipEventDisableTiming);
     }
 
   }
@@ -1968,6 +2043,8 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
   M.wbtail = nullptr;
   M.n = n_per_channel;
   M.n_channels = h->n_channels;
+  M.tile0 = 0;
+  M.tiles_launch = 0;
   const uint32_t tiles = (n_per_channel + kModTile - 1) / kModTile;
   const uint32_t grid = h->n_channels * tiles;
   if (h->kind == HRFD_MOD_WBFM)
@@ -1999,15 +2076,104 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     B.n = n_per_channel;
     B.n_channels = h->n_channels;
     hipLaunchKernelGGL(k_wb_pairs, dim3((uint32_t)((samples + 255) / 256)), dim3(256), 0, s, B);
+    // The passes run in TIME SLICES of whole blocks (512 PCM samples), on three streams: the x32 cascade with the Nco
+    // steps (k_mod<WB_HEAD>) on the caller's, the phase recurrence -- serial per channel, the same 17 ns per step for
+    // 64 channels as for 4096, two thirds of the call -- on one of the handle's, the table lookup and the x8 cascade
+    // (k_wb_rails, k_mod<WB_TAIL>) on another: slice t's rails and tail run beside the recurrence of slice t + 1, so
+    // the call costs little more than the recurrence alone.  (WbFmModulator.cc:583-637 does the three per sample.)
+    // slice boundaries (input samples, multiples of the cascade's tile): a short first slice (the recurrence starts
+    // behind its head pass), short last ones (what is left behind the last recurrence is one slice's rails and
+    // tail), long ones between (every slice costs the recurrence a launch: ~12 us)
+    std::vector<uint32_t> cuts;
+    {
+      const uint32_t q = 256 / kModTile * kModTile > 0 ? 256 / kModTile * kModTile : kModTile;   // quarter of a block
+      uint32_t lo = 0;
+      const uint32_t n = n_per_channel;
+      auto push = [&](uint32_t len) {
+        if (len != 0 && cuts.size() + 1 < (size_t)hrfd_mod::kMaxSlices)
+        {
+          lo += len;
+          cuts.push_back(lo);
+        }
+      };
+      if (n > 6 * q)
+      {
+        push(2 * q);
+        while (n - lo > 2 * q + 8 * q)
+        {
+          push(8 * q);
+        }
+        if (n - lo > 2 * q)
+        {
+          push((n - lo - 2 * q + kModTile - 1) / kModTile * kModTile);
+        }
+        if (n - lo > q)
+        {
+          push(q);
+        }
+      }
+      if (lo < n)
+      {
+        cuts.push_back(n);
+      }
+    }
+    // (only when the recurrence has CUs of its own: beside other kernels on its CUs it loses more than the overlap gains)
+    const bool sliced = h->sliced != 0 && cuts.size() > 1 && h->s_scan != nullptr && (h->cu_masked || h->sliced > 1);
     M.in = h->d_rails;
     M.wbstep = h->d_wb;
     M.param = h->d_param;
-    hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_HEAD>, dim3(grid), dim3(kModThreads), 0, s, M);
-    phase_scan(h, h->d_wb, (size_t)n_per_channel * 32, h->d_acc, h->n_channels, s);
-    hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(512, (s32 / 4 + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, s, B);
-    M.in = reinterpret_cast<const int16_t *>(h->d_wb);
-    M.wbtail = h->d_wbtail[h->cur];
-    hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(grid), dim3(kModThreads), 0, s, M);
+    if (!sliced)
+    {
+      hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_HEAD>, dim3(grid), dim3(kModThreads), 0, s, M);
+      phase_scan(h, h->d_wb, (size_t)n_per_channel * 32, (size_t)n_per_channel * 32, h->d_acc, h->n_channels, s);
+      hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(512, (s32 / 4 + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, s, B);
+      M.in = reinterpret_cast<const int16_t *>(h->d_wb);
+      M.wbtail = h->d_wbtail[h->cur];
+      hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(grid), dim3(kModThreads), 0, s, M);
+    }
+    else
+    {
+      // Three streams of the handle's own, created one after the other (different hardware queues; the caller's
+      // stream may share its hardware queue with any one stream -- when it carried kernels, the next slice's head
+      // queued up behind the previous slice's tail: measured, everything in series).  The caller's stream only
+      // forks and joins.  The head passes of all slices go out first: they depend on nothing but the input.
+      hipStream_t hs = h->s_head;
+      HIP_TRY(hipEventRecord(h->ev_fork, s));
+      HIP_TRY(hipStreamWaitEvent(hs, h->ev_fork, 0));
+      HIP_TRY(hipStreamWaitEvent(h->s_scan, h->ev_fork, 0));
+      HIP_TRY(hipStreamWaitEvent(h->s_tail, h->ev_fork, 0));
+      ModParams T = M;
+      T.in = reinterpret_cast<const int16_t *>(h->d_wb);
+      T.wbtail = h->d_wbtail[h->cur];
+      for (size_t k = 0; k < cuts.size(); k++)
+      {
+        const uint32_t lo = (k == 0) ? 0u : cuts[k - 1], len = cuts[k] - lo;
+        M.tile0 = lo / kModTile;
+        M.tiles_launch = (len + kModTile - 1) / kModTile;
+        hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_HEAD>, dim3(h->n_channels * M.tiles_launch), dim3(kModThreads), 0, hs, M);
+        HIP_TRY(hipEventRecord(h->ev_head[k], hs));
+      }
+      for (size_t k = 0; k < cuts.size(); k++)
+      {
+        const uint32_t lo = (k == 0) ? 0u : cuts[k - 1], len = cuts[k] - lo;
+        const uint32_t tl = (len + kModTile - 1) / kModTile;
+        HIP_TRY(hipStreamWaitEvent(h->s_scan, h->ev_head[k], 0));
+        phase_scan(h, h->d_wb + (size_t)lo * 32, (size_t)len * 32, (size_t)n_per_channel * 32, h->d_acc, h->n_channels, h->s_scan);
+        HIP_TRY(hipEventRecord(h->ev_scan[k], h->s_scan));
+        HIP_TRY(hipStreamWaitEvent(h->s_tail, h->ev_scan[k], 0));
+        B.lo = lo;
+        B.len = len;
+        const size_t q = (size_t)len * 32 / 4 * h->n_channels;
+        hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(256, (q + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, h->s_tail, B);
+        T.tile0 = lo / kModTile;
+        T.tiles_launch = tl;
+        hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(h->n_channels * tl), dim3(kModThreads), 0, h->s_tail, T);
+      }
+      HIP_TRY(hipEventRecord(h->ev_join, h->s_tail));
+      HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+      M.tile0 = 0;
+      M.tiles_launch = 0;
+    }
   }
   else if (h->kind == HRFD_MOD_AM || h->kind == HRFD_MOD_FM)
   {
@@ -2037,7 +2203,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     else
     {
       hipLaunchKernelGGL(k_fm_step, dim3(gs), dim3(256), 0, s, B);
-      phase_scan(h, reinterpret_cast<uint32_t *>(h->d_phase), (size_t)n_per_channel, h->d_acc, h->n_channels, s);
+      phase_scan(h, reinterpret_cast<uint32_t *>(h->d_phase), (size_t)n_per_channel, (size_t)n_per_channel, h->d_acc, h->n_channels, s);
       hipLaunchKernelGGL(k_fm_rails, dim3(gs), dim3(256), 0, s, B);
     }
     M.in = h->d_rails;
@@ -2092,6 +2258,17 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
   HIP_TRY(hipGetLastError());
   h->cur ^= 1;
   h->last_stream = s;
+  return HRFD_OK;
+}
+
+// test hook: 0 = the WBFM modulator's passes one after the other on the caller's stream (no time slices)
+extern "C" int hrfd_mod_debug_set_sliced(hrfd_mod *h, int on)
+{
+  if (h == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL");
+  }
+  h->sliced = on;                                          // 0 off, 1 when the recurrence's stream has CUs of its own, 2 always
   return HRFD_OK;
 }
 

@@ -51,6 +51,8 @@ struct ModParams
   const uint32_t *wbtail;   // WB_TAIL: [C][2] the last two (I,Q) rail pairs of the previous call
   uint32_t n;               // input samples per channel
   uint32_t n_channels;
+  uint32_t tile0, tiles_launch;   // this launch covers tiles [tile0, tile0 + tiles_launch) of every channel (tiles_launch 0: all of
+                                  // them) -- the WBFM modulator runs its passes in time slices beside the phase recurrence
 };
 
 // taps of the eight stages as the reference's constructors quantise them
@@ -139,9 +141,10 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   // interpolateSignal's own
   constexpr bool kPairs = (KIND == HRFD_MOD_INTERP) || (KIND == HRFD_MOD_RAILS) || (KIND == HRFD_MOD_WB_HEAD);
   const uint32_t tiles = (M.n + kModTile - 1) / kModTile;
-  const uint32_t c = blockIdx.x / tiles;
-  const uint32_t tile = blockIdx.x - c * tiles;
-  if (c >= M.n_channels)
+  const uint32_t tiles_l = (M.tiles_launch != 0u) ? M.tiles_launch : tiles;
+  const uint32_t c = blockIdx.x / tiles_l;
+  const uint32_t tile = M.tile0 + (blockIdx.x - c * tiles_l);
+  if (c >= M.n_channels || tile >= tiles)
   {
     return;
   }
@@ -456,6 +459,7 @@ struct BaseParams
   const uint32_t *wbpack;   // WBFM: [16384] (int16)(cos_t[i] * 900) | (int16)(sin_t[i] * 900) << 16
   uint32_t *wbtail_out;     // WBFM: [C][2] the call's last two rail pairs (next call's history)
   uint32_t n, n_channels;
+  uint32_t lo, len;         // k_wb_rails: input samples [lo, lo + len) of every channel (len 0: all): a time slice
 };
 
 __global__ void k_am_rails(const BaseParams B)
@@ -624,7 +628,7 @@ __device__ __forceinline__ float ps_wrap_loops(float acc)
 // kPsChan: channels per workgroup (lanes of the recurrence wave in use).  The wave's time per step does not depend on
 // it, so a bank that leaves CUs idle anyway is spread thinly (16 per workgroup: less LDS traffic beside the chain, 8 %).
 template <int kPsChan>
-__global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size_t steps, float *acc_io, uint32_t n_channels, uint32_t *err)
+__global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size_t steps, size_t row_stride, float *acc_io, uint32_t n_channels, uint32_t *err)
 {
   constexpr int kPsPieces = kPsChan / 4;                  // 16-byte pieces per mover lane and chunk
   __shared__ __attribute__((aligned(16))) uint32_t ring[kPsSlots][kPsChan * kPsRow];
@@ -851,7 +855,7 @@ __global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size
         v[r] = make_uint4(0u, 0u, 0u, 0u);               // a zero step leaves the accumulator alone (x + 0 = x, no wrap: |x| <= pi)
         if (ch < n_channels && k0 < steps)
         {
-          v[r] = *reinterpret_cast<const uint4 *>(cells + (size_t)ch * steps + k0);
+          v[r] = *reinterpret_cast<const uint4 *>(cells + (size_t)ch * row_stride + k0);
         }
       }
       uint32_t big = 0u;                                   // the largest |step| as bits (a NaN or an infinity is larger still)
@@ -887,7 +891,7 @@ __global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size
         const uint4 t = *reinterpret_cast<const uint4 *>(&ring[slot][(4 * r + mc) * kPsRow + 4 * mq]);
         if ((uint32_t)r < nlive)
         {
-          *reinterpret_cast<uint4 *>(cells + (size_t)(c0 + 4u * r + (uint32_t)mc) * steps + k0) = t;
+          *reinterpret_cast<uint4 *>(cells + (size_t)(c0 + 4u * r + (uint32_t)mc) * row_stride + k0) = t;
         }
       }
       ps_order();                                          // the slot has been read (the stores may still be on their way)
@@ -899,13 +903,13 @@ __global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size
   }
 }
 
-template __global__ void k_phase_scan<16>(uint32_t *, size_t, float *, uint32_t, uint32_t *);
-template __global__ void k_phase_scan<32>(uint32_t *, size_t, float *, uint32_t, uint32_t *);
-template __global__ void k_phase_scan<64>(uint32_t *, size_t, float *, uint32_t, uint32_t *);
+template __global__ void k_phase_scan<16>(uint32_t *, size_t, size_t, float *, uint32_t, uint32_t *);
+template __global__ void k_phase_scan<32>(uint32_t *, size_t, size_t, float *, uint32_t, uint32_t *);
+template __global__ void k_phase_scan<64>(uint32_t *, size_t, size_t, float *, uint32_t, uint32_t *);
 
 // the same recurrence for a cell count that is not a multiple of four (no 16-byte pieces): one thread per channel,
 // straight from memory
-__global__ void k_phase_scan_plain(uint32_t *cells, size_t steps, float *acc_io, uint32_t n_channels)
+__global__ void k_phase_scan_plain(uint32_t *cells, size_t steps, size_t row_stride, float *acc_io, uint32_t n_channels)
 {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_channels)
@@ -913,7 +917,7 @@ __global__ void k_phase_scan_plain(uint32_t *cells, size_t steps, float *acc_io,
     return;
   }
   float acc = acc_io[c];
-  uint32_t *cell = cells + (size_t)c * steps;
+  uint32_t *cell = cells + (size_t)c * row_stride;
   for (size_t k = 0; k < steps; k++)
   {
     const float st = __builtin_bit_cast(float, cell[k]);
@@ -967,11 +971,14 @@ __global__ __launch_bounds__(kWbRailsThreads) void k_wb_rails(const BaseParams B
   }
   __syncthreads();
   const size_t n32 = (size_t)B.n * 32;
-  const size_t quads = n32 * B.n_channels / 4;
+  const size_t lo32 = (size_t)B.lo * 32, len32 = (B.len != 0u) ? (size_t)B.len * 32 : n32;   // the slice of every channel's row
+  const size_t sq = len32 / 4;                           // quads per channel in the slice
+  const size_t quads = sq * B.n_channels;
   const double two_pi = 6.283185307179586476925286766559;
   for (size_t q = (size_t)blockIdx.x * kWbRailsThreads + threadIdx.x; q < quads; q += (size_t)gridDim.x * kWbRailsThreads)
   {
-    const size_t t = 4 * q;
+    const size_t cq = q / sq;
+    const size_t t = cq * n32 + lo32 + 4 * (q - cq * sq);
     const uint4 ph = *reinterpret_cast<const uint4 *>(B.wb + t);
     const uint32_t pb[4] = {ph.x, ph.y, ph.z, ph.w};
     uint32_t w[4];

@@ -159,6 +159,24 @@ def test_wbfm_modulator_bit_exact(oracle):
     assert _mod_case(oracle, "wbfmmod", api.MOD_WBFM, 0) == 0.0
 
 
+def test_wbfm_modulator_time_slices(oracle):
+    """a long call (16 blocks and a ragged rest) runs its passes in time slices on three streams -- the phase
+    recurrence of slice t + 1 beside the table lookup and the x8 cascade of slice t: bit-exact against the oracle, equal
+    to the unsliced call (hook), and the state a second call continues from"""
+    C, n = 5, 16 * 512 + 77
+    pcm = np.stack([synth.lcg_pcm(140 + c, 2 * n) for c in range(C)])
+    a, b = api.Mod(api.MOD_WBFM, C), api.Mod(api.MOD_WBFM, C)
+    a.debug_set_sliced(2)                                   # slices whether or not the recurrence's stream got CUs of its own
+    b.debug_set_sliced(0)
+    os_ = [oracle.wbfmmod() for _ in range(C)]
+    for call in range(2):
+        x = pcm[:, call * n:(call + 1) * n]
+        ga, gb = a.process(x), b.process(x)
+        assert (ga == gb).all(), call
+        for c in range(C):
+            assert (ga[c] == os_[c].process(x[c])).all(), (call, c)
+
+
 def test_wbfm_modulator_absurd_deviation_takes_the_loops(oracle):
     """setFrequencyDeviation tests the CURRENT value against its limit (WbFmModulator.cc:313), so one absurd deviation
     gets through: Nco steps of tens of radians, several turns of the wrap loops per sample.  k_phase_scan's branch-free
