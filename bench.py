@@ -496,7 +496,7 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
     if threshold is not None:
         rx.set_threshold(int(threshold))
     if serial_modes:
-        rx.debug_set_split(False)
+        rx.debug_set_fir_flow(0)
     stream = torch.cuda.Stream(device=device)
     iq_root = None
     scatter = scatter and world > 1
@@ -630,7 +630,7 @@ def main():
     ap.add_argument("--threshold", type=int, default=None, help="squelch threshold in dBFS (setSignalDetectThreshold)")
     ap.add_argument("--iqdump", action="store_true", help="also write the 256 kS/s stream (`enable iqdump`)")
     ap.add_argument("--serial-modes", action="store_true",
-                    help="mixed bank: the modes' kernels one after the other (test hook; default: the WBFM flow kernel beside the rest)")
+                    help="mixed bank: one kernel per mode, one after the other (test hook; default: ONE launch, the mode read per workgroup)")
     ap.add_argument("--stride-pad", type=int, default=0,
                     help="experiment: extra bytes between the channels' input buffers (channel_stride = blocks * 262144 + pad)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

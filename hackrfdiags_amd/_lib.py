@@ -90,7 +90,6 @@ def load() -> C.CDLL:
     L.hrfd_rx_debug_counters.argtypes = [_vp, _u32p]
     L.hrfd_rx_debug_set_stagger.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_expire.argtypes = [_vp, C.c_int]
-    L.hrfd_rx_debug_set_split.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_set_gated.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_set_fir_flow.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_set_stream.argtypes = [_vp, C.c_int]

@@ -140,10 +140,6 @@ class Rx:
         """test hook: False = no gated second pass on the device (closed gates in a batch go back to the host's replay)"""
         check(self.L.hrfd_rx_debug_set_gated(self.h, int(bool(on))), "hrfd_rx_debug_set_gated")
 
-    def debug_set_split(self, on: bool):
-        """test hook: False = the kernels of a bank of several modes run one after the other"""
-        check(self.L.hrfd_rx_debug_set_split(self.h, int(bool(on))), "hrfd_rx_debug_set_split")
-
     def debug_expire(self, where: int):
         """test hook: workgroup 0 of the next k_rx_wbfm_flow launch treats its wait `where` (1..6) as expired"""
         check(self.L.hrfd_rx_debug_expire(self.h, int(where)), "hrfd_rx_debug_expire")

@@ -163,8 +163,7 @@ struct hrfd_rx
   uint32_t *d_local = nullptr;          // the per-launch counters of the latest launch (set 0 = d_counters, set 1 behind it)
   int parity = 0;
   uint32_t *d_lists = nullptr;         // [10][n_channels] channel ids grouped by mode; list 6: every channel that is not WBFM,
-                                       // list 7: the AM and SSB channels, list 8: those followed by the FM channels,
-                                       // list 9: every channel but those in mode NONE
+                                       // list 7: the AM and SSB channels, list 9: every channel but those in mode NONE
   uint32_t list_count[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t *d_sub_lists = nullptr;     // the same for a launch over a subset of the channels (replay of failed channels);
                                        // list 6 there: the subset itself
@@ -194,10 +193,7 @@ struct hrfd_rx
 
   // measurement hook: HIP events around the demodulator kernels of a launch
   std::vector<hipEvent_t> ev;           // 2 events per slot; slot = launch index % slots
-  hipStream_t side = nullptr;           // a bank of several modes: everything but the WBFM flow kernel runs here, beside it
-  hipEvent_t ev_rest = nullptr, ev_fin = nullptr;   // mixed bank: fork (the launch stream so far) and join (the side stream's last kernel)
   uint32_t ev_launches = 0;
-  std::vector<uint8_t> ev_side_used;    // per slot: the side stream ran kernels in that launch
 
   // test hooks
   unsigned long long *d_dbg = nullptr;  // optional phase stamps (hrfd_rx_debug_stamps)
@@ -209,7 +205,6 @@ struct hrfd_rx
   int32_t wbfm_max_threshold = -200;   // the highest squelch threshold among the WBFM channels (can a gate close at all?)
   int fir_flow = -1;                   // test hook: AM / SSB / FM batches on the flow kernel's FIR modes: -1 when the bank is large enough, 0 never, 1 always
   int gated_pass = 1;                  // test hook: 0 = no gated second pass on the device (closed gates go back to the host's replay)
-  int split_modes = 1;                 // test hook: 0 = a bank of several modes runs its kernels one after the other
   int expire_once = 0;                 // test hook: the next k_rx_wbfm_flow launch treats this wait (1..6) of workgroup 0 as expired
   uint32_t last_counters[kNumCounters] = {0};
 };
@@ -222,7 +217,6 @@ static int rx_free(hrfd_rx *h)
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  if (h->side) (void)hipStreamSynchronize(h->side);
   void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_atcorr2, h->d_att0, h->d_dbfs, h->d_counters,
                   h->d_lists, h->d_sub_lists, h->d_chan, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
                   h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq, h->d_dbg};
@@ -234,9 +228,6 @@ static int rx_free(hrfd_rx *h)
   {
     (void)hipEventDestroy(e);
   }
-  if (h->ev_rest) (void)hipEventDestroy(h->ev_rest);
-  if (h->ev_fin) (void)hipEventDestroy(h->ev_fin);
-  if (h->side) (void)hipStreamDestroy(h->side);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return HRFD_OK;
@@ -294,9 +285,6 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
     return true;
   };
   bool ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming) == hipSuccess &&
-       hipEventCreateWithFlags(&h->ev_fin, hipEventDisableTiming) == hipSuccess;
   ok = ok && alloc((void **)&h->d_cfg, sizeof(ChanCfg) * n_channels);
   ok = ok && alloc((void **)&h->d_state, sizeof(ChanState) * n_channels);
   ok = ok && alloc((void **)&h->d_state_out, sizeof(ChanState) * n_channels);
@@ -550,35 +538,23 @@ extern "C" int hrfd_rx_debug_enable_timing(hrfd_rx *h, int slots)
   }
   h->ev.clear();
   h->ev_launches = 0;
-  // per slot: the launch stream's start and end, and the ends of the two other streams a bank of several modes uses
-  for (int i = 0; i < 4 * slots; i++)
+  // per slot: the start and the end of the launch's kernels on its stream
+  for (int i = 0; i < 2 * slots; i++)
   {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
     h->ev.push_back(e);
   }
-  h->ev_side_used.assign((size_t)slots, 0);
   return HRFD_OK;
 }
 
 extern "C" int hrfd_rx_debug_kernel_ms(hrfd_rx *h, int slot, float *ms)
 {
-  if (h == nullptr || ms == nullptr || slot < 0 || (size_t)(4 * slot + 3) >= h->ev.size())
+  if (h == nullptr || ms == nullptr || slot < 0 || (size_t)(2 * slot + 1) >= h->ev.size())
   {
     return fail(HRFD_EINVAL, "timing slot out of range");
   }
-  // From the launch's first kernel to the end of its last one: the later of the two streams' ends.  (The join of the
-  // side stream into the launch stream comes behind both and is the caller's time between steps, not the kernels'.)
-  HIP_TRY(hipEventElapsedTime(ms, h->ev[4 * slot], h->ev[4 * slot + 1]));
-  for (int k = 0; k < 2; k++)
-  {
-    if (h->ev_side_used[(size_t)slot] & (1 << k))
-    {
-      float side_ms = 0.0f;
-      HIP_TRY(hipEventElapsedTime(&side_ms, h->ev[4 * slot], h->ev[4 * slot + 2 + k]));
-      *ms = std::max(*ms, side_ms);
-    }
-  }
+  HIP_TRY(hipEventElapsedTime(ms, h->ev[2 * slot], h->ev[2 * slot + 1]));
   return HRFD_OK;
 }
 
@@ -666,17 +642,6 @@ extern "C" int hrfd_rx_debug_set_gated(hrfd_rx *h, int on)
     return fail(HRFD_EINVAL, "NULL");
   }
   h->gated_pass = on ? 1 : 0;
-  return HRFD_OK;
-}
-
-// test hook: 0 = the kernels of a bank of several modes run one after the other instead of the flow kernel beside the rest
-extern "C" int hrfd_rx_debug_set_split(hrfd_rx *h, int on)
-{
-  if (h == nullptr)
-  {
-    return fail(HRFD_EINVAL, "NULL");
-  }
-  h->split_modes = on ? 1 : 0;
   return HRFD_OK;
 }
 
@@ -869,15 +834,6 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
           lists[(size_t)9 * h->n_channels + cnt[9]++] = c;   // list 9: every channel that has a demodulator (k_rx_flow_bank)
         }
       }
-      // list 8: the AM and SSB channels (their 8 kS/s tails run beside what follows), then the FM channels
-      for (uint32_t i = 0; i < cnt[7]; i++)
-      {
-        lists[(size_t)8 * h->n_channels + cnt[8]++] = lists[(size_t)7 * h->n_channels + i];
-      }
-      for (uint32_t i = 0; i < cnt[HRFD_MODE_FM]; i++)
-      {
-        lists[(size_t)8 * h->n_channels + cnt[8]++] = lists[(size_t)HRFD_MODE_FM * h->n_channels + i];
-      }
       memcpy(h->list_count, cnt, sizeof(cnt));
       h->wbfm_max_threshold = INT32_MIN;
       for (uint32_t c = 0; c < h->n_channels; c++)
@@ -1030,64 +986,110 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.self_finish = 0;
   P.sticky = h->d_counters;
 
-  const size_t ev_slots = h->ev.size() / 4;
+  const size_t ev_slots = h->ev.size() / 2;
   const size_t ev_slot = ev_slots ? (h->ev_launches % ev_slots) : 0;
   if (ev_slots)
   {
-    HIP_TRY(hipEventRecord(h->ev[4 * ev_slot], s));
-    h->ev_side_used[ev_slot] = 0;
+    HIP_TRY(hipEventRecord(h->ev[2 * ev_slot], s));
   }
-  auto side_stamp = [&]() -> hipError_t {               // behind every kernel that goes to the side stream
-    if (!ev_slots)
-    {
-      return hipSuccess;
-    }
-    h->ev_side_used[ev_slot] |= 1;
-    return hipEventRecord(h->ev[4 * ev_slot + 2], h->side);
-  };
-  // per-mode dispatch (BASELINE config 3).
-  //
-  // A bank of WBFM channels alone is one launch of k_rx_wbfm_flow on the caller's stream.  A bank of several modes
-  // runs in TWO PARTS SIDE BY SIDE (`split`): the flow kernel goes out first, one persistent workgroup per WBFM
-  // channel (it holds a whole CU: 157 KB of LDS, 16 waves x 124 VGPRs, so nothing else is ever placed beside it), and
-  // the other modes' kernels -- the FIR front kernel of the AM / SSB / FM channels, the 8 kS/s recurrences, mode NONE,
-  // the finisher of all channels that are not WBFM -- follow on the handle's side stream and fill the CUs the flow
-  // kernel left.  The launch stream joins the side stream at the end.  (Submitted the other way round, or as equals
-  // between a fork and a join, the FIR workgroups take the CUs first and the whole-CU workgroups wait: 0.35 ms
-  // against 0.26 serial)  Without a flow kernel in the launch everything is serial on the caller's
-  // stream, the recurrences on the side stream beside the next mode's front kernel.
+  // ---------------------------------------------------------------- dispatch
+  // Everything goes to the caller's stream, in this order of preference:
+  //  1. k_rx_flow_bank: a bank of several kinds (WBFM, FM, AM / SSB) as ONE launch -- one persistent workgroup per
+  //     channel, the mode read per workgroup, every channel finished inside (BASELINE config 3);
+  //  2. k_rx_wbfm_flow<.., MODE> per kind, the same shape, when there are channels enough of that kind to fill the
+  //     chip that way (WBFM: always; BASELINE configs 2 and 4), behind it the gated pass for WBFM channels whose
+  //     squelch gates may close;
+  //  3. the block kernels (one workgroup per channel-block: k_rx_wbfm, k_rx_fir + k_rx_post) with k_rx_finish behind
+  //     them: single-block calls (the reference's cadence), the inner demodulator API, the exact replay of a subset,
+  //     block sizes that are not whole units of 512 samples at 256 kS/s, FIR-mode batches with the iq dump, small banks.
+  // The flow shapes need whole units of two 4 KiB pieces per block, at most 64 blocks, and the first-octant table.
   P.dbg = nullptr;
-  const uint32_t n_wb = list_count[HRFD_MODE_WBFM];
-  const bool streaming = n_wb != 0 && h->use_stream && n_blocks > 1 && !opt.serial && !opt.src256;
-  // k_rx_wbfm_flow: whole units of two 4 KiB pieces, the first-octant-table atan2
-  const bool flow = streaming && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 &&
-                    (n256 % 512u) == 0 && n256 >= 2048u;
-  // A bank of several modes as ONE launch (k_rx_flow_bank: one persistent workgroup per channel, the mode read per
-  // workgroup): whole-bank batches of whole units without the iq dump, up to 16 blocks, channels enough to fill the chip
-  const bool bank = flow && opt.subset == nullptr && d_iq256 == nullptr && n_blocks <= 16u && h->fir_flow != 0 && h->split_modes &&
-                    (list_count[7] + list_count[HRFD_MODE_FM]) != 0 && (h->fir_flow > 0 || list_count[9] >= 48u);
-  const bool split = flow && !bank && opt.subset == nullptr && list_count[6] != 0 && h->split_modes;
-  hipStream_t fs = split ? h->side : s;                    // where the kernels of the other modes go
-  hipStream_t ws = s;                                      // ... and the flow kernel: first in line, on the caller's stream
+  const uint32_t n_wb = list_count[HRFD_MODE_WBFM], n_as = list_count[7], n_fm = list_count[HRFD_MODE_FM];
+  const bool batch = n_blocks > 1 && !opt.serial && !opt.src256 && opt.subset == nullptr;
+  const bool flow_shape = batch && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 && (n256 % 512u) == 0 && n256 >= 2048u;
+  const bool flow = flow_shape && n_wb != 0;              // the WBFM channels run on the flow kernel
+  const bool fir_shape = flow_shape && h->fir_flow != 0 && n_blocks <= 64u && d_iq256 == nullptr;
+  const int kinds = (n_wb != 0) + (n_as != 0) + (n_fm != 0);
+  const bool bank = fir_shape && kinds >= 2 && n_blocks <= 16u && (h->fir_flow > 0 || list_count[9] >= 48u);
+  const bool as_flow = !bank && fir_shape && n_as != 0 && (h->fir_flow > 0 || n_as >= 48u);
+  const bool fm_flow = !bank && fir_shape && n_fm != 0 && (h->fir_flow > 0 || n_fm >= 48u);
+  const bool may_close = (int64_t)h->wbfm_max_threshold > -42 - (int64_t)gain_db;   // can a WBFM gate close at all? (see below)
 
-  auto launch_wbfm_or_none = [&](int m, hipStream_t ks) -> int {
-    const uint32_t n = list_count[m];
-    if (n == 0)
+  // k_rx_wbfm_flow / k_rx_flow_bank over a channel list: one run per channel unless the WBFM bank alone is too small
+  // to fill the chip with whole-CU workgroups
+  auto launch_flow = [&](int list, uint32_t n, int mode) -> int {
+    P.chan_list = d_lists + (size_t)list * h->n_channels;
+    P.n_list = n;
+    const uint32_t groups = 8u * ((n + 7u) / 8u);
+    uint32_t run_len = n_blocks;
+    if (mode == HRFD_MODE_WBFM)
     {
-      return HRFD_OK;
+      // runs of consecutive blocks per workgroup (only a run's first block re-produces the history in front of it):
+      // as long as possible (16) while the launch still fills the chip
+      run_len = (h->run_len > 0) ? (uint32_t)h->run_len : 16u;
+      run_len = std::min(run_len, n_blocks);
+      while (h->run_len <= 0 && run_len > 1 && groups * ((n_blocks + run_len - 1) / run_len) < 256u)
+      {
+        run_len--;
+      }
     }
+    P.run_len = run_len;
+    P.n_runs = (n_blocks + run_len - 1) / run_len;
+    const uint32_t grid = groups * P.n_runs;
+    P.dbg = (h->d_dbg != nullptr && (size_t)grid * kDbgSlots <= h->dbg_cap && mode == HRFD_MODE_WBFM) ? h->d_dbg : nullptr;
+    P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here (the FIR modes: ring tiles read below a generation)
+    P.self_finish = 1;                                     // the last workgroup of a channel finishes it (finish_channel)
+    P.dbg_flags |= h->expire_once << 16;
+    h->expire_once = 0;
+    if (mode < 0)
+    {
+      hipLaunchKernelGGL((k_rx_flow_bank<HRFD_FLOW_SVC>), dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    else if (mode == HRFD_MODE_FM)
+    {
+      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 2>), dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    else if (mode != HRFD_MODE_WBFM)
+    {
+      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 14>), dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    else if (d_iq256 != nullptr)
+    {
+      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    else
+    {
+      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
+    }
+    P.dbg_flags &= 0xffff;
+    P.dbg = nullptr;
+    HIP_TRY(hipGetLastError());
+    // Squelch (Squelch.cc:227-273, IqDataProcessor.cc:961-1034).  The detector's lowest level is 0 - 42 - gain_db dBFS
+    // (DbfsCalculator.cc:111-147): with a threshold at or below it -- the reference's default is -200 -- no gate of
+    // the bank can ever close and the batch launch is all there is.  Otherwise the gated pass follows: its
+    // workgroups redo the WBFM channels that failed on a closed gate, exactly, and the others leave at once.
+    if ((mode < 0 || mode == HRFD_MODE_WBFM) && n_wb != 0 && h->gated_pass && n_blocks <= 64u && may_close)
+    {
+      P.chan_list = d_lists + (size_t)HRFD_MODE_WBFM * h->n_channels;
+      P.n_list = n_wb;
+      P.run_len = n_blocks;
+      P.n_runs = 1;
+      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>), dim3(8u * ((n_wb + 7u) / 8u)), dim3(kThreads), 0, s, P);
+      HIP_TRY(hipGetLastError());
+    }
+    P.self_finish = 0;
+    P.warm_tiles = warm_tiles;
+    return HRFD_OK;
+  };
+  // the block kernels of mode NONE (front end and squelch only) and WBFM: runs of blocks per workgroup
+  auto launch_wbfm_blocks = [&](int m) -> int {
+    const uint32_t n = list_count[m];
     P.chan_list = d_lists + (size_t)m * h->n_channels;
     P.n_list = n;
-    // runs of consecutive blocks per workgroup (only a run's first block re-produces the history
-    // in front of it): as long as possible while the launch still fills the chip --
-    // the streaming kernels hold one workgroup per CU (256), k_rx_wbfm two (512).  Beside the other modes' kernels
-    // (split) the chip is filled by them: one run per channel.
     const uint32_t groups = 8u * ((n + 7u) / 8u);
-    const bool strm = (m == HRFD_MODE_WBFM) && flow;
-    const uint32_t fill = strm ? 256u : 512u;
-    uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : (strm ? 16u : 8u);
+    uint32_t run_len = (h->run_len > 0) ? (uint32_t)h->run_len : 8u;
     run_len = std::min(run_len, n_blocks);
-    while (!(split && m == HRFD_MODE_WBFM) && h->run_len <= 0 && run_len > 1 && groups * ((n_blocks + run_len - 1) / run_len) < fill)
+    while (h->run_len <= 0 && run_len > 1 && groups * ((n_blocks + run_len - 1) / run_len) < 512u)
     {
       run_len--;
     }
@@ -1101,50 +1103,19 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     P.dbg = (h->d_dbg != nullptr && (size_t)grid * kDbgSlots <= h->dbg_cap && m == HRFD_MODE_WBFM) ? h->d_dbg : nullptr;
     if (m == HRFD_MODE_NONE)
     {
-      hipLaunchKernelGGL((k_rx_wbfm<0, false, false>), dim3(grid), dim3(kThreads), 0, ks, P);
+      hipLaunchKernelGGL((k_rx_wbfm<0, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     else if (opt.src256)
     {
-      hipLaunchKernelGGL((k_rx_wbfm<3, true, false>), dim3(grid), dim3(kThreads), 0, ks, P);
-    }
-    else if (flow)
-    {
-      P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here
-      P.self_finish = 1;                                 // the last workgroup of a channel finishes it (finish_channel)
-      P.dbg_flags |= h->expire_once << 16;
-      h->expire_once = 0;
-      if (d_iq256 != nullptr)
-      {
-        hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true>), dim3(grid), dim3(kThreads), 0, ks, P);
-      }
-      else
-      {
-        hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false>), dim3(grid), dim3(kThreads), 0, ks, P);
-      }
-      P.dbg_flags &= 0xffff;
-      // Squelch (Squelch.cc:227-273, IqDataProcessor.cc:961-1034).  The detector's lowest level is 0 - 42 - gain_db dBFS
-      // (DbfsCalculator.cc:111-147): with a threshold at or below it -- the reference's default is -200 -- no gate of
-      // the bank can ever close and the batch launch is all there is.  Otherwise the gated pass follows: its
-      // workgroups redo the channels that failed on a closed gate, exactly, and the others leave at once.
-      if (h->gated_pass && n_blocks <= 64u && (int64_t)h->wbfm_max_threshold > -42 - (int64_t)gain_db)
-      {
-        const uint32_t run_len_b = P.run_len, n_runs_b = P.n_runs;
-        P.run_len = n_blocks;
-        P.n_runs = 1;
-        hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>), dim3(groups), dim3(kThreads), 0, ks, P);
-        P.run_len = run_len_b;
-        P.n_runs = n_runs_b;
-      }
-      P.self_finish = 0;
-      P.warm_tiles = warm_tiles;
+      hipLaunchKernelGGL((k_rx_wbfm<3, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     else if (h->arith_ok && h->atan_mode != 0)
     {
-      hipLaunchKernelGGL((k_rx_wbfm<3, false, true>), dim3(grid), dim3(kThreads), 0, ks, P);
+      hipLaunchKernelGGL((k_rx_wbfm<3, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     else
     {
-      hipLaunchKernelGGL((k_rx_wbfm<3, false, false>), dim3(grid), dim3(kThreads), 0, ks, P);
+      hipLaunchKernelGGL((k_rx_wbfm<3, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     P.dbg = nullptr;
     HIP_TRY(hipGetLastError());
@@ -1153,197 +1124,102 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
 
   if (bank)
   {
-    P.chan_list = d_lists + (size_t)9 * h->n_channels;
-    P.n_list = list_count[9];
-    P.run_len = n_blocks;
-    P.n_runs = 1;
-    P.self_finish = 1;
-    P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);
-    P.dbg_flags |= h->expire_once << 16;
-    h->expire_once = 0;
-    hipLaunchKernelGGL((k_rx_flow_bank<HRFD_FLOW_SVC>), dim3(8u * ((P.n_list + 7u) / 8u)), dim3(kThreads), 0, s, P);
-    P.dbg_flags &= 0xffff;
-    HIP_TRY(hipGetLastError());
-    if (n_wb != 0 && h->gated_pass && (int64_t)h->wbfm_max_threshold > -42 - (int64_t)gain_db)
-    {
-      // the gated second pass over the WBFM channels whose gates closed (see launch_wbfm_or_none)
-      P.chan_list = d_lists + (size_t)HRFD_MODE_WBFM * h->n_channels;
-      P.n_list = n_wb;
-      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>), dim3(8u * ((n_wb + 7u) / 8u)), dim3(kThreads), 0, s, P);
-      HIP_TRY(hipGetLastError());
-    }
-    P.self_finish = 0;
-    P.warm_tiles = warm_tiles;
-  }
-  if (split)
-  {
-    // everything submitted to the launch stream so far (resets, the previous launch) is in front of both parts
-    HIP_TRY(hipEventRecord(h->ev_rest, s));
-    HIP_TRY(hipStreamWaitEvent(h->side, h->ev_rest, 0));
-    if ((rc = launch_wbfm_or_none(HRFD_MODE_WBFM, ws)) != HRFD_OK) return rc;
-  }
-  // AM, SSB and FM.
-  //  * beside the flow kernel (split): ONE grid for all of them (k_rx_fir<15>: the mode is read per workgroup; list 8
-  //    holds the AM and SSB channels in front of the FM channels) that finishes its own channels;
-  //  * else AM and SSB as one launch for both kinds (k_rx_fir<14>: the same three decimators) and their 8 kS/s
-  //    recurrences as the next (k_rx_post<14>, one workgroup per channel, which also finishes the channel), then FM
-  //    (k_rx_fir<2>, whose workgroups finish their own channels);
-  //  * the inner demodulator API and the replay of a subset (single blocks, latency paths): the same kernels with a
-  //    finisher kernel at the end.
-  const bool fir_self = !opt.src256 && opt.subset == nullptr;
-  // The flow kernel's FIR modes (k_rx_wbfm_flow<.., 2> FM, <.., 14> AM / SSB): one persistent workgroup per channel,
-  // the whole call as one stream, everything finished inside.  For whole-bank batches of whole units without the iq
-  // dump, when there are channels enough to fill the chip that way.
-  auto fir_flow_ok = [&](uint32_t n, bool needs_tab) -> bool {
-    if (!fir_self || h->fir_flow == 0 || n_blocks < 2u || n_blocks > 64u || (n256 % 512u) != 0 || n256 < 2048u || d_iq256 != nullptr)
-    {
-      return false;
-    }
-    if (needs_tab && (!h->tab_ok || h->atan_mode == 0))
-    {
-      return false;
-    }
-    return h->fir_flow > 0 || n >= 48u;
-  };
-  auto launch_fir_flow = [&](int list, uint32_t n, bool fm) -> int {
-    P.chan_list = d_lists + (size_t)list * h->n_channels;
-    P.n_list = n;
-    P.run_len = n_blocks;
-    P.n_runs = 1;
-    P.self_finish = 1;
-    P.warm_tiles = 1;                                      // ring tiles a generation reads below its own
-    const uint32_t grid = 8u * ((n + 7u) / 8u);
-    if (fm)
-    {
-      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 2>), dim3(grid), dim3(kThreads), 0, fs, P);
-    }
-    else
-    {
-      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 14>), dim3(grid), dim3(kThreads), 0, fs, P);
-    }
-    P.self_finish = 0;
-    P.warm_tiles = warm_tiles;
-    HIP_TRY(hipGetLastError());
-    return HRFD_OK;
-  };
-  const bool amssb_flow = !bank && list_count[7] != 0 && fir_flow_ok(list_count[7], false);
-  const bool fm_flow = !bank && list_count[HRFD_MODE_FM] != 0 && fir_flow_ok(list_count[HRFD_MODE_FM], true);
-  if (amssb_flow)
-  {
-    if ((rc = launch_fir_flow(7, list_count[7], false)) != HRFD_OK) return rc;
-  }
-  if (fm_flow)
-  {
-    if ((rc = launch_fir_flow(HRFD_MODE_FM, list_count[HRFD_MODE_FM], true)) != HRFD_OK) return rc;
-  }
-  if (bank)
-  {
-    // (everything with a demodulator went out in the bank launch)
-  }
-  else if (split && list_count[8] != 0 && !amssb_flow && !fm_flow)
-  {
-    P.chan_list = d_lists + (size_t)8 * h->n_channels;
-    P.n_list = list_count[8];
-    P.self_finish = 1;
-    const uint32_t grid = 8u * ((P.n_list + 7u) / 8u) * n_blocks;
-    if (h->arith_ok && h->atan_mode != 0)
-    {
-      hipLaunchKernelGGL((k_rx_fir<15, false, true>), dim3(grid), dim3(kThreads), 0, fs, P);
-    }
-    else
-    {
-      hipLaunchKernelGGL((k_rx_fir<15, false, false>), dim3(grid), dim3(kThreads), 0, fs, P);
-    }
-    P.self_finish = 0;
-    HIP_TRY(hipGetLastError());
+    if ((rc = launch_flow(9, list_count[9], -1)) != HRFD_OK) return rc;
   }
   else
   {
-    if (list_count[7] != 0 && !amssb_flow)
+    // AM and SSB: one launch for both kinds (the same three decimators), then their 8 kS/s recurrences
+    if (as_flow)
     {
-      const uint32_t n = list_count[7];
+      if ((rc = launch_flow(7, n_as, HRFD_MODE_AM)) != HRFD_OK) return rc;
+    }
+    else if (n_as != 0)
+    {
       P.chan_list = d_lists + (size_t)7 * h->n_channels;
-      P.n_list = n;
-      const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+      P.n_list = n_as;
+      const uint32_t grid = 8u * ((n_as + 7u) / 8u) * n_blocks;
       if (opt.src256)
       {
-        hipLaunchKernelGGL((k_rx_fir<14, true, false>), dim3(grid), dim3(kThreads), 0, fs, P);
+        hipLaunchKernelGGL((k_rx_fir<14, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       else
       {
-        hipLaunchKernelGGL((k_rx_fir<14, false, false>), dim3(grid), dim3(kThreads), 0, fs, P);
+        hipLaunchKernelGGL((k_rx_fir<14, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
       }
-      P.self_finish = fir_self ? 1 : 0;
-      hipLaunchKernelGGL(k_rx_post<14>, dim3(n), dim3(256), 0, fs, P);
-      P.self_finish = 0;
+      hipLaunchKernelGGL(k_rx_post<14>, dim3(n_as), dim3(256), 0, s, P);
       HIP_TRY(hipGetLastError());
     }
-    if (list_count[HRFD_MODE_FM] != 0 && !fm_flow)
+    if (fm_flow)
     {
-      const uint32_t n = list_count[HRFD_MODE_FM];
+      if ((rc = launch_flow(HRFD_MODE_FM, n_fm, HRFD_MODE_FM)) != HRFD_OK) return rc;
+    }
+    else if (n_fm != 0)
+    {
       P.chan_list = d_lists + (size_t)HRFD_MODE_FM * h->n_channels;
-      P.n_list = n;
-      P.self_finish = fir_self ? 1 : 0;
-      const uint32_t grid = 8u * ((n + 7u) / 8u) * n_blocks;
+      P.n_list = n_fm;
+      const uint32_t grid = 8u * ((n_fm + 7u) / 8u) * n_blocks;
       if (opt.src256)
       {
-        hipLaunchKernelGGL((k_rx_fir<2, true, false>), dim3(grid), dim3(kThreads), 0, fs, P);
+        hipLaunchKernelGGL((k_rx_fir<2, true, false>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       else if (h->arith_ok && h->atan_mode != 0)
       {
-        hipLaunchKernelGGL((k_rx_fir<2, false, true>), dim3(grid), dim3(kThreads), 0, fs, P);
+        hipLaunchKernelGGL((k_rx_fir<2, false, true>), dim3(grid), dim3(kThreads), 0, s, P);
       }
       else
       {
-        hipLaunchKernelGGL((k_rx_fir<2, false, false>), dim3(grid), dim3(kThreads), 0, fs, P);
+        hipLaunchKernelGGL((k_rx_fir<2, false, false>), dim3(grid), dim3(kThreads), 0, s, P);
       }
-      P.self_finish = 0;
       HIP_TRY(hipGetLastError());
     }
+    if (flow)
+    {
+      if ((rc = launch_flow(HRFD_MODE_WBFM, n_wb, HRFD_MODE_WBFM)) != HRFD_OK) return rc;
+    }
+    else if (n_wb != 0)
+    {
+      if ((rc = launch_wbfm_blocks(HRFD_MODE_WBFM)) != HRFD_OK) return rc;
+    }
   }
-  if ((rc = launch_wbfm_or_none(HRFD_MODE_NONE, fs)) != HRFD_OK) return rc;
-  if (!split && !bank)
+  if (list_count[HRFD_MODE_NONE] != 0)
   {
-    if ((rc = launch_wbfm_or_none(HRFD_MODE_WBFM, s)) != HRFD_OK) return rc;
+    if ((rc = launch_wbfm_blocks(HRFD_MODE_NONE)) != HRFD_OK) return rc;
   }
   // the channels that no kernel finished by itself
-  auto finish_list = [&](const uint32_t *list, uint32_t n, hipStream_t ks) -> int {
+  auto finish_list = [&](const uint32_t *list, uint32_t n) -> int {
     if (n != 0)
     {
       EpilogueParams G = E;
       G.chan_list = list;
       G.n_channels = n;
-      hipLaunchKernelGGL(k_rx_finish, dim3(n), dim3(64), 0, ks, G);
+      hipLaunchKernelGGL(k_rx_finish, dim3(n), dim3(64), 0, s, G);
       HIP_TRY(hipGetLastError());
     }
     return HRFD_OK;
   };
   if (opt.subset != nullptr)
   {
-    if ((rc = finish_list(d_lists + (size_t)6 * h->n_channels, list_count[6], s)) != HRFD_OK) return rc;   // the subset itself
+    if ((rc = finish_list(d_lists + (size_t)6 * h->n_channels, list_count[6])) != HRFD_OK) return rc;   // the subset itself
   }
-  else if (!fir_self)
+  else if (!bank && !flow && !as_flow && !fm_flow)
   {
-    if ((rc = finish_list(nullptr, h->n_channels, s)) != HRFD_OK) return rc;
+    if ((rc = finish_list(nullptr, h->n_channels)) != HRFD_OK) return rc;                                  // everything, one launch
   }
   else
   {
-    if ((rc = finish_list(d_lists + (size_t)HRFD_MODE_NONE * h->n_channels, list_count[HRFD_MODE_NONE], fs)) != HRFD_OK) return rc;
-    if (!flow)
+    for (int m : {HRFD_MODE_NONE, HRFD_MODE_AM, HRFD_MODE_FM, HRFD_MODE_WBFM, HRFD_MODE_LSB, HRFD_MODE_USB})
     {
-      if ((rc = finish_list(d_lists + (size_t)HRFD_MODE_WBFM * h->n_channels, list_count[HRFD_MODE_WBFM], s)) != HRFD_OK) return rc;
+      const bool self = (m == HRFD_MODE_NONE) ? false : bank || (m == HRFD_MODE_WBFM ? flow : m == HRFD_MODE_FM ? fm_flow : as_flow);
+      if (!self)
+      {
+        if ((rc = finish_list(d_lists + (size_t)m * h->n_channels, list_count[m])) != HRFD_OK) return rc;
+      }
     }
   }
   if (ev_slots)
   {
-    HIP_TRY(hipEventRecord(h->ev[4 * ev_slot + 1], ws));   // behind the launch stream's last kernel, in front of the join
+    HIP_TRY(hipEventRecord(h->ev[2 * ev_slot + 1], s));
     h->ev_launches++;
-  }
-  if (split)
-  {
-    HIP_TRY(hipEventRecord(h->ev_fin, h->side));
-    HIP_TRY(side_stamp());
-    HIP_TRY(hipStreamWaitEvent(s, h->ev_fin, 0));
   }
   h->last_stream = s;
   return HRFD_OK;

@@ -1,6 +1,11 @@
 // hackrfdiags_amd/csrc/hrfd_rx_fir_kernels.hip -- AM, narrow-band FM and SSB receive
-// kernels for gfx950.  Included after hrfd_rx_kernels.hip (same translation unit):
+// kernels for gfx950, one workgroup per channel-BLOCK.  Included after hrfd_rx_kernels.hip (same translation unit):
 // they share its front end (half-band cascade, Fs/4 mix, squelch magnitude).
+//
+// These are the kernels of single-block calls (the reference's own cadence: one acceptIqData per 262144-byte block),
+// of the inner demodulator API, of the exact replay, of block sizes that are not whole units of 512 samples at
+// 256 kS/s, of batches with the iq dump and of small banks.  Batches of 48 channels or more run on the FIR modes of
+// k_rx_wbfm_flow (hrfd_rx_flow.hip): one persistent workgroup per channel, no tail kernel.
 //
 //   k_rx_fir<FM>   tuner D(32,4) on both rails -> atan2 table -> theta[n-2]-theta[n-4]
 //                  -> +-pi wrap -> gain -> (int16) -> D(12,4) -> D(40,2) -> PCM
@@ -23,6 +28,7 @@
 
 namespace hrfd {
 
+// (the decimators' tap tables kRevTuner, kRevAmD1..3 live in hrfd_rx_kernels.hip: k_rx_wbfm_flow's FIR modes use them too)
 
 constexpr int kFirRailI16 = kFmTail + kMaxN256 + 8;            // int16 per rail (FM is the larger)
 constexpr int kFirDwords = kFirRailI16;                         // two rails of int16 = kFirRailI16 dwords
@@ -41,24 +47,27 @@ __device__ __forceinline__ int fir_dot(const uint32_t *x, const RevTaps<N> &t, i
   return acc;
 }
 
-// The FIR stages of one channel-block, by the calling workgroup; returns false when the block is not demodulated (a
-// closed gate of a single-block call).  MODE 2: FM; 14: AM or SSB (read from the channel's configuration); 15: any of
-// the three -- a bank of several modes pays ONE launch, one ramp and one tail, for all its FIR channels.
-constexpr uint32_t kNotArrived = 0xffffffffu;
-
-// `arrived` (thread 0; FM with P.self_finish only): the count this unit's arrival at its channel found, when the unit
-// could signal it early; kNotArrived when the caller still has to signal it.
 template <int MODE, bool S256, bool ARITH>
-__device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, const uint32_t b, const ChanCfg &cfg, uint32_t *lds,
-                                         uint32_t *red, uint8_t *atcorr, float *atinv, uint32_t &arrived)
+__global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
 {
-  arrived = kNotArrived;
-  constexpr bool kMayFm = (MODE == 2 || MODE == 15), kMayAmSsb = (MODE != 2);
-  const bool fm = (MODE == 15) ? (cfg.mode == 2) : (MODE == 2);
-  const int H = fm ? kFmTail : kAmTail;                   // 256 kS/s history in front of the block
+  __shared__ __attribute__((aligned(16))) uint32_t lds[kFirDwords];
+  __shared__ uint32_t red[kWaves];
+  // FM with the arithmetic atan2 (theta_arith, hrfd_rx_kernels.hip): correction bytes and 1/a
+  __shared__ __attribute__((aligned(16))) uint8_t atcorr[(ARITH && MODE == 2) ? kCorrBytes : 16];
+  __shared__ __attribute__((aligned(16))) float atinv[(ARITH && MODE == 2) ? kInvEntries : 4];
+  static_assert(sizeof(uint32_t) * kFirDwords + kCorrBytes + sizeof(float) * kInvEntries + 512 <= 81920,
+                "two workgroups per CU need <= 80 KiB of LDS each");
+
+  constexpr int H = (MODE == 2) ? kFmTail : kAmTail;     // 256 kS/s history in front of the block
+  uint32_t ci, b;
+  if (!map_unit(blockIdx.x, P.n_list, P.n_blocks, ci, b))
+  {
+    return;
+  }
+  const uint32_t c = P.chan_list[ci];
   const int tid = threadIdx.x;
   uint4 attab = make_uint4(0u, 0u, 0u, 0u);
-  if (ARITH && kMayFm && fm)
+  if (ARITH && MODE == 2)
   {
     // this thread's 16 bytes of the atan2 tables, requested now, published to LDS before F1
     if (tid < kCorrBytes / 16)
@@ -75,7 +84,11 @@ __device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, co
   const int n256 = (int)P.n256;
   const bool first = (b == 0);
   const ChanState *st = P.state + c;
-  const bool am = kMayAmSsb && cfg.mode == 1;
+  const ChanCfg cfg = P.cfg[c];
+  // MODE 14: AM and SSB channels in one launch (the same three decimators; what differs is where the tail is kept
+  // and what leaves the last stage) -- a bank of several modes pays one launch for both
+  constexpr int PM = (MODE == 14) ? 1 : MODE;
+  const bool am = (MODE == 14) ? (cfg.mode == 1) : (MODE == 1);
   const size_t unit = (size_t)c * P.n_blocks + b;
   int16_t *rails = reinterpret_cast<int16_t *>(lds);
   const int qoff = (H + n256 + 7) & ~7;
@@ -101,7 +114,7 @@ __device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, co
   // last (offset-binary bytes, i then q)
   if (first)
   {
-    const uint8_t *tail = fm ? st->fm_tail : am ? st->am_tail : st->ssb_tail;
+    const uint8_t *tail = (MODE == 2) ? st->fm_tail : am ? st->am_tail : st->ssb_tail;
     for (int t = tid; t < H; t += kThreads)
     {
       rails[t] = (int16_t)((int)tail[2 * t] - 128);
@@ -119,11 +132,11 @@ __device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, co
     uint32_t e[4];
     if (P.iq256 != nullptr)
     {
-      produce_stream<1, false, true, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<PM, false, true, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
     }
     else
     {
-      produce_stream<1, false, false, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
+      produce_stream<PM, false, false, S256, false>(X, c0, c1, X.vstart, n256, magsum, e);
     }
   }
   for (int off = 32; off > 0; off >>= 1)
@@ -146,44 +159,43 @@ __device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, co
   const bool present = dbfs >= cfg.threshold;
   // (the inner demodulator API has no squelch: X::acceptIqData always demodulates)
   const bool allowed = S256 ? true : (first ? (present || st->tracking != 0) : true);
-  // (FM finishes its channels inside the kernel: everything the finishing workgroup reads goes out written through)
-  constexpr bool kCoh = (MODE == 2 || MODE == 15);         // the modes whose kernels finish channels themselves
   if (tid == 0)
   {
     P.magnitude[X.ounit] = mean_mag;
-    st_sel<kCoh>(&P.present[unit], (uint8_t)(present ? 1 : 0));
+    P.present[unit] = present ? 1 : 0;
   }
   const bool last = (b + 1 == P.n_blocks);
   ChanState *so = P.state_out + c;
   if (last && tid < 4 && !S256)
   {
-    st_sel<kCoh>(reinterpret_cast<uint32_t *>(so->fe_tail) + tid, reinterpret_cast<const uint32_t *>(blk + P.block_bytes - 16)[tid]);
+    reinterpret_cast<uint32_t *>(so->fe_tail)[tid] =
+        reinterpret_cast<const uint32_t *>(blk + P.block_bytes - 16)[tid];
   }
   if (!allowed)
   {
-    return false;
+    return;
   }
   if (last)
   {
     // the demodulator's new input tail (the rails are overwritten below)
-    uint16_t *tail = reinterpret_cast<uint16_t *>(fm ? so->fm_tail : am ? so->am_tail : so->ssb_tail);
+    uint8_t *tail = (MODE == 2) ? so->fm_tail : am ? so->am_tail : so->ssb_tail;
     for (int t = tid; t < H; t += kThreads)
     {
-      st_sel<kCoh>(tail + t, (uint16_t)((uint32_t)(uint8_t)(rails[n256 + t] + 128) | ((uint32_t)(uint8_t)(rails[qoff + n256 + t] + 128) << 8)));
+      tail[2 * t] = (uint8_t)(rails[n256 + t] + 128);
+      tail[2 * t + 1] = (uint8_t)(rails[qoff + n256 + t] + 128);
     }
   }
   const uint32_t *ri = lds;                               // I rail as dwords (two samples each)
   const uint32_t *rq = lds + (qoff >> 1);
   const int n64 = n256 >> 2, n16 = n256 >> 4, n8 = n256 >> 5;
 
-  if (kMayFm && fm)
+  if (MODE == 2)
   {
     // ------------------------------------------------------------- FM
     // F1: tuner decimators (FmDemodulator.cc:395-442) and the table lookup of
     // demodulateSignal (:493-499), held in registers until the rails are dead.
     constexpr int kK0 = -164;                             // first 64 kS/s sample needed
     constexpr int kPairs = ((kMaxN256 / 4 + 164) / 2 + kThreads - 1) / kThreads;
-    constexpr int HF = kFmTail;
     const int npairs = (n64 - kK0) >> 1;
     if (ARITH)
     {
@@ -207,7 +219,7 @@ __device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, co
       if (q < npairs)
       {
         const int k = kK0 + 2 * q;
-        const int d0 = (4 * k - 28 + HF) >> 1;            // dword of x[4k-28]
+        const int d0 = (4 * k - 28 + H) >> 1;             // dword of x[4k-28]
         uint32_t xi[18], xq[18];
 #pragma unroll
         for (int j = 0; j < 9; j++)
@@ -228,15 +240,6 @@ __device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, co
           th[r][o] = ARITH ? theta_arith((qi << 16) | ii, atcorr, atinv) : P.atan2_lut[(qi << 8) | ii];
         }
       }
-    }
-    if (P.self_finish && !last && tid == 0)
-    {
-      // What the channel's finisher reads of a block that is not the call's last is its `present` flag, stored (written
-      // through) long ago: the arrival goes out here, behind the tuner stage, where waiting for that store costs nothing,
-      // and its result is looked at when the unit is through, three stages later.  (The last block stores the pending state at its very end: the caller
-      // signals its arrival behind those stores.)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      arrived = __hip_atomic_fetch_add(&P.fin.chan_arrived[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     float *TH = reinterpret_cast<float *>(lds);           // TH[k - kK0]
@@ -288,22 +291,19 @@ __device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, co
     {
       if (tid < kWbU)
       {
-        st_dev(&so->fm_u[tid], (int16_t)U16[kUHist + n64 - kWbU + tid]);
+        so->fm_u[tid] = (int16_t)U16[kUHist + n64 - kWbU + tid];
       }
       if (tid < kWbV)
       {
-        st_dev(&so->fm_v[tid], (int16_t)V16[kVHist + n16 - kWbV + tid]);
+        so->fm_v[tid] = (int16_t)V16[kVHist + n16 - kWbV + tid];
       }
     }
-    return true;
+    return;
   }
 
-  if (kMayAmSsb)
-  {
   // --------------------------------------------------------------- AM / SSB
   // M1: D(8,4) on both rails, outputs k in [-80, n64) (registers, then over the rails);
   // stage 2 reads from 4*(-16) - 8 = -72 on
-  constexpr int HA = kAmTail;
   constexpr int kA1Hist = 80;
   constexpr int kA1Pairs = ((kMaxN256 / 4 + kA1Hist) / 2 + kThreads - 1) / kThreads;
   const int np1 = (n64 + kA1Hist) >> 1;
@@ -317,7 +317,7 @@ __device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, co
     if (q < np1)
     {
       const int k = -kA1Hist + 2 * q;
-      const int d0 = (4 * k - 4 + HA) >> 1;               // dword of x[4k-4]
+      const int d0 = (4 * k - 4 + H) >> 1;                // dword of x[4k-4]
       uint32_t xi[6], xq[6];
 #pragma unroll
       for (int j = 0; j < 3; j++)
@@ -389,18 +389,16 @@ __device__ __forceinline__ bool fir_unit(const RxParams &P, const uint32_t c, co
         const int im = (int)(short)abs(iv), qm = (int)(short)abs(qv);
         return (im > qm) ? (int)(short)(im + (qm >> 1)) : (int)(short)(qm + (im >> 1));
       };
-      st_sel<MODE == 15>(reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)n8) + q,
-                         ((uint32_t)env(i0, q0) & 0xffffu) | ((uint32_t)env(i1, q1) << 16));
+      reinterpret_cast<uint32_t *>(P.pcm + X.ounit * (size_t)n8)[q] =
+          ((uint32_t)env(i0, q0) & 0xffffu) | ((uint32_t)env(i1, q1) << 16);
     }
     else
     {
       uint32_t *dst = reinterpret_cast<uint32_t *>(P.ssb_iq + unit * (size_t)(2 * n8));
-      st_sel<MODE == 15>(dst + q, ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16));
-      st_sel<MODE == 15>(dst + (n8 >> 1) + q, ((uint32_t)q0 & 0xffffu) | ((uint32_t)q1 << 16));
+      dst[q] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
+      dst[(n8 >> 1) + q] = ((uint32_t)q0 & 0xffffu) | ((uint32_t)q1 << 16);
     }
   }
-  }
-  return true;
 }
 
 // =============================================================================
@@ -434,10 +432,11 @@ __device__ __forceinline__ float dcrem_step(float x, float &xp, float y)
 // groups of eight with the next group in flight and v = x[k] - x[k-1] is formed off the chain,
 // so that the dependent chain per step is the multiply and the subtract only (a plain
 // `for` over LDS pays the LDS latency on every step: 5x slower).
-template <bool STORE, int U = 8>
+template <bool STORE>
 __device__ __forceinline__ float dcrem_run(const float *x, float *out, const int dummy, const int count, const int lo,
                                            const int hi, float y)
 {
+  constexpr int U = 8;
   // "lo <= k < hi" as ONE unsigned compare into VCC, and stores of the other lanes go to a dummy
   // slot: no scalar instruction and no exec-mask change between the steps (a VALU -> SALU -> VALU
   // hand-over per step made this loop 4x slower)
@@ -492,26 +491,23 @@ __device__ __forceinline__ float dcrem_run(const float *x, float *out, const int
   return y;
 }
 
-constexpr int kPostXsDw = kPostWarm + kPostSeg + 8;      // floats: kPostWarm of padding, x[-1], the segment
-constexpr int kPostYsDw = kPostSeg + 1;                  // floats: the segment's y and one dummy slot for masked-off stores
-constexpr int kPostIqDw = kPostSeg + kSsbHist;           // dwords: two int16 rails of kPostSeg + kSsbHist samples
-constexpr int kPostLdsDw = kPostXsDw + kPostYsDw + kPostIqDw;
-
-// The 8 kS/s tail of ONE AM or SSB channel over all blocks of the call, by the NT threads of the calling workgroup
-// (every thread must call it).  lds: kPostLdsDw dwords of the caller's.
-template <int MODE, int NT, bool COH = false>
-__device__ __forceinline__ void post_channel(const RxParams &P, const uint32_t c, uint32_t *lds)
+template <int MODE>
+__global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
 {
   // xs[1 + n] = x[n] of the segment, xs[0] = x[-1]; the kPostWarm floats in
   // front are never used as data (tiles near the segment start skip those steps) but keep every
   // lane's warm-up window inside the array
-  float *const xs_pad = reinterpret_cast<float *>(lds);
+  __shared__ float xs_pad[kPostWarm + kPostSeg + 8];
   float *const xs = xs_pad + kPostWarm;                   // xs[0] = x[-1] of the segment
-  float *const ys = reinterpret_cast<float *>(lds + kPostXsDw);
-  int16_t *const iq0 = reinterpret_cast<int16_t *>(lds + kPostXsDw + kPostYsDw);   // SSB: i, q with 32 samples of history
-  int16_t *const iq1 = iq0 + kPostIqDw;
-  int16_t *const iq[2] = {iq0, iq1};
-  constexpr int kPostThreads = NT;
+  __shared__ float ys[kPostSeg + 1];                      // + one dummy slot for masked-off stores
+  __shared__ int16_t iq[2][kPostSeg + kSsbHist];          // SSB: i, q with 32 samples of history
+
+  const uint32_t ci = blockIdx.x;
+  if (ci >= P.n_list)
+  {
+    return;
+  }
+  const uint32_t c = P.chan_list[ci];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -524,7 +520,7 @@ __device__ __forceinline__ void post_channel(const RxParams &P, const uint32_t c
   if (P.n_blocks == 1)
   {
     // exact gate of a single-block call (Squelch::run): closed -> nothing happens
-    const bool present = ld_dev<COH>(&P.present[(size_t)c]) != 0;
+    const bool present = P.present[(size_t)c] != 0;
     if (!P.src256 && !(present || st->tracking != 0))
     {
       return;
@@ -550,7 +546,7 @@ __device__ __forceinline__ void post_channel(const RxParams &P, const uint32_t c
       for (int r = 0; r < kPer; r++)
       {
         const int n = tid + r * kPostThreads;
-        ev[r] = (n < len) ? ld_dev<COH>(pcm + s0 + n) : (int16_t)0;
+        ev[r] = (n < len) ? pcm[s0 + n] : (int16_t)0;
       }
 #pragma unroll
       for (int r = 0; r < kPer; r++)
@@ -585,8 +581,8 @@ __device__ __forceinline__ void post_channel(const RxParams &P, const uint32_t c
           else
           {
             const int bb = g / npcm, pp = g - bb * npcm;
-            iv[r] = ld_dev<COH>(siq + (size_t)bb * (2 * npcm) + pp);
-            qv[r] = ld_dev<COH>(siq + (size_t)bb * (2 * npcm) + npcm + pp);
+            iv[r] = siq[(size_t)bb * (2 * npcm) + pp];
+            qv[r] = siq[(size_t)bb * (2 * npcm) + npcm + pp];
           }
         }
       }
@@ -637,12 +633,10 @@ __device__ __forceinline__ void post_channel(const RxParams &P, const uint32_t c
       float y = (w0 == 0) ? y1 : 0.0f;
       // warm-up: the kPostWarm samples in front of the tile (those before the segment start do
       // not exist: skipped), then the tile itself
-      // (inside k_rx_fir<15> a thread has 64 registers: groups of four there)
-      constexpr int kU = (NT > 256) ? 4 : 8;
-      y = dcrem_run<false, kU>(xs + 1 + (s - kPostWarm), nullptr, 0, kPostWarm, kPostWarm - (s - w0),
+      y = dcrem_run<false>(xs + 1 + (s - kPostWarm), nullptr, 0, kPostWarm, kPostWarm - (s - w0),
                            min(s, len) - (s - kPostWarm), y);
       const float y_spec = y;                             // speculated y[s-1]
-      y = dcrem_run<true, kU>(xs + 1 + s, ys + s, kPostSeg - s, T, 0, e - s, y);   // dummy slot: ys[kPostSeg]
+      y = dcrem_run<true>(xs + 1 + s, ys + s, kPostSeg - s, T, 0, e - s, y);   // dummy slot: ys[kPostSeg]
       const bool active = s < len;
       const bool anchored = (w0 == 0);
       const float y_left = u2f(shr1(f2u(y), f2u(y_spec)));
@@ -720,108 +714,11 @@ __device__ __forceinline__ void post_channel(const RxParams &P, const uint32_t c
       else
       {
         const int bb = g / npcm, pp = g - bb * npcm;
-        iv = ld_dev<COH>(siq + (size_t)bb * (2 * npcm) + pp);
-        qv = ld_dev<COH>(siq + (size_t)bb * (2 * npcm) + npcm + pp);
+        iv = siq[(size_t)bb * (2 * npcm) + pp];
+        qv = siq[(size_t)bb * (2 * npcm) + npcm + pp];
       }
       so->ssb_i[t] = iv;
       so->ssb_q[t] = qv;
-    }
-  }
-}
-
-// One workgroup per channel-block.  MODE 2: FM; 14: AM or SSB; 15: any of the three, read from the channel's
-// configuration -- a bank of several modes pays ONE launch, one ramp and one tail for all its FIR channels (the host
-// lists the AM and SSB channels in front of the FM channels).
-//
-// With P.self_finish (MODE 2 and 15) the kernel finishes its own channels, the way k_rx_wbfm_flow does: every
-// workgroup signals its arrival at its channel (an agent-scope counter) and the one that completes the channel runs
-// the channel's 8 kS/s tail (AM / SSB: post_channel -- the dc-removal recurrence needs every block of the call in
-// order) and its finisher (finish_channel).  No kernel behind this one.  What the finishing workgroup reads of
-// another went out written through (st_dev) and is read with ld_dev; an arrival is signalled behind the stores it
-// covers (s_waitcnt vmcnt(0)).  For an FM block that is free (fir_unit signals early, behind stores that are long
-// complete) unless it is the call's last; an AM / SSB block pays the acknowledgement of its last stage's stores,
-// ~2 us per workgroup: a bank of AM or SSB channels alone is better off with k_rx_post as a launch of its own (the
-// host does that); beside k_rx_wbfm_flow in a bank of several modes one kernel for everything wins.
-template <int MODE, bool S256, bool ARITH>
-__global__ __launch_bounds__(kThreads, 8) void k_rx_fir(const RxParams P)
-{
-  __shared__ __attribute__((aligned(16))) uint32_t lds[kFirDwords];
-  __shared__ uint32_t red[kWaves + 1];
-  // FM with the arithmetic atan2 (theta_arith, hrfd_rx_kernels.hip): correction bytes and 1/a
-  __shared__ __attribute__((aligned(16))) uint8_t atcorr[(ARITH && MODE != 14) ? kCorrBytes : 16];
-  __shared__ __attribute__((aligned(16))) float atinv[(ARITH && MODE != 14) ? kInvEntries : 4];
-  static_assert(sizeof(uint32_t) * kFirDwords + kCorrBytes + sizeof(float) * kInvEntries + 512 <= 81920,
-                "two workgroups per CU need <= 80 KiB of LDS each");
-  static_assert(kPostLdsDw <= kFirDwords, "the channel's tail runs in the FIR stages' LDS");
-  uint32_t ci, b;
-  if (!map_unit(blockIdx.x, P.n_list, P.n_blocks, ci, b))
-  {
-    return;
-  }
-  const uint32_t c = P.chan_list[ci];
-  const ChanCfg cfg = P.cfg[c];
-  uint32_t arrived;
-  const bool demodulated = fir_unit<MODE, S256, ARITH>(P, c, b, cfg, lds, red, atcorr, atinv, arrived);
-  if (MODE == 14 || !P.self_finish)
-  {
-    return;
-  }
-  const int tid = threadIdx.x;
-  const bool fm = (MODE == 2) || cfg.mode == 2;
-  if (!fm || b + 1 == P.n_blocks || !demodulated)
-  {
-    // not signalled yet -- an AM / SSB block (its last stage's outputs), the call's last block (its pending state went
-    // out at the end), a block that was not demodulated: behind every wave's stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-    {
-      arrived = (P.n_blocks > 1u) ? __hip_atomic_fetch_add(&P.fin.chan_arrived[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-    }
-  }
-  if (tid == 0)
-  {
-    red[kWaves] = arrived;
-  }
-  __syncthreads();
-  if (red[kWaves] != P.n_blocks - 1u)
-  {
-    return;
-  }
-  if (tid == 0 && P.n_blocks > 1u)
-  {
-    __hip_atomic_store(&P.fin.chan_arrived[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero between launches
-  }
-  if (MODE == 15 && !fm)
-  {
-    post_channel<14, kThreads, true>(P, c, lds);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // its stores to the pending state are complete
-    __syncthreads();
-  }
-  if (tid < 64)
-  {
-    finish_channel<-1, true>(P.fin, c, tid);
-  }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kPostThreads) void k_rx_post(const RxParams P)
-{
-  __shared__ __attribute__((aligned(16))) uint32_t lds[kPostLdsDw];
-  if (blockIdx.x >= P.n_list)
-  {
-    return;
-  }
-  const uint32_t c = P.chan_list[blockIdx.x];
-  post_channel<MODE, kPostThreads>(P, c, lds);
-  if (P.self_finish)
-  {
-    // ... and the channel's finisher, behind the tail's stores to the pending state: no kernel behind this one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x < 64)
-    {
-      finish_channel<-1>(P.fin, c, (int)threadIdx.x);
     }
   }
 }
@@ -832,7 +729,5 @@ template __global__ void k_rx_fir<2, true, false>(const RxParams);
 template __global__ void k_rx_post<14>(const RxParams);
 template __global__ void k_rx_fir<14, false, false>(const RxParams);
 template __global__ void k_rx_fir<14, true, false>(const RxParams);
-template __global__ void k_rx_fir<15, false, false>(const RxParams);
-template __global__ void k_rx_fir<15, false, true>(const RxParams);
 
 } // namespace hrfd

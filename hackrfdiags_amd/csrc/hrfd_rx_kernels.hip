@@ -52,39 +52,6 @@ __device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uin
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
-// Data that another workgroup of the SAME launch reads (k_rx_fir<FM>: the workgroup that arrives last at a channel runs
-// the channel's finisher): stores that are written through to memory and loads that do not trust a
-// non-local L2 (gfx950: sc1 -- agent scope; workgroups of one launch run on all eight XCDs, each with an L2 of its
-// own).  With these, "my stores are complete" (s_waitcnt vmcnt(0)) in front of an agent-scope arrival counter is all
-// the hand-over needs; an agent-scope release FENCE instead writes the whole L2 back (buffer_wbl2) -- from every one
-// of thousands of workgroups that made the kernel 2.5x slower and the kernel beside it 1.35x (measured).
-template <typename T>
-__device__ __forceinline__ void st_dev(T *p, T v)
-{
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH, typename T>
-__device__ __forceinline__ void st_sel(T *p, T v)
-{
-  if (COH)
-  {
-    st_dev(p, v);
-  }
-  else
-  {
-    *p = v;
-  }
-}
-template <bool COH, typename T>
-__device__ __forceinline__ T ld_dev(const T *p)
-{
-  if (COH)
-  {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return *p;
-}
-
 // ---- cross-lane neighbours without LDS ------------------------------------------
 // prev(v): lane i <- v[i-1]; lane 0 <- lane 0 of `carry` (v_mov_b32_dpp wave_shr:1,
 // lanes without a source keep the tied `old` operand).
@@ -2021,7 +1988,7 @@ __device__ __forceinline__ void state_section(const int mode, int &off, int &nd)
   else if (mode == 4 || mode == 5) { off = (int)offsetof(ChanState, ssb_tail); nd = ((int)sizeof(ChanState) - off) / 4; }
 }
 
-template <int MODE, bool COH = false>
+template <int MODE>
 __device__ __forceinline__ void finish_gather(const EpilogueParams &E, const uint32_t c, const int lane, FinishIn<MODE> &I)
 {
   const ChanState *dst = E.state + c;
@@ -2037,10 +2004,10 @@ __device__ __forceinline__ void finish_gather(const EpilogueParams &E, const uin
   I.tracking = dst->tracking;
   I.poison = E.chan_poison[c];
   I.expired = E.chan_expired[c];
-  I.pl_raw = ld_dev<COH>(pres + (nb - 1));
-  I.pp_raw = ld_dev<COH>(pres + (nb >= 2 ? nb - 2 : 0));
+  I.pl_raw = pres[nb - 1];
+  I.pp_raw = pres[nb >= 2 ? nb - 2 : 0];
   const bool in0 = (uint32_t)lane < nb;
-  I.pres0 = in0 ? (uint32_t)ld_dev<COH>(pres + lane) : 0u;
+  I.pres0 = in0 ? (uint32_t)pres[lane] : 0u;
   I.spec0 = 0.0f;
   I.pub0 = 0.0f;
   if (in0 && lane > 0 && (MODE < 0 || MODE == 3))
@@ -2048,7 +2015,7 @@ __device__ __forceinline__ void finish_gather(const EpilogueParams &E, const uin
     I.spec0 = E.chk_spec[(size_t)c * nb + lane];
     I.pub0 = E.chk_pub[(size_t)c * nb + lane - 1];
   }
-  I.fe = (lane < 4) ? ld_dev<COH>(reinterpret_cast<const uint32_t *>(src->fe_tail) + lane) : 0u;
+  I.fe = (lane < 4) ? reinterpret_cast<const uint32_t *>(src->fe_tail)[lane] : 0u;
   // ---- round trip 2 (the same one when the mode is known): the mode's section of the pending state
   int off, nd;
   state_section(I.mode, off, nd);
@@ -2056,7 +2023,7 @@ __device__ __forceinline__ void finish_gather(const EpilogueParams &E, const uin
 #pragma unroll
   for (int k = 0; k < FinishIn<MODE>::kSecDw; k++)
   {
-    I.sec[k] = (lane + 64 * k < nd) ? ld_dev<COH>(ssec + (lane + 64 * k)) : 0u;
+    I.sec[k] = (lane + 64 * k < nd) ? ssec[lane + 64 * k] : 0u;
   }
 }
 
@@ -2186,11 +2153,11 @@ __device__ __forceinline__ void finish_apply(const EpilogueParams &E, const uint
   }
 }
 
-template <int MODE = -1, bool COH = false>
+template <int MODE = -1>
 __device__ __forceinline__ void finish_channel(const EpilogueParams &E, const uint32_t c, const int lane)
 {
   FinishIn<MODE> I;
-  finish_gather<MODE, COH>(E, c, lane, I);
+  finish_gather<MODE>(E, c, lane, I);
   finish_apply<MODE>(E, c, lane, I);
 }
 

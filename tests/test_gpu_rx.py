@@ -120,12 +120,12 @@ def test_fir_modes_on_the_flow_kernel(oracle, mode):
         assert rx.debug_counters()[5] == 0, "a launch was not committed"
 
 
-@pytest.mark.parametrize("fir_flow", [-1, 1, 0], ids=["kernels_per_mode", "one_bank_kernel", "block_kernels_beside_the_flow_kernel"])
+@pytest.mark.parametrize("fir_flow", [-1, 1, 0], ids=["kernels_per_mode", "one_bank_kernel", "block_kernels"])
 def test_mixed_mode_bank(oracle, fir_flow):
     """BASELINE config 3 in miniature: AM + FM + WBFM + LSB + USB + NONE channels in
     one handle, two calls.  A bank this small is dispatched per mode by default; the hook forces what a bank of 48
     channels or more gets: ONE launch of k_rx_flow_bank, one persistent workgroup per channel, the mode read per
-    workgroup (mode NONE keeps its own kernel) -- or, with 0, the block kernels of the FIR modes beside the flow kernel."""
+    workgroup (mode NONE keeps its own kernel) -- or, with 0, the block kernels of the FIR modes in front of the flow kernel."""
     modes = [AM, FM, WBFM, LSB, USB, NONE, WBFM, AM, FM, USB]
     C, B = len(modes), 3
     xs = np.stack([synth.make_input("lcg" if c % 2 else "amtone", 60 + c, 2 * B) for c in range(C)])
