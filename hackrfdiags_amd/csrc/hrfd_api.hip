@@ -202,7 +202,7 @@ struct hrfd_rx
   int stagger = 4;
   int run_len = 0;                     // test hook: blocks per workgroup run of k_rx_wbfm (0 = automatic)
   int use_stream = 2;                  // test hook: 0 = WBFM batches on k_rx_wbfm (runs of blocks, phases in sequence) instead of k_rx_wbfm_flow
-  int32_t wbfm_max_threshold = -200;   // the highest squelch threshold among the WBFM channels (can a gate close at all?)
+  int32_t wbfm_max_threshold = -200;   // the highest squelch threshold among the channels with a demodulator (can a gate close at all?)
   int fir_flow = -1;                   // test hook: AM / SSB / FM batches on the flow kernel's FIR modes: -1 when the bank is large enough, 0 never, 1 always
   int gated_pass = 1;                  // test hook: 0 = no gated second pass on the device (closed gates go back to the host's replay)
   int expire_once = 0;                 // test hook: the next k_rx_wbfm_flow launch treats this wait (1..6) of workgroup 0 as expired
@@ -838,7 +838,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
       h->wbfm_max_threshold = INT32_MIN;
       for (uint32_t c = 0; c < h->n_channels; c++)
       {
-        if (h->h_cfg[c].mode == HRFD_MODE_WBFM)
+        if (h->h_cfg[c].mode != HRFD_MODE_NONE)
         {
           h->wbfm_max_threshold = std::max(h->wbfm_max_threshold, h->h_cfg[c].threshold);
         }
@@ -1066,15 +1066,36 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     HIP_TRY(hipGetLastError());
     // Squelch (Squelch.cc:227-273, IqDataProcessor.cc:961-1034).  The detector's lowest level is 0 - 42 - gain_db dBFS
     // (DbfsCalculator.cc:111-147): with a threshold at or below it -- the reference's default is -200 -- no gate of
-    // the bank can ever close and the batch launch is all there is.  Otherwise the gated pass follows: its
-    // workgroups redo the WBFM channels that failed on a closed gate, exactly, and the others leave at once.
-    if ((mode < 0 || mode == HRFD_MODE_WBFM) && n_wb != 0 && h->gated_pass && n_blocks <= 64u && may_close)
+    // the bank can ever close and the batch launch is all there is.  Otherwise the gated pass follows, one launch per
+    // kind: its workgroups redo the channels that failed on a closed gate, exactly, and the others leave at once.
+    if (h->gated_pass && n_blocks <= 64u && may_close)
     {
-      P.chan_list = d_lists + (size_t)HRFD_MODE_WBFM * h->n_channels;
-      P.n_list = n_wb;
       P.run_len = n_blocks;
       P.n_runs = 1;
-      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>), dim3(8u * ((n_wb + 7u) / 8u)), dim3(kThreads), 0, s, P);
+      auto gated = [&](int glist, uint32_t gn, int gmode) {
+        if (gn == 0)
+        {
+          return;
+        }
+        P.chan_list = d_lists + (size_t)glist * h->n_channels;
+        P.n_list = gn;
+        const dim3 gg(8u * ((gn + 7u) / 8u));
+        if (gmode == HRFD_MODE_WBFM)
+        {
+          hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>), gg, dim3(kThreads), 0, s, P);
+        }
+        else if (gmode == HRFD_MODE_FM)
+        {
+          hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false, 2>), gg, dim3(kThreads), 0, s, P);
+        }
+        else
+        {
+          hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false, 14>), gg, dim3(kThreads), 0, s, P);
+        }
+      };
+      if (mode < 0 || mode == HRFD_MODE_WBFM) gated(HRFD_MODE_WBFM, n_wb, HRFD_MODE_WBFM);
+      if (mode < 0 || mode == HRFD_MODE_FM) gated(HRFD_MODE_FM, n_fm, HRFD_MODE_FM);
+      if (mode < 0 || (mode != HRFD_MODE_WBFM && mode != HRFD_MODE_FM && mode >= 0)) gated(7, n_as, HRFD_MODE_AM);
       HIP_TRY(hipGetLastError());
     }
     P.self_finish = 0;

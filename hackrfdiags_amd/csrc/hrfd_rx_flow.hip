@@ -236,7 +236,7 @@ constexpr int kFinWords = 168;
 
 // GATED: the exact second pass over channels whose squelch gate closed inside the batch.  The batch launch (GATED ==
 // false) speculates every gate open; a channel with a closed gate fails ITS verdict (kFailGate, nothing committed) and
-// this variant, launched behind it with one workgroup per WBFM channel, redoes only those channels: the stream of the
+// this variant, launched behind it with one workgroup per channel of its mode, redoes only those channels: the stream of the
 // blocks the tracker ALLOWS (Squelch.cc:227-273: present now or in the block before), from the committed state -- the
 // demodulator does not see the squelched blocks at all (IqDataProcessor.cc:961-1034: acceptIqData is not called, its
 // state is frozen), while the front end runs over everything (a block's 16 bytes of history are its physical
@@ -292,7 +292,7 @@ template <int SVC, bool GATED, bool DUMP, int MODE>
 __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds)
 {
   static_assert(MODE == 3 || MODE == 2 || MODE == 14, "WBFM, FM, AM / SSB");
-  static_assert(MODE == 3 || (!GATED && !DUMP), "the gated pass and the iq dump are WBFM's");
+  static_assert(MODE == 3 || !DUMP, "the iq dump is WBFM's here (the block kernels write it for the FIR modes)");
   typedef FlowLds<MODE> Lds;
   constexpr bool kWb = (MODE == 3);
   constexpr bool kAtan = Lds::kAtan;
@@ -541,7 +541,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
     const uint32_t dead = 0xffff0000u;                   // outside the descriptor: zeros, no memory traffic
     // byte offset of unit u's input.  GATED: the stream is a list of blocks (units are taken in ascending order, so a
     // wave follows the list with a cursor)
-    int cur_bu0 = 0, cur_blk = 0;
+    int cur_bu0 = hal >> 9, cur_blk = 0;                  // (the history unit(s) in front of the stream belong to no block)
     auto unit_off = [&](const int uu) -> uint32_t {
       if (!GATED)
       {
@@ -946,6 +946,16 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
       }
       return __builtin_amdgcn_readfirstlane((int)v);
     };
+    // where PCM pair q / 2 of the stream goes (dword index).  GATED: the stream is a list of blocks
+    auto pcm_at = [&](const uint32_t q) -> uint32_t {
+      if (!GATED)
+      {
+        return q >> 1;
+      }
+      const uint32_t npcm = (uint32_t)n256 >> 5;
+      const uint32_t k = q / npcm;
+      return ((uint32_t)blist[k & 63u] * npcm + (q - k * npcm)) >> 1;
+    };
     auto wait_for = [&](const uint32_t *word, const uint32_t want, const uint32_t where) {
       FlowSpin sp;
       while (lds_ld(word) != want && !sp.expired(P, ctl, fail_code, where))
@@ -1183,7 +1193,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
           }
           if ((uint32_t)pp >= pcm_off)
           {
-            pcm32[((uint32_t)pp - pcm_off) >> 1] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+            pcm32[pcm_at((uint32_t)pp - pcm_off)] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
           }
         }
       }
@@ -1293,7 +1303,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
         if (have && (uint32_t)pp >= pcm_off)
         {
           const float2 yy = *reinterpret_cast<const float2 *>(&ys8k[2 * lane]);
-          pcm32[((uint32_t)pp - pcm_off) >> 1] = ((uint32_t)f2i16(gain8k * yy.x) & 0xffffu) | ((uint32_t)f2i16(gain8k * yy.y) << 16);
+          pcm32[pcm_at((uint32_t)pp - pcm_off)] = ((uint32_t)f2i16(gain8k * yy.x) & 0xffffu) | ((uint32_t)f2i16(gain8k * yy.y) << 16);
         }
       }
       // ---- the carried state for the next call (pending: the finisher commits it)
@@ -1766,6 +1776,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
     {
       lds_st(&ctl[6], 1u);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the FIR modes' pending state went to memory: complete before the count)
     uint32_t prev = 0;
     if (lane == 0)
     {
@@ -1801,9 +1812,21 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
         {
           reinterpret_cast<uint32_t *>(dst->fe_tail)[lane] = lds_ld(&finl[162 + lane]);
         }
-        if (n_stream_blocks != 0u && lane < 30)
+        if (kWb && n_stream_blocks != 0u && lane < 30)
         {
           reinterpret_cast<uint32_t *>(&dst->wb_theta)[lane] = lds_ld(&finl[128 + lane]);
+        }
+        if (!kWb && n_stream_blocks != 0u)
+        {
+          // the mode's section of the pending state, as the service waves left it in memory (written on this CU)
+          int off, nd;
+          state_section(cfg.mode, off, nd);
+          const uint32_t *ssec = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(P.state_out + c) + off);
+          uint32_t *dsec = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(dst) + off);
+          for (int i = lane; i < nd; i += 64)
+          {
+            dsec[i] = ssec[i];
+          }
         }
         if (lane == 0)
         {
@@ -1953,6 +1976,8 @@ template __global__ void k_rx_flow_bank<HRFD_FLOW_SVC>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>(const RxParams);
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false, 2>(const RxParams);
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false, 14>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 2>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 14>(const RxParams);
 

@@ -356,11 +356,12 @@ def test_one_quiet_channel_does_not_stop_the_bank(oracle, run_len):
             assert (got2[c] == pcm2[c]).all(), c
 
 
-@pytest.mark.parametrize("run_len", [0, 16], ids=["several_runs_per_channel", "one_workgroup_per_channel"])
-def test_closed_gates_are_redone_on_the_device(oracle, run_len):
+@pytest.mark.parametrize("mode,run_len", [(WBFM, 0), (WBFM, 16), (AM, 0), (FM, 0), (LSB, 0)],
+                         ids=["wbfm_several_runs_per_channel", "wbfm_one_workgroup_per_channel", "am", "fm", "lsb"])
+def test_closed_gates_are_redone_on_the_device(oracle, mode, run_len):
     """Squelch inside a batch without the host (IqDataProcessor.cc:961-1034, Squelch.cc:227-273, SignalTracker.cc:104-146):
-    the batch launch speculates every gate open; the gated pass behind it (k_rx_wbfm_flow<GATED>) redoes, on the
-    device, the channels whose gates closed -- the stream of the ALLOWED blocks only, from the committed state,
+    the batch launch speculates every gate open; the gated pass behind it (k_rx_wbfm_flow<GATED>, every mode) redoes, on
+    the device, the channels whose gates closed -- the stream of the ALLOWED blocks only, from the committed state,
     squelched blocks zero -- so hrfd_rx_sync reports no failed channel and every output is the oracle's: PCM, n_pcm,
     signal_allowed, magnitude, and the state a second batch continues from (the tracker's tail block included).
     Gate patterns: never open, closing and reopening, open only at the end, the tracker's tail across the call
@@ -377,12 +378,13 @@ def test_closed_gates_are_redone_on_the_device(oracle, run_len):
         for b, ch in enumerate(pat[::-1]):                 # the second batch: the pattern backwards
             if ch == "0":
                 xs[c, B + b] = 0
-    want = [_oracle_stream(oracle, WBFM, xs[c], 2 * B, threshold=-30) for c in range(C)]
+    want = [_oracle_stream(oracle, mode, xs[c], 2 * B, threshold=-30) for c in range(C)]
     dev = torch.device("cuda:0")
     rx = api.Rx(C)
-    rx.set_mode(api.WBFM)
+    rx.set_mode(mode)
     rx.set_threshold(-30)
     rx.debug_set_run_len(run_len)
+    rx.debug_set_fir_flow(1)                                # (AM / FM / SSB: the flow kernel's FIR modes, whatever the bank's size)
     out = torch.full((C, B, 512), 777, dtype=torch.int16, device=dev)
     npcm = torch.zeros((C, B), dtype=torch.int32, device=dev)
     mag = torch.zeros((C, B), dtype=torch.int32, device=dev)
