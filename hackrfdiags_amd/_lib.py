@@ -82,6 +82,7 @@ def load() -> C.CDLL:
     L.hrfd_rx_process_device.argtypes = [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                          _vp, _vp, _vp, _vp, _vp, _vp]
     L.hrfd_rx_sync.argtypes = [_vp, _u32p]
+    L.hrfd_rx_reduce_sample_rate.argtypes = [_vp, _vp, C.c_uint32, _vp]
     L.hrfd_rx_failed_channels.argtypes = [_vp, C.c_void_p, C.c_uint32]
     L.hrfd_rx_debug_set_warm.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_set_atan.argtypes = [_vp, C.c_int]

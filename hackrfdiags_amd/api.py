@@ -69,6 +69,14 @@ class Rx:
               "hrfd_rx_process_block")
         return pcm, n_pcm, mag, allowed, iq256
 
+    def reduce_sample_rate(self, iq: np.ndarray) -> np.ndarray:
+        """IqDataProcessor::reduceSampleRate for one block of every channel: iq int8 [C, block_bytes] -> the 256 kS/s
+        stream int8 [C, block_bytes / 8] (with the Fs/4 rotation); only the decimator pipelines advance"""
+        iq = np.ascontiguousarray(iq, dtype=np.int8).reshape(self.n, -1)
+        out = np.zeros((self.n, iq.shape[1] // 8), dtype=np.int8)
+        check(self.L.hrfd_rx_reduce_sample_rate(self.h, _ptr(iq), iq.shape[1], _ptr(out)), "hrfd_rx_reduce_sample_rate")
+        return out
+
     def process_device(self, d_iq, channel_stride, block_bytes, n_blocks, d_pcm, d_n_pcm=None,
                        d_magnitude=None, d_allowed=None, d_iq256=None, stream=None):
         """All pointers are device addresses (ints); asynchronous."""

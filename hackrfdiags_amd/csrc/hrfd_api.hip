@@ -1461,6 +1461,46 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
   return HRFD_OK;
 }
 
+// IqDataProcessor::reduceSampleRate as a call of its own (IqDataProcessor.cc:429-500: public in the reference): the
+// three half-band stages per rail over one block of every channel, the decimator pipelines advanced, nothing else --
+// no squelch, no demodulator.  Here the front end only exists fused with the Fs/4 mixer and the squelch detector, so a
+// mode-NONE block runs and the squelch tracker's state is put back afterwards; iq256k receives the MIXED stream
+// (upconvertByFsOver4 applied: the caller takes it out again if it wants the reference's decimatedData).
+extern "C" int hrfd_rx_reduce_sample_rate(hrfd_rx *h, const int8_t *iq, uint32_t block_bytes, int8_t *iq256k)
+{
+  if (h == nullptr || iq == nullptr || iq256k == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_reduce_sample_rate: NULL argument");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const uint32_t C = h->n_channels;
+  std::vector<int> modes(C);
+  std::vector<uint32_t> tracking(C), npcm(C);
+  std::vector<int16_t> pcm((size_t)C * (block_bytes / 512 + 1));
+  {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint32_t c = 0; c < C; c++)
+    {
+      modes[c] = h->h_cfg[c].mode;
+      h->h_cfg[c].mode = HRFD_MODE_NONE;
+    }
+    h->cfg_dirty = true;
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy2D(tracking.data(), sizeof(uint32_t), &h->d_state->tracking, sizeof(ChanState), sizeof(uint32_t), C, hipMemcpyDeviceToHost));
+  const int rc = hrfd_rx_process_block(h, iq, block_bytes, 1, 0, pcm.data(), npcm.data(), nullptr, nullptr, iq256k);
+  HIP_TRY(hipMemcpy2D(&h->d_state->tracking, sizeof(ChanState), tracking.data(), sizeof(uint32_t), sizeof(uint32_t), C, hipMemcpyHostToDevice));
+  {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (uint32_t c = 0; c < C; c++)
+    {
+      h->h_cfg[c].mode = modes[c];
+    }
+    h->cfg_dirty = true;
+  }
+  return rc;
+}
+
 // ------------------------------------------------------------------ inner boundary
 // hrfd_demod: n_channels instances of ONE demodulator class, fed with the
 // 256 kS/s, already mixed, int8 IQ stream -- X::acceptIqData(int8_t*,uint32_t).

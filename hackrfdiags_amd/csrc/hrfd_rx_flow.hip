@@ -507,7 +507,8 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
     }
     else if (tid == 512)
     {
-      gctl[2] = 0u;                                       // AM / SSB: generations through their 8 kS/s part
+      gctl[2] = 0u;                                       // AM / SSB: generations through their 8 kS/s recurrence
+      gctl[3] = 0u;                                       // SSB: generations whose 8 kS/s rails are in their rings
       ctl[0] = 1u;                                        // the stream waves start with unit 1
       uflag[0] = 1u;                                      // unit 0, the history, is in the ring
       thfin[0] = thfin[1] = thfin[2] = thfin[3] = 0u;
@@ -925,11 +926,12 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
     //      PCM (FmDemodulator.cc:551-585); AM / SSB: D(12,4) per rail, and the generation is released: the third
     //      decimator D(16,2) needs nothing but V (its own and the last of the generation in front, written by then),
     //      so it runs beside the next generation's part c (the V ring holds four generations for that);
-    //   d. AM / SSB, in order once more (gctl[2]), the 8 kS/s part: the envelope (AM) or the negating delay line, the
-    //      Hilbert transformer and I -/+ Q (SSB), and the dc-removal recurrence y = (x - x1) - a1 y1
+    //      at 8 kS/s the envelope (AM) or the negating delay line, the Hilbert transformer and I -/+ Q (SSB: the rails
+    //      are published in order, gctl[3], nothing else waits);
+    //   d. AM / SSB, in order once more (gctl[2]): the dc-removal recurrence y = (x - x1) - a1 y1
     //      (IirFilter.cc:161-176) SEQUENTIALLY over the generation's 128 samples on one lane, from the y the
     //      generation in front left: exact, nothing to verify -- then gain, (int16_t), PCM (AmDemodulator.cc:434-471,
-    //      SsbDemodulator.cc:563-598).  Only this part is a chain through all generations: ~2 us of 3 per generation.
+    //      SsbDemodulator.cc:563-598).  Only this part is a chain through all generations: ~1.3 us of 3 per generation.
     __builtin_amdgcn_s_setprio(HRFD_FLOW_SVC_PRIO);
     const uint32_t pcm_off = (uint32_t)(hal >> 5);       // PCM samples that the history in front would yield
     uint32_t *pcm32 = reinterpret_cast<uint32_t *>(P.pcm + ((size_t)c * P.out_blocks + P.out_b0 + b_first) * (size_t)(n256 >> 5));
@@ -1223,12 +1225,11 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
             o[r][1] = q15_out(acc1);
           }
         }
-        // ---- d. the 8 kS/s part, generation by generation
-        wait_for(&gctl[2], (uint32_t)g, 4);
-        if (fail_code != 0u)
-        {
-          break;
-        }
+        // the recurrence's input of the lane's two samples.  AM: the envelope.  SSB: the rails at 8 kS/s go to their
+        // rings (the samples in front of sample 0 are the carried ones; generations publish their rails in order,
+        // gctl[3]: the Hilbert transformer reads 30 samples back, into the generation in front), then the negating
+        // delay line (Q15 tap 1.0 narrows to -32768), the 31-tap Hilbert transformer, I -/+ Q
+        float xv[2] = {0.0f, 0.0f};
         if (am)
         {
           // AmDemodulator::demodulateSignal (:447-461): int16 abs, compare, add with wrap
@@ -1236,23 +1237,28 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
             const int im = (int)(short)abs(iv), qm = (int)(short)abs(qv);
             return (im > qm) ? (int)(short)(im + (qm >> 1)) : (int)(short)(qm + (im >> 1));
           };
-          if (have)
-          {
-            *reinterpret_cast<float2 *>(&xs8k[2 * lane]) = make_float2((float)env(o[0][0], o[1][0]), (float)env(o[0][1], o[1][1]));
-          }
+          xv[0] = (float)env(o[0][0], o[1][0]);
+          xv[1] = (float)env(o[0][1], o[1][1]);
         }
         else
         {
-          // SSB: the rails at 8 kS/s (the samples in front of sample 0 are the carried ones), then the negating
-          // delay line (Q15 tap 1.0 narrows to -32768), the 31-tap Hilbert transformer, I -/+ Q
           if (have && pp >= 2 * kHalTiles)
           {
             reinterpret_cast<uint32_t *>(r8k[0])[(pp >> 1) & 255] = ((uint32_t)o[0][0] & 0xffffu) | ((uint32_t)o[0][1] << 16);
             reinterpret_cast<uint32_t *>(r8k[1])[(pp >> 1) & 255] = ((uint32_t)o[1][0] & 0xffffu) | ((uint32_t)o[1][1] << 16);
           }
+          lds_order();
+          wait_for(&gctl[3], (uint32_t)g, 4);
+          if (fail_code != 0u)
+          {
+            break;
+          }
+          if (lane == 0)
+          {
+            lds_st(&gctl[3], (uint32_t)g + 1u);
+          }
           if (have)
           {
-            float xv[2];
 #pragma unroll
             for (int e = 0; e < 2; e++)
             {
@@ -1267,8 +1273,17 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
               const int qh = q15_out(acc);
               xv[e] = (float)(cfg.lsb ? (idel - qh) : (idel + qh));
             }
-            *reinterpret_cast<float2 *>(&xs8k[2 * lane]) = make_float2(xv[0], xv[1]);
           }
+        }
+        // ---- d. the recurrence, generation by generation
+        wait_for(&gctl[2], (uint32_t)g, 4);
+        if (fail_code != 0u)
+        {
+          break;
+        }
+        if (have)
+        {
+          *reinterpret_cast<float2 *>(&xs8k[2 * lane]) = make_float2(xv[0], xv[1]);
         }
         // the dc-removal recurrence over the generation's samples, one lane, groups of eight with the next group's
         // inputs in flight (the chain per step is the multiply and the subtract)

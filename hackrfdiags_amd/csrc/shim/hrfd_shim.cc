@@ -308,23 +308,14 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
 
 // Public in the reference (IqDataProcessor.cc:429-500): the three half-band stages per rail over one buffer,
 // result in the private decimatedData, decimator pipelines advanced, NO Fs/4 mix (acceptIqData applies that
-// separately).  Here the front end only exists fused with the mixer, so a mode-NONE block runs (front-end history
-// advanced like the reference's pipelines) and the mix is taken out of decimatedData again -- the int8 rotation is
-// exactly invertible, -(-128) wraps to -128 both ways.  One deviation: the squelch detector and tracker also see
-// this block (the reference's reduceSampleRate does not touch them); the application never calls this directly.
+// separately), squelch and demodulators untouched.  hrfd_rx_reduce_sample_rate does that on the device, where the
+// front end only exists fused with the mixer: the mix is taken out of decimatedData again -- the int8 rotation is
+// exactly invertible, -(-128) wraps to -128 both ways.
 uint32_t IqDataProcessor::reduceSampleRate(int8_t *bufferPtr,uint32_t bufferLength)
 {
-  uint32_t sampleCount = 0;
   ensureHandle();
-  int rc = hrfd_rx_set_mode(handle, 0, HRFD_MODE_NONE);
-  if (rc == HRFD_OK)
-  {
-    rc = hrfd_rx_process_block(handle, bufferPtr, bufferLength, 1, radio_adjustableReceiveGainInDb,
-                               pcmData, &sampleCount, NULL, NULL, decimatedData);
-  }
+  const int rc = hrfd_rx_reduce_sample_rate(handle, bufferPtr, bufferLength, decimatedData);
   if (rc != HRFD_OK) fatal("reduceSampleRate", rc);
-  rc = hrfd_rx_set_mode(handle, 0, (int)demodulatorMode);
-  if (rc != HRFD_OK) fatal("hrfd_rx_set_mode", rc);
   downconvertByFsOver4(decimatedData, bufferLength / 8);
   return bufferLength / 8;
 }

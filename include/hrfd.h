@@ -101,14 +101,22 @@ int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t block_bytes,
                           uint32_t *n_pcm, uint32_t *magnitude,
                           uint8_t *signal_allowed, int8_t *iq256k_opt);
 
+/* IqDataProcessor::reduceSampleRate (IqDataProcessor.cc:429-500; public in the reference, not called by the
+ * application): one block of every channel through the three half-band stages only -- the decimator pipelines advance,
+ * the squelch and the demodulators are left alone.  iq [n_channels][block_bytes]; iq256k [n_channels][block_bytes/8]
+ * receives the stream WITH the Fs/4 rotation (the front end is fused with the mixer here; the rotation is exactly
+ * invertible, the shim class takes it out again). */
+int hrfd_rx_reduce_sample_rate(hrfd_rx *h, const int8_t *iq, uint32_t block_bytes, int8_t *iq256k);
+
 /* Same work with every buffer already resident in device memory (HBM); this is
  * the entry the batched benchmark drives.  d_iq is [n_channels][n_blocks]
  * [block_bytes] with channel_stride bytes between channels.  Asynchronous on
  * `stream` (a hipStream_t, NULL = the handle's own stream).  Optional outputs
- * may be NULL.  When n_blocks > 1 the blocks of one channel are demodulated
- * concurrently: the call speculates that every squelch gate in the batch is
- * open and that the WBFM de-emphasis tiles re-synchronise; both
- * assumptions are verified on the device and hrfd_rx_sync() reports them.
+ * may be NULL.  When n_blocks > 1 the call is one continuous stream per channel (or, for small banks and odd block
+ * sizes, blocks demodulated concurrently): it speculates that every squelch gate in the batch is open and that the
+ * WBFM de-emphasis tiles re-synchronise; both assumptions are verified on the device.  A gate that closes
+ * inside the batch is repaired on the device as well: a gated pass behind the batch launch redoes the channels
+ * concerned exactly (the stream of the blocks the squelch tracker allows).  hrfd_rx_sync() reports what is left.
  * Stream ordering is the caller's: the handle's own stream is non-blocking, so buffers that
  * were filled or cleared on another stream (e.g. a framework's default stream) must be
  * complete -- or `stream` must be that stream -- before this call.
@@ -119,14 +127,13 @@ int hrfd_rx_process_device(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stri
                            uint8_t *d_signal_allowed, int8_t *d_iq256k_opt,
                            void *stream);
 /* Waits for the last hrfd_rx_process_device call.  *n_violations (may be NULL)
- * receives the number of CHANNELS whose speculation failed in that call or that
- * ran behind an unrepaired failure of their own (0 = every output is exact).  The
- * verdict is per channel: a channel that verified clean has advanced its state and
+ * receives the number of CHANNELS that did not commit in that call (0 = every output is exact and every state
+ * advanced).  The verdict is per channel: a channel that verified clean has advanced its state and
  * its outputs are exact; a failed channel has NOT advanced and the caller should
  * resubmit that channel one block per call (n_blocks == 1 is always exact) --
  * hrfd_rx_failed_channels says which, hrfd_rx_process_block does all of this by
- * itself.  With a real squelch threshold a quiet channel fails every batch it is in
- * (its gate closes) and costs its own replay only. */
+ * itself.  Closed squelch gates are not failures (the device repairs them, see above) unless the batch has more
+ * than 64 blocks or runs on the block kernels (small banks, odd block sizes, FIR modes with the iq dump). */
 int hrfd_rx_sync(hrfd_rx *h, uint32_t *n_violations);
 /* out[c] != 0 for the channels of that call that did not commit (n = n_channels). */
 int hrfd_rx_failed_channels(hrfd_rx *h, uint8_t *out, uint32_t n);

@@ -186,6 +186,37 @@ def test_mixed_bank_with_closed_gates(oracle, fir_flow):
             assert (r[0][c, b % B, :len(p)] == p).all() and (r[0][c, b % B, len(p):] == 0).all(), (c, m, b)
 
 
+def test_reduce_sample_rate_advances_the_front_end_only(oracle):
+    """IqDataProcessor::reduceSampleRate (IqDataProcessor.cc:429-500) as a call of its own: the 256 kS/s stream of the
+    block comes back, the half-band pipelines advance, and neither the squelch tracker nor a demodulator sees the block.
+    Sequence: a loud block (the tracker goes to Tracking), a SILENT block through reduceSampleRate only (a squelch run
+    would drop the tracker), another silent block through acceptIqData: it must still pass as the tracker's tail block."""
+    loud = synth.make_input("fmtone", 3, 1).reshape(BLK)
+    x = synth.make_input("lcg", 4, 1).reshape(BLK) // 64         # noise of +-1: below -30 dBFS
+    y = synth.make_input("lcg", 5, 1).reshape(BLK) // 64
+    rx = api.Rx(1)
+    rx.set_mode(api.WBFM)
+    rx.set_threshold(-30)
+    o = oracle.rx()
+    o.set_mode(WBFM)
+    o.set_threshold(-30)
+    a = rx.process_block(loud.reshape(1, 1, BLK), 1)
+    wa = o.process(loud)
+    assert (a[0][0, 0] == wa[0]).all()
+    got = rx.reduce_sample_rate(x.reshape(1, BLK))
+    # the oracle has no such entry: the same effect is a mode-NONE block whose squelch leaves the tracker alone
+    o.set_mode(NONE)
+    o.set_threshold(-200)
+    wx = o.process(x)
+    assert (got[0] == wx[3]).all()
+    o.set_mode(WBFM)
+    o.set_threshold(-30)
+    b = rx.process_block(y.reshape(1, 1, BLK), 1)
+    wb = o.process(y)
+    assert wb[2] and len(wb[0]) == 512, "the oracle passes the tail block"
+    assert b[1][0, 0] == 512 and bool(b[3][0, 0]) and (b[0][0, 0] == wb[0]).all()
+
+
 def test_mode_switch_keeps_each_demodulators_state(oracle):
     x = synth.make_input("lcg", 5, 6).reshape(1, 6, BLK)
     rx = api.Rx(1)
