@@ -725,8 +725,15 @@ def main():
                                     f"PMC summary is of kernel sources {ptag}, this run is {kernel_source_tag()}: not reported")),
                 "measured_stream_copy_GBps": round(copy_gbs, 1),
                 "frac_of_measured_copy": round(achieved / copy_gbs, 4),
-                "kernel": ("hrfd::k_rx_wbfm_flow<4> (one persistent workgroup per CU, LDS ring, first-octant-table atan2)"
-                           if args.workload == "wbfm" else "all demodulator kernels of a step: first kernel's start to the later of the two streams' last kernel end (HIP events on both)"),
+                "kernel": ("hrfd::k_rx_wbfm_flow<4, GATED=false, DUMP=%s, WBFM> (one persistent workgroup per CU, LDS ring, "
+                           "first-octant-table atan2)%s" % ("true" if args.iqdump else "false",
+                                                            ", the gated pass behind it" if args.quiet_fraction > 0 else "")
+                           if args.workload == "wbfm" else
+                           "hrfd::k_rx_flow_bank<4> (a bank of several modes as one launch, the mode read per workgroup)"
+                           if args.workload == "mixed" and not args.serial_modes else
+                           "the demodulator kernels of a step (hrfd::k_rx_wbfm_flow<4, .., MODE> per mode; with --serial-modes "
+                           "the block kernels k_rx_fir / k_rx_post / k_rx_finish): first kernel's start to last kernel's end, "
+                           "HIP events on the launch stream"),
                 "kernel_ms_mean": round(r["mean_ms"], 4),
                 "kernel_ms_min": round(r["kernel_ms_min"], 4),
                 "kernel_ms_median": round(r["kernel_ms_median"], 4),

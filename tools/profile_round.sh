@@ -4,7 +4,7 @@
 # "rocprofv3 PMC slots").  The PMC summary carries the tag of the kernel sources it was taken with
 # (bench.kernel_source_tag), so that bench.py reports it only for the code it measured.
 # usage: tools/profile_round.sh <tag> [all]
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
@@ -33,6 +33,11 @@ if [ "$2" = "all" ]; then
   stats mixed --steps 100 --warmup 50 --workload mixed
   stats ssbmod1024 --steps 100 --warmup 50 --workload ssbmod
   stats wbfmmod1024 --steps 20 --warmup 10 --workload wbfmmod
+  stats wbfm256x16_quiet25 --steps 100 --warmup 50 --quiet-fraction 0.25 --threshold -30
+  stats wbfm256x16_iqdump --steps 100 --warmup 50 --iqdump
+  stats am256x16 --steps 100 --warmup 50 --workload am
+  stats fm256x16 --steps 100 --warmup 50 --workload fm
+  stats ssb256x16 --steps 100 --warmup 50 --workload ssb
 fi
 for CNT in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc_$CNT -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extras > /dev/null 2> $O/pmc_$CNT.log
