@@ -1990,10 +1990,9 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     const size_t samples = (size_t)n_per_channel * h->n_channels;
     const size_t s32 = samples * 32;
     int rc;
-    if (samples * 4 > h->cap_rails || s32 * 4 > h->cap_wb)
+    if (s32 * 4 > h->cap_wb)
     {
       HIP_TRY(hipStreamSynchronize(s));
-      if ((rc = grow((void **)&h->d_rails, &h->cap_rails, samples * 4)) != HRFD_OK) return rc;
       if ((rc = grow((void **)&h->d_wb, &h->cap_wb, s32 * 4)) != HRFD_OK) return rc;
     }
     // (Cutting the bank into groups of channels on streams of their own buys nothing: the recurrence's time does not
@@ -2012,7 +2011,6 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     B.wbtail_out = h->d_wbtail[h->cur ^ 1];
     B.n = n_per_channel;
     B.n_channels = h->n_channels;
-    hipLaunchKernelGGL(k_wb_pairs, dim3((uint32_t)((samples + 255) / 256)), dim3(256), 0, s, B);
     // The passes run in TIME SLICES of whole blocks (512 PCM samples), on three streams: the x32 cascade with the Nco
     // steps (k_mod<WB_HEAD>) on the caller's, the phase recurrence -- serial per channel, the same 17 ns per step for
     // 64 channels as for 4096, two thirds of the call -- on one of the handle's, the table lookup and the x8 cascade
@@ -2023,40 +2021,46 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     // tail), long ones between (every slice costs the recurrence a launch: ~12 us)
     std::vector<uint32_t> cuts;
     {
-      const uint32_t q = 256 / kModTile * kModTile > 0 ? 256 / kModTile * kModTile : kModTile;   // quarter of a block
+      // Lengths in tiles of the cascade (64 input samples).  The recurrence takes ~0.54 us per input sample, a head
+      // pass ~0.1, rails and tail together ~0.25 (on the CUs the recurrence leaves them) plus ~30 us of launches:
+      // slices may grow fourfold at the start (the next head pass is through before the recurrence of the slice in
+      // front is) and halve at the end (a slice's rails and tail are through before the next, shorter recurrence is);
+      // what stays exposed is the first slice's head pass and the last slice's rails and tail, so those two slices
+      // are two tiles long.  Every slice costs the recurrence a launch (~20 us).
+      static_assert(kModTile == 64, "slice lengths below are in tiles of 64 samples");
+      const uint32_t nt = (n_per_channel + kModTile - 1) / kModTile;
+      std::vector<uint32_t> lens;
+      if (nt > 24)
+      {
+        const uint32_t head[2] = {2, 8};
+        const uint32_t tail4[4] = {16, 8, 4, 2}, tail2[2] = {4, 2};
+        const bool long_tail = nt >= 72;
+        const uint32_t n_tail = long_tail ? 4u : 2u;
+        const uint32_t *tail = long_tail ? tail4 : tail2;
+        uint32_t mid = nt - 10u - (long_tail ? 30u : 6u);
+        lens.assign(head, head + 2);
+        const uint32_t room = (uint32_t)hrfd_mod::kMaxSlices - 2u - n_tail - 1u;
+        const uint32_t piece = std::max(32u, (mid + room - 1u) / room);
+        while (mid != 0u)
+        {
+          const uint32_t k = (mid + piece - 1u) / piece;        // pieces still to go: even shares
+          const uint32_t len = (mid + k - 1u) / k;
+          lens.push_back(len);
+          mid -= len;
+        }
+        lens.insert(lens.end(), tail, tail + n_tail);
+      }
       uint32_t lo = 0;
-      const uint32_t n = n_per_channel;
-      auto push = [&](uint32_t len) {
-        if (len != 0 && cuts.size() + 1 < (size_t)hrfd_mod::kMaxSlices)
-        {
-          lo += len;
-          cuts.push_back(lo);
-        }
-      };
-      if (n > 6 * q)
+      for (size_t k = 0; k + 1 < lens.size(); k++)
       {
-        push(2 * q);
-        while (n - lo > 2 * q + 8 * q)
-        {
-          push(8 * q);
-        }
-        if (n - lo > 2 * q)
-        {
-          push((n - lo - 2 * q + kModTile - 1) / kModTile * kModTile);
-        }
-        if (n - lo > q)
-        {
-          push(q);
-        }
+        lo += lens[k] * kModTile;
+        cuts.push_back(lo);
       }
-      if (lo < n)
-      {
-        cuts.push_back(n);
-      }
+      cuts.push_back(n_per_channel);                          // (the last slice ends with the call, whole tile or not)
     }
     // (only when the recurrence has CUs of its own: beside other kernels on its CUs it loses more than the overlap gains)
     const bool sliced = h->sliced != 0 && cuts.size() > 1 && h->s_scan != nullptr && (h->cu_masked || h->sliced > 1);
-    M.in = h->d_rails;
+    M.in = d_pcm;                                             // (k_mod<WB_HEAD> reads the PCM itself)
     M.wbstep = h->d_wb;
     M.param = h->d_param;
     if (!sliced)
@@ -2094,14 +2098,23 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
       {
         const uint32_t lo = (k == 0) ? 0u : cuts[k - 1], len = cuts[k] - lo;
         const uint32_t tl = (len + kModTile - 1) / kModTile;
-        HIP_TRY(hipStreamWaitEvent(h->s_scan, h->ev_head[k], 0));
+        // (the head passes are through long before the fourth recurrence starts: it waits for the last of them, the
+        // ones behind it for nothing -- every wait is a packet the queue takes microseconds over)
+        if (k < 3)
+        {
+          HIP_TRY(hipStreamWaitEvent(h->s_scan, h->ev_head[k], 0));
+        }
+        else if (k == 3)
+        {
+          HIP_TRY(hipStreamWaitEvent(h->s_scan, h->ev_head[cuts.size() - 1], 0));
+        }
         phase_scan(h, h->d_wb + (size_t)lo * 32, (size_t)len * 32, (size_t)n_per_channel * 32, h->d_acc, h->n_channels, h->s_scan);
         HIP_TRY(hipEventRecord(h->ev_scan[k], h->s_scan));
         HIP_TRY(hipStreamWaitEvent(h->s_tail, h->ev_scan[k], 0));
         B.lo = lo;
         B.len = len;
         const size_t q = (size_t)len * 32 / 4 * h->n_channels;
-        hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(256, (q + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, h->s_tail, B);
+        hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(384, (q + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, h->s_tail, B);
         T.tile0 = lo / kModTile;
         T.tiles_launch = tl;
         hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(h->n_channels * tl), dim3(kModThreads), 0, h->s_tail, T);

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   // k_am_rails / k_fm_rails) runs them through the modulators' stage-1 table, INTERP through
   // interpolateSignal's own
   constexpr bool kPairs = (KIND == HRFD_MOD_INTERP) || (KIND == HRFD_MOD_RAILS) || (KIND == HRFD_MOD_WB_HEAD);
+  constexpr bool kMono = (KIND == HRFD_MOD_WB_HEAD);      // the input is the PCM itself, [C][n]: rail 0, rail 1 is zero (WbFmModulator.cc:389-425)
   const uint32_t tiles = (M.n + kModTile - 1) / kModTile;
   const uint32_t tiles_l = (M.tiles_launch != 0u) ? M.tiles_launch : tiles;
   const uint32_t c = blockIdx.x / tiles_l;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   }
   else
   {
-    const int16_t *in = M.in + (size_t)c * M.n * (kPairs ? 2 : 1);
+    const int16_t *in = M.in + (size_t)c * M.n * ((kPairs && !kMono) ? 2 : 1);
     const int16_t *tin = M.tail_in + (size_t)c * 4 * kModTail;
 
     // ---- stage-0 source: scaled PCM (SSB) or the IQ pair (INTERP), history first
@@ -192,7 +193,11 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       }
       else if (g < n)
       {
-        if (kPairs)
+        if (kMono)
+        {
+          a = in[g];
+        }
+        else if (kPairs)
         {
           a = in[2 * g];
           b = in[2 * g + 1];
@@ -221,6 +226,10 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
           const int o = kModTail + g;                       // still inside the old tail
           a = tin[o];
           b = tin[kModTail + o];
+        }
+        else if (kMono)
+        {
+          a = in[g];
         }
         else if (kPairs)
         {
@@ -946,16 +955,6 @@ __global__ void k_fm_rails(const BaseParams B)
 }
 
 // ---- WBFM modulator (WbFmModulator.cc:341-356) between the two halves of the cascade --------
-// (pcm, 0) pairs for k_mod<WB_HEAD>
-__global__ void k_wb_pairs(const BaseParams B)
-{
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (size_t)B.n * B.n_channels)
-  {
-    reinterpret_cast<uint32_t *>(B.rails)[t] = (uint32_t)(uint16_t)B.pcm[t];
-  }
-}
-
 // per sample, in parallel: Nco::runFast (Nco.cc:222-257) on the stored phase, x900, (int16_t):
 // phase -> (I,Q) rail pair in place; the call's last two pairs are kept for the next call.
 // The two float tables, x900 and narrowed, are one table of 16384 rail pairs (B.wbpack, built by the host with the
