@@ -31,6 +31,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps a process's streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4) plus one per stream with a
+# CU mask (the WBFM modulator holds two).  With six or more queues alive the cross-queue event hops of the sliced WBFM
+# modulator take ~50 us instead of ~10 (measured: 5.2 ms per step against 4.7 in the same process);
+# nothing here needs more than two.  Read by the runtime when it starts, reported in the line as `runtime`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -234,7 +239,9 @@ def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle,
     mean_ms = float(np.mean(kernel_ms))
     achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
     fill = stream_fill_gbs(device, out) if (rank == 0 and extras) else None
+    m.close()
     del out, pcm
+    torch.cuda.empty_cache()                             # the next workload of the line starts from a clean allocator
     return {
         "kname": kname, "value": world * samples * steps / elapsed / 1e6, "ms_per_step": 1e3 * elapsed / steps,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -553,6 +560,7 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
     }
     rx.close()
     del iq, pcm, n_pcm, iq256, iq_root
+    torch.cuda.empty_cache()                             # the next workload of the line starts from a clean allocator
     return out
 
 
@@ -742,6 +750,7 @@ def main():
             "verification": {"uncommitted_launches": counters[5], "tiles_repaired_in_place": counters[4],
                              "launches": counters[6]},
             "kernel_source_tag": kernel_source_tag(),
+            "runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         }
         if counters[5] != 0:
             # a launch that did not commit means later launches started from a stale state and the batch path was

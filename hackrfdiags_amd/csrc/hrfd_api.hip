@@ -1652,7 +1652,7 @@ struct hrfd_mod
   uint32_t *d_err = nullptr;            // k_phase_scan: waits that expired (never, unless the kernel is broken)
   // WBFM: the call's passes run in time slices on three streams (hrfd_mod_process_device)
   static constexpr int kMaxSlices = 32;
-  hipStream_t s_scan = nullptr, s_tail = nullptr, s_head = nullptr;
+  hipStream_t s_scan = nullptr, s_tail = nullptr;  // the recurrence's stream; the stream of every other pass of a sliced call
   bool cu_masked = false;               // the recurrence's stream has CUs of its own
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_head[kMaxSlices] = {}, ev_scan[kMaxSlices] = {};
   int sliced = 1;                        // test hook: 0 = one pass after the other on the caller's stream
@@ -1695,7 +1695,7 @@ static int mod_free(hrfd_mod *h)
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (hipStream_t st : {h->s_scan, h->s_tail, h->s_head})
+  for (hipStream_t st : {h->s_scan, h->s_tail})
   {
     if (st)
     {
@@ -1810,14 +1810,12 @@ extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_m
         {
           (i < want ? scan_mask : rest_mask)[i / 32] |= 1u << (i % 32);
         }
-        hipStream_t a = nullptr, b = nullptr, c = nullptr;
+        hipStream_t a = nullptr, b = nullptr;
         if (hipExtStreamCreateWithCUMask(&a, words, scan_mask.data()) == hipSuccess &&
-            hipExtStreamCreateWithCUMask(&b, words, rest_mask.data()) == hipSuccess &&
-            hipExtStreamCreateWithCUMask(&c, words, rest_mask.data()) == hipSuccess)
+            hipExtStreamCreateWithCUMask(&b, words, rest_mask.data()) == hipSuccess)
         {
           h->s_scan = a;
           h->s_tail = b;
-          h->s_head = c;
           masked = true;
         }
         else
@@ -1825,14 +1823,12 @@ extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_m
           (void)hipGetLastError();
           if (a) (void)hipStreamDestroy(a);
           if (b) (void)hipStreamDestroy(b);
-          if (c) (void)hipStreamDestroy(c);
         }
       }
       if (!masked)
       {
         e = hipStreamCreateWithFlags(&h->s_scan, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s_tail, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->s_head, hipStreamNonBlocking);
       }
       h->cu_masked = masked;
     }
@@ -2074,15 +2070,16 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     }
     else
     {
-      // Three streams of the handle's own, created one after the other (different hardware queues; the caller's
-      // stream may share its hardware queue with any one stream -- when it carried kernels, the next slice's head
-      // queued up behind the previous slice's tail: measured, everything in series).  The caller's stream only
-      // forks and joins.  The head passes of all slices go out first: they depend on nothing but the input.
-      hipStream_t hs = h->s_head;
+      // Two streams of the handle's own: the recurrences on one (with CUs of its own), every other pass on the second.
+      // The caller's stream only forks and joins (it may share its hardware queue with either: when it carried
+      // kernels, everything ran in series).  The head passes of all slices go out first -- they depend on nothing but
+      // the input -- and the rails and tails of the first slices queue up behind them: those have a millisecond of
+      // slack, and every stream with a CU mask is a hardware queue of its own, of which a process should hold few
+      // (measured: the same call takes 4.7 ms in a process with five queues and 5.2 with seven).
+      hipStream_t hs = h->s_tail;
       HIP_TRY(hipEventRecord(h->ev_fork, s));
       HIP_TRY(hipStreamWaitEvent(hs, h->ev_fork, 0));
       HIP_TRY(hipStreamWaitEvent(h->s_scan, h->ev_fork, 0));
-      HIP_TRY(hipStreamWaitEvent(h->s_tail, h->ev_fork, 0));
       ModParams T = M;
       T.in = reinterpret_cast<const int16_t *>(h->d_wb);
       T.wbtail = h->d_wbtail[h->cur];

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/tl_any
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu --no-extras "$@" > $O/bench.json 2> $O/log.txt
+rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --steps 10 --warmup 5 --no-cpu ${HRFD_TL_EXTRAS:---no-extras} "$@" > $O/bench.json 2> $O/log.txt
 python3 - "$O" "$PER" <<'PY'
 import csv, glob, sys
 rows = []
