@@ -1979,7 +1979,8 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
   M.tile0 = 0;
   M.tiles_launch = 0;
   const uint32_t tiles = (n_per_channel + kModTile - 1) / kModTile;
-  const uint32_t grid = h->n_channels * tiles;
+  const uint32_t groups8 = 8u * ((h->n_channels + 7u) / 8u);     // k_mod deals channels to XCDs: whole groups of eight
+  const uint32_t grid = groups8 * tiles;
   if (h->kind == HRFD_MOD_WBFM)
   {
     // WbFmModulator::acceptData (WbFmModulator.cc:341-356): x32 on the PCM, the 256 kS/s Nco, x8
@@ -2088,7 +2089,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
         const uint32_t lo = (k == 0) ? 0u : cuts[k - 1], len = cuts[k] - lo;
         M.tile0 = lo / kModTile;
         M.tiles_launch = (len + kModTile - 1) / kModTile;
-        hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_HEAD>, dim3(h->n_channels * M.tiles_launch), dim3(kModThreads), 0, hs, M);
+        hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_HEAD>, dim3(groups8 * M.tiles_launch), dim3(kModThreads), 0, hs, M);
         HIP_TRY(hipEventRecord(h->ev_head[k], hs));
       }
       for (size_t k = 0; k < cuts.size(); k++)
@@ -2114,7 +2115,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
         hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(384, (q + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, h->s_tail, B);
         T.tile0 = lo / kModTile;
         T.tiles_launch = tl;
-        hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(h->n_channels * tl), dim3(kModThreads), 0, h->s_tail, T);
+        hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(groups8 * tl), dim3(kModThreads), 0, h->s_tail, T);
       }
       HIP_TRY(hipEventRecord(h->ev_join, h->s_tail));
       HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));

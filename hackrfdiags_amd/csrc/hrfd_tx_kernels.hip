@@ -34,6 +34,9 @@ constexpr int HRFD_MOD_WB_TAIL = 102;   // WBFM modulator: 256 kS/s (I,Q) rails 
 #ifndef HRFD_MOD_TILE
 #define HRFD_MOD_TILE 64
 #endif
+#ifndef HRFD_MOD_ABLATE
+#define HRFD_MOD_ABLATE 0
+#endif
 constexpr int kModTile = HRFD_MOD_TILE;  // input samples per workgroup
 constexpr int kModThreads = 256;
 constexpr int kModTail = 64;            // carried input history per channel (>= 54)
@@ -88,6 +91,25 @@ __device__ __forceinline__ void hb8(int a, int b, int c, int d, int &y0, int &y1
   y1 = (b + 1) >> 1;
 }
 
+// Two consecutive positions n (even) and n + 1 of that stage from three aligned dwords of its input,
+// d0 = (x[n-4], x[n-3]), d1 = (x[n-2], x[n-1]), d2 = (x[n], x[n+1]): the outputs of n and of n + 1 as two packed
+// pairs.  Phase 0 is h x[n-3] + g x[n-2] + g x[n-1] + h x[n]: two v_dot2_i32_i16 on sample pairs (v_alignbit shifts
+// the pairs of the even position into place) instead of two sums and two multiplies in int32 -- for which the
+// compiler chose a quarter-rate v_mul_lo_u32 where the tap is negative.
+__device__ __forceinline__ void hb8_pair(const uint32_t d0, const uint32_t d1, const uint32_t d2, uint32_t &o0, uint32_t &o1)
+{
+  constexpr uint32_t h = (uint16_t)Q_INTERP_HB8[0], g = (uint16_t)Q_INTERP_HB8[2];
+  constexpr uint32_t kHG = h | (g << 16), kGH = g | (h << 16);
+  const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, 16);   // (x[n-3], x[n-2])
+  const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, 16);   // (x[n-1], x[n])
+  const int a0 = dot2(hi, kGH, dot2(lo, kHG, 1 << 14));
+  const int a1 = dot2(d2, kGH, dot2(d1, kHG, 1 << 14));
+  const int y1 = (((int)d1 >> 16) + 1) >> 1;                   // (x[n-1] + 1) >> 1
+  const int y3 = ((int)(int16_t)d2 + 1) >> 1;                  // (x[n] + 1) >> 1
+  o0 = ((uint32_t)(a0 >> 15) & 0xffffu) | ((uint32_t)y1 << 16);
+  o1 = ((uint32_t)(a1 >> 15) & 0xffffu) | ((uint32_t)y3 << 16);
+}
+
 // x2 stage with a 4-tap prototype {h, 16384, h, 0}: phase 0 = h (x[n] + x[n-1]), phase 1 = (x[n] + 1) >> 1
 template <int H>
 __device__ __forceinline__ void hb4(int xn, int xm1, int &y0, int &y1)
@@ -130,11 +152,32 @@ __device__ __forceinline__ float div_then_float(const double p, const double d, 
   return risky ? (float)(p / d) : (float)q;
 }
 
+// The items 0 .. LIMIT-1 of a pass dealt to the workgroup's threads: the whole rounds run without a predicate (their
+// count is a constant: a loop "t = tid; t < LIMIT; t += threads" makes the compiler carry a per-lane trip count, an
+// exec mask and a dozen instructions of loop control per round), the ragged last round under one compare.
+template <int LIMIT, typename F>
+__device__ __forceinline__ void wg_loop(const int tid, F &&body)
+{
+  constexpr int kWhole = LIMIT / kModThreads;
+#pragma unroll
+  for (int k = 0; k < kWhole; k++)
+  {
+    body(tid + k * kModThreads);
+  }
+  if constexpr (LIMIT % kModThreads != 0)
+  {
+    if (tid < LIMIT % kModThreads)
+    {
+      body(tid + kWhole * kModThreads);
+    }
+  }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 {
   __shared__ int16_t src[2][kModTail + kModTile];         // stage-0 source with history
-  __shared__ int16_t r[2][kRail];                         // the two rails, stages 0..5
+  __shared__ __attribute__((aligned(16))) int16_t r[2][kRail];   // the two rails, stages 0..5
 
   // INTERP and RAILS take int16 (I,Q) pairs; RAILS (the AM / FM modulators' baseband, produced by
   // k_am_rails / k_fm_rails) runs them through the modulators' stage-1 table, INTERP through
@@ -143,8 +186,13 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   constexpr bool kMono = (KIND == HRFD_MOD_WB_HEAD);      // the input is the PCM itself, [C][n]: rail 0, rail 1 is zero (WbFmModulator.cc:389-425)
   const uint32_t tiles = (M.n + kModTile - 1) / kModTile;
   const uint32_t tiles_l = (M.tiles_launch != 0u) ? M.tiles_launch : tiles;
-  const uint32_t c = blockIdx.x / tiles_l;
-  const uint32_t tile = M.tile0 + (blockIdx.x - c * tiles_l);
+  // Workgroup ids go round the eight XCDs, each with an L2 of its own: XCD x takes the channels x, x + 8, ... and a
+  // channel's tiles one after the other, so that what an L2 writes back is one contiguous stream (32 KiB per
+  // workgroup, consecutive workgroups of the XCD adjacent).  Measured on a pure store stream of this shape
+  // (tools/ubench/store_shapes.hip): 5.75 TB/s with consecutive chunks going round the XCDs, 6.3-6.4 this way.
+  const uint32_t xcd = blockIdx.x & 7u, bi = blockIdx.x >> 3;
+  const uint32_t c = 8u * (bi / tiles_l) + xcd;
+  const uint32_t tile = M.tile0 + (bi % tiles_l);
   if (c >= M.n_channels || tile >= tiles)
   {
     return;
@@ -159,7 +207,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
     // previous call's last two pairs
     const uint32_t *rin = reinterpret_cast<const uint32_t *>(M.in) + (size_t)c * M.n * 32;
     const int n32 = (int)M.n * 32;
-    for (int t = tid; t < kH5 + 32 * kModTile; t += kModThreads)
+    wg_loop<kH5 + 32 * kModTile>(tid, [&](const int t)
     {
       const int g = 32 * t0 + t - kH5;
       uint32_t w = 0u;
@@ -173,16 +221,16 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       }
       r[0][kO5 + t] = (int16_t)(w & 0xffffu);
       r[1][kO5 + t] = (int16_t)(w >> 16);
-    }
+    });
     __syncthreads();
   }
-  else
+  else if (!(HRFD_MOD_ABLATE & 4))                        // (4: TIMING EXPERIMENT ONLY, stages 0 .. 5 skipped)
   {
     const int16_t *in = M.in + (size_t)c * M.n * ((kPairs && !kMono) ? 2 : 1);
     const int16_t *tin = M.tail_in + (size_t)c * 4 * kModTail;
 
     // ---- stage-0 source: scaled PCM (SSB) or the IQ pair (INTERP), history first
-    for (int t = tid; t < kModTail + kModTile; t += kModThreads)
+    wg_loop<kModTail + kModTile>(tid, [&](const int t)
     {
       const int g = t0 - kModTail + t;                      // global input index
       int a = 0, b = 0;
@@ -212,7 +260,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       }
       src[0][t] = (int16_t)a;
       src[1][t] = (int16_t)b;
-    }
+    });
     // the last tile of the call also leaves the new tail (the other buffer of the ping-pong)
     if (tile + 1 == tiles)
     {
@@ -249,7 +297,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
     __syncthreads();
 
     // ---- stage 0: the two rails at the input rate, x0[j] for j in [-kH0, kModTile)
-    for (int t = tid; t < kH0 + kModTile; t += kModThreads)
+    wg_loop<kH0 + kModTile>(tid, [&](const int t)
     {
       const int j = t - kH0;
       const int16_t *s0 = &src[0][kModTail + j];            // s[n], s0[-k] = s[n-k]
@@ -286,7 +334,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       }
       r[0][kO0 + t] = (int16_t)iv;
       r[1][kO0 + t] = (int16_t)qv;
-    }
+    });
     __syncthreads();
     if (tile + 1 == tiles)
     {
@@ -301,31 +349,37 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
     }
 
     // ---- stage 1: 40-tap prototype, x2: both phases of one input position n per thread and rail,
-    //      outputs m = 2n, 2n + 1 for n in [-kH1/2, tile)
+    //      outputs m = 2n, 2n + 1 for n in [-kH1/2, tile).  Phase p is sum_j h[2j + p] x[n - j], j < 20: the twenty
+    //      samples x[n-19 .. n] as ten int16 pairs (eleven aligned dwords, shifted by a sample where n is even) against
+    //      the taps in pairs -- v_dot2_i32_i16, int32 wrap-around like the reference's accumulator.
     {
       constexpr const int16_t (&h)[40] = (KIND == HRFD_MOD_INTERP) ? Q_INTERPSIG_S1 : Q_AUDIO_D40;
-      for (int t = tid; t < 2 * (kH1 / 2 + kModTile); t += kModThreads)
-      {
+      static_assert((kO0 + kH0 - kH1 / 2 - 19) >= 0 && (kRail % 2) == 0, "the dwords below");
+      if (!(HRFD_MOD_ABLATE & 16))   // (TIMING EXPERIMENT ONLY when set)
+      wg_loop<2 * (kH1 / 2 + kModTile)>(tid, [&](const int t) {
         const int rail = t & 1, u = t >> 1;
-        const int nn = u - kH1 / 2;
-        const int16_t *x = &r[rail][kO0 + kH0 + nn];
+        const int first = kO0 + kH0 + (u - kH1 / 2) - 19;   // index of x[n - 19]
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&r[rail][first & ~1]);
+        const uint32_t sh = (first & 1) ? 16u : 0u;
         int acc0 = 1 << 14, acc1 = 1 << 14;
   #pragma unroll
-        for (int j = 0; j < 20; j++)
+        for (int k = 0; k < 10; k++)
         {
-          const int xv = (int)x[-j];
-          acc0 += (int)h[2 * j] * xv;
-          acc1 += (int)h[2 * j + 1] * xv;
+          // (lo, hi) = x[n - 19 + 2k], x[n - 18 + 2k], i.e. x[n - j] for j = 19 - 2k and 18 - 2k
+          const uint32_t pr = __builtin_amdgcn_alignbit(w[k + 1], w[k], sh);
+          constexpr auto tap2 = [](int lo, int hi) { return ((uint32_t)(uint16_t)(int16_t)lo) | ((uint32_t)(uint16_t)(int16_t)hi << 16); };
+          acc0 = dot2(pr, tap2(h[2 * (19 - 2 * k)], h[2 * (18 - 2 * k)]), acc0);
+          acc1 = dot2(pr, tap2(h[2 * (19 - 2 * k) + 1], h[2 * (18 - 2 * k) + 1]), acc1);
         }
         // (int16 stores narrow: the 40-tap phases can exceed the int16 range for adversarial input, wrap is the contract)
-        r[rail][kO1 + 2 * u] = (int16_t)(acc0 >> 15);
-        r[rail][kO1 + 2 * u + 1] = (int16_t)(acc1 >> 15);
-      }
+        reinterpret_cast<uint32_t *>(&r[rail][kO1])[u] = ((uint32_t)(acc0 >> 15) & 0xffffu) | ((uint32_t)(acc1 >> 15) << 16);
+      });
     }
     __syncthreads();
     // ---- stages 2 (HB8) and 3 (HB3): one stage-1 position p per thread and rail -> s2[2p], s2[2p+1] in
     //      registers (and s2[2p-1], the cheap phase-1 value of the position before) -> s3[4p .. 4p+3]
-    for (int t = tid; t < 2 * (kH3 / 4 + 2 * kModTile); t += kModThreads)
+    if (!(HRFD_MOD_ABLATE & 32))   // (TIMING EXPERIMENT ONLY when set)
+    wg_loop<2 * (kH3 / 4 + 2 * kModTile)>(tid, [&](const int t)
     {
       const int rail = t & 1, u = t >> 1;
       const int pp = u - kH3 / 4;                          // stage-1 index, from -2
@@ -341,42 +395,37 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       uint32_t *o = reinterpret_cast<uint32_t *>(&r[rail][kO3 + 4 * u]);
       o[0] = ((uint32_t)y0 & 0xffffu) | ((uint32_t)y1 << 16);
       o[1] = ((uint32_t)y2 & 0xffffu) | ((uint32_t)y3 << 16);
-    }
+    });
     __syncthreads();
     // ---- stage 4: HB8, outputs m in [-kH4, 16*tile); two stage-3 positions per thread and rail
-    for (int t = tid; t < 2 * ((kH4 / 2 + 8 * kModTile) / 2); t += kModThreads)
+    if (!(HRFD_MOD_ABLATE & 64))   // (TIMING EXPERIMENT ONLY when set)
+    wg_loop<2 * ((kH4 / 2 + 8 * kModTile) / 2)>(tid, [&](const int t)
     {
-      const int rail = t & 1, u = t >> 1;                   // u: pair of input positions 2u, 2u+1 (offset by the history)
-      const int nn = 2 * u - kH4 / 2;                       // first input index of the pair (even)
-      const int16_t *x = &r[rail][kO3 + kH3 + nn];
-      const int x1 = x[1], x0 = x[0], xm1 = x[-1], xm2 = x[-2], xm3 = x[-3];
-      int y0, y1, y2, y3;
-      hb8(x0, xm1, xm2, xm3, y0, y1);
-      hb8(x1, x0, xm1, xm2, y2, y3);
+      const int rail = t & 1, u = t >> 1;                   // u: the input positions n = 2u - kH4/2 and n + 1
+      constexpr int kFirst = kO3 + kH3 - kH4 / 2 - 4;       // index of x[n - 4] for u = 0
+      static_assert(kFirst >= kO3 && (kFirst % 2) == 0 && (kO4 % 2) == 0, "aligned dwords inside stage 3's outputs");
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r[rail][kFirst]) + u;
       uint32_t *o = reinterpret_cast<uint32_t *>(&r[rail][kO4 + 4 * u]);
-      o[0] = ((uint32_t)y0 & 0xffffu) | ((uint32_t)y1 << 16);
-      o[1] = ((uint32_t)y2 & 0xffffu) | ((uint32_t)y3 << 16);
-    }
+      hb8_pair(w[0], w[1], w[2], o[0], o[1]);
+    });
     __syncthreads();
     // ---- stage 5: HB8, outputs m in [-kH5, 32*tile)
-    for (int t = tid; t < 2 * ((kH5 / 2 + 16 * kModTile + 1) / 2); t += kModThreads)
+    if (!(HRFD_MOD_ABLATE & 128))   // (TIMING EXPERIMENT ONLY when set)
+    wg_loop<2 * ((kH5 / 2 + 16 * kModTile + 1) / 2)>(tid, [&](const int t)
     {
-      const int rail = t & 1, u = t >> 1;
-      const int nn = 2 * u - kH5 / 2 - 1;                   // odd first index: output dwords stay aligned (kO5 + kH5 + 2 nn even)
-      const int16_t *x = &r[rail][kO4 + kH4 + nn];
-      const int x1 = x[1], x0 = x[0], xm1 = x[-1], xm2 = x[-2], xm3 = x[-3];
-      int y0, y1, y2, y3;
-      hb8(x0, xm1, xm2, xm3, y0, y1);
-      hb8(x1, x0, xm1, xm2, y2, y3);
-      int16_t *o = &r[rail][kO5 + kH5 + 2 * nn];
-      if (nn >= -kH5 / 2)
+      const int rail = t & 1, u = t >> 1;                   // the input positions n = 2u - kH5/2 - 1 (even) and n + 1
+      constexpr int kFirst = kO4 + kH4 - kH5 / 2 - 1 - 4;   // index of x[n - 4] for u = 0: two samples in front of the stage's
+      static_assert(kFirst >= 0 && (kFirst % 2) == 0 && ((kO5 + kH5) % 2) == 0, "aligned dwords in, aligned dwords out");   // history (they only reach the outputs of position -2, which are not kept)
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r[rail][kFirst]) + u;
+      uint32_t o0, o1;
+      hb8_pair(w[0], w[1], w[2], o0, o1);
+      uint32_t *o = reinterpret_cast<uint32_t *>(&r[rail][kO5 + kH5 - 4]) + 2 * u;   // outputs 2n .. 2n + 3, n = 2u - 2
+      if (u != 0)
       {
-        o[0] = (int16_t)y0;
-        o[1] = (int16_t)y1;
+        o[0] = o0;
       }
-      o[2] = (int16_t)y2;
-      o[3] = (int16_t)y3;
-    }
+      o[1] = o1;
+    });
     __syncthreads();
 
     if constexpr (KIND == HRFD_MOD_WB_HEAD)
@@ -401,8 +450,10 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   // ---- stages 6, 7, 8 in registers: one 256 kS/s sample j -> 8 output IQ pairs
   const int valid = min(kModTile, n - t0);                // input samples really in this tile
   int8_t *out = M.out + ((size_t)c * M.n + t0) * 512;
-  for (int j = tid; j < 32 * kModTile; j += kModThreads)
-  {
+  auto eight = [&](const int j) -> uint4 {
+#if (HRFD_MOD_ABLATE & 2)
+    return make_uint4((uint32_t)j, (uint32_t)j * 3u, (uint32_t)tid, 7u);   // TIMING EXPERIMENT ONLY: no tail arithmetic
+#endif
     uint32_t w[4];
     int z[2][8];
 #pragma unroll
@@ -436,10 +487,41 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       const uint32_t hi = __builtin_amdgcn_perm((uint32_t)z[1][2 * d + 1], (uint32_t)z[0][2 * d + 1], 0x06020c0cu);
       w[d] = lo | hi;
     }
-    if (j < 32 * valid)
-    {
-      *reinterpret_cast<uint4 *>(out + (size_t)j * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  if (valid == kModTile)
+  {
+    // (a whole tile, the usual case: eight rounds of stores without a predicate)
+#if (HRFD_MOD_ABLATE & 1)
+    wg_loop<32 * kModTile>(tid, [&](const int j) {                        // TIMING EXPERIMENT ONLY: no stores
+      const uint4 w4 = eight(j);
+      if (w4.x == 0x12345678u && w4.y == 0x9abcdef0u && w4.z == 0x0fedcba9u)
+      {
+        *reinterpret_cast<uint4 *>(out + (size_t)j * 16) = w4;
+      }
+    });
+#else
+#if (HRFD_MOD_ABLATE & 8)
+    wg_loop<32 * kModTile>(tid, [&](const int j) { *reinterpret_cast<uint4 *>(out + (size_t)j * 16) = eight(j); });   // TIMING EXPERIMENT ONLY: plain stores
+#else
+    // (nontemporal: the output is written once and read by nobody on this device -- 2 % on the whole kernel)
+    wg_loop<32 * kModTile>(tid, [&](const int j) {
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      const uint4 w4 = eight(j);
+      __builtin_nontemporal_store(u4{w4.x, w4.y, w4.z, w4.w}, reinterpret_cast<u4 *>(out + (size_t)j * 16));
+    });
+#endif
+#endif
+  }
+  else
+  {
+    wg_loop<32 * kModTile>(tid, [&](const int j) {
+      const uint4 w4 = eight(j);
+      if (j < 32 * valid)
+      {
+        *reinterpret_cast<uint4 *>(out + (size_t)j * 16) = w4;
+      }
+    });
   }
 }
 
