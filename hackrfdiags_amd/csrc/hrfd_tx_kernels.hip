@@ -77,6 +77,26 @@ __constant__ constexpr int16_t kS1Interp[40] = {
     Q_INTERPSIG_S1[30], Q_INTERPSIG_S1[31], Q_INTERPSIG_S1[32], Q_INTERPSIG_S1[33], Q_INTERPSIG_S1[34],
     Q_INTERPSIG_S1[35], Q_INTERPSIG_S1[36], Q_INTERPSIG_S1[37], Q_INTERPSIG_S1[38], Q_INTERPSIG_S1[39]};
 
+// tap x sample (or sum of two samples): both fit 24 bits.  Written as the instruction: where only bits 15 .. 30 of a
+// sum are looked at later, the compiler "simplifies" a negative tap to tap + 2^31, no longer sees a 24-bit operand and
+// takes the full 32-bit multiply, which issues at a quarter of the rate.
+template <int TAP>
+__device__ __forceinline__ int mul24(const int x)
+{
+  static_assert(TAP >= -(1 << 23) && TAP < (1 << 23), "24-bit tap");
+  int r;
+  asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "i"(TAP), "v"(x));
+  return r;
+}
+
+// (the same with the tap as a uniform value: an unrolled loop's tap index is no template argument)
+__device__ __forceinline__ int mul24s(const int tap, const int x)
+{
+  int r;
+  asm("v_mul_i32_i24_e32 %0, %1, %2" : "=v"(r) : "s"(tap), "v"(x));
+  return r;
+}
+
 // Q15 output of an interpolator phase: (16384 + sum) >> 15, low 16 bits
 __device__ __forceinline__ int q15(int acc) { return (int)(short)(acc >> 15); }
 
@@ -115,6 +135,13 @@ template <int H>
 __device__ __forceinline__ void hb4(int xn, int xm1, int &y0, int &y1)
 {
   y0 = ((1 << 14) + H * (xn + xm1)) >> 15;
+  y1 = (xn + 1) >> 1;
+}
+// (the same for inputs whose range the compiler cannot see -- values out of v_dot2: mul24)
+template <int H>
+__device__ __forceinline__ void hb4_m24(int xn, int xm1, int &y0, int &y1)
+{
+  y0 = ((1 << 14) + mul24<H>(xn + xm1)) >> 15;
   y1 = (xn + 1) >> 1;
 }
 // the same stage with its outputs as twice the Q15 numerators: z >> 16 is the output, byte 2 of z its low byte
@@ -324,7 +351,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
         for (int k = 0; k < 15; k += 2)
         {
           static_assert(N_SSB_HILBERT == 31, "");
-          acc += (int)Q_SSB_HILBERT[k] * ((int)s0[-k] - (int)s0[-(30 - k)]);
+          acc += mul24s((int)Q_SSB_HILBERT[k], (int)s0[-k] - (int)s0[-(30 - k)]);
         }
         qv = q15(acc);
         if (!M.lsb[c])
@@ -382,15 +409,22 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
     wg_loop<2 * (kH3 / 4 + 2 * kModTile)>(tid, [&](const int t)
     {
       const int rail = t & 1, u = t >> 1;
-      const int pp = u - kH3 / 4;                          // stage-1 index, from -2
-      const int16_t *x = &r[rail][kO1 + kH1 + pp];
-      const int xa = x[0], xb = x[-1], xc = x[-2], xd = x[-3];
-      int e0, e1;
-      hb8(xa, xb, xc, xd, e0, e1);                         // s2[2p], s2[2p+1]
-      const int em1 = (xc + 1) >> 1;                       // s2[2p-1]
+      // stage-1 index p = u - kH3/4, from -2; x[p-3 .. p] as two sample pairs out of three aligned dwords (shifted by
+      // a sample where p - 3 is odd), the HB8 phase 0 as two v_dot2 (hb8_pair has the arithmetic)
+      constexpr int kFirst = kO1 + kH1 - kH3 / 4 - 3;      // index of x[p - 3] for u = 0
+      static_assert(kFirst >= kO1 && (kO1 % 2) == 0, "inside stage 1's outputs");
+      const int first = kFirst + u;
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r[rail][first & ~1]);
+      const uint32_t sh = (first & 1) ? 16u : 0u;
+      const uint32_t lo = __builtin_amdgcn_alignbit(w[1], w[0], sh);   // (x[p-3], x[p-2])
+      const uint32_t hi = __builtin_amdgcn_alignbit(w[2], w[1], sh);   // (x[p-1], x[p])
+      constexpr uint32_t th = (uint16_t)Q_INTERP_HB8[0], tg = (uint16_t)Q_INTERP_HB8[2];
+      const int e0 = dot2(hi, tg | (th << 16), dot2(lo, th | (tg << 16), 1 << 14)) >> 15;   // s2[2p]
+      const int e1 = ((int)(int16_t)hi + 1) >> 1;          // s2[2p+1] = (x[p-1] + 1) >> 1
+      const int em1 = (((int)lo >> 16) + 1) >> 1;          // s2[2p-1] = (x[p-2] + 1) >> 1
       int y0, y1, y2, y3;
-      hb4<Q_INTERP_HB3[0]>(e0, em1, y0, y1);
-      hb4<Q_INTERP_HB3[0]>(e1, e0, y2, y3);
+      hb4_m24<Q_INTERP_HB3[0]>(e0, em1, y0, y1);
+      hb4_m24<Q_INTERP_HB3[0]>(e1, e0, y2, y3);
       // (int16 pairs: 4u is even)
       uint32_t *o = reinterpret_cast<uint32_t *>(&r[rail][kO3 + 4 * u]);
       o[0] = ((uint32_t)y0 & 0xffffu) | ((uint32_t)y1 << 16);
