@@ -538,7 +538,8 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 #if (HRFD_MOD_ABLATE & 8)
     wg_loop<32 * kModTile>(tid, [&](const int j) { *reinterpret_cast<uint4 *>(out + (size_t)j * 16) = eight(j); });   // TIMING EXPERIMENT ONLY: plain stores
 #else
-    // (nontemporal: the output is written once and read by nobody on this device -- 2 % on the whole kernel)
+    // (nontemporal: the output is written once and read by nobody on this device -- 2.6 % on the whole kernel; sc0 / sc1
+    //  beside or instead of nt: no better, alone 2-4 % worse)
     wg_loop<32 * kModTile>(tid, [&](const int j) {
       typedef unsigned int u4 __attribute__((ext_vector_type(4)));
       const uint4 w4 = eight(j);
