@@ -725,7 +725,8 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
       }
       finish_block();                                    // of the previous unit
       FLOW_MARK(3)
-      const int slot0 = ring_slot(8 * u);                // NT is a multiple of 8: a unit never wraps
+      // (uniform, and said so: left to itself the compiler computes the row offset per lane with a quarter-rate v_mul_lo_u32)
+      const int slot0 = __builtin_amdgcn_readfirstlane(ring_slot(8 * u));   // NT is a multiple of 8: a unit never wraps
       uint32_t *dst = ring + slot0 * kFStride + lane_dw;
       uint32_t v[4], mag4, magsum;
       uint32_t iqb[2] = {0u, 0u};
