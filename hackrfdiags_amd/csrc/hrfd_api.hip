@@ -2064,7 +2064,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     {
       hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_HEAD>, dim3(grid), dim3(kModThreads), 0, s, M);
       phase_scan(h, h->d_wb, (size_t)n_per_channel * 32, (size_t)n_per_channel * 32, h->d_acc, h->n_channels, s);
-      hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(512, (s32 / 4 + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, s, B);
+      hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(512, (s32 / 4 + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, s, B);   // (two workgroups per CU: the 64 KiB table)
       M.in = reinterpret_cast<const int16_t *>(h->d_wb);
       M.wbtail = h->d_wbtail[h->cur];
       hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(grid), dim3(kModThreads), 0, s, M);

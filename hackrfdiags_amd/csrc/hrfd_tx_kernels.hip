@@ -1077,6 +1077,25 @@ __global__ void k_fm_rails(const BaseParams B)
 // The two float tables, x900 and narrowed, are one table of 16384 rail pairs (B.wbpack, built by the host with the
 // same float multiply): 64 KiB, held in LDS by every workgroup -- one ds_read per sample instead of two gathers
 // from memory -- and the workgroups walk the cells four at a time (16-byte accesses).
+// Nco::runFast (Nco.cc:222-257) on a stored phase, x900, (int16_t): the rail pair of one 256 kS/s sample out of the
+// packed table
+__device__ __forceinline__ uint32_t wb_lookup(const uint32_t *pack, const uint32_t phase_bits)
+{
+  const double two_pi = 6.283185307179586476925286766559;
+  const float scaled = __builtin_bit_cast(float, phase_bits) * 16384.0f;
+  // (int)(x / two_pi): the product with the reciprocal is within two ulps of the quotient, so the truncation can only
+  // differ when an integer is that close -- then, and only then, the division itself
+  double quot = (double)scaled * (1.0 / two_pi);
+  if (__builtin_fabs(quot - __builtin_rint(quot)) < 1e-6)
+  {
+    quot = (double)scaled / two_pi;
+  }
+  int idx = (int)(short)(int)quot;
+  idx += 8192;
+  idx = max(0, min(16383, idx));
+  return pack[idx];
+}
+
 constexpr int kWbRailsThreads = 512;
 __global__ __launch_bounds__(kWbRailsThreads) void k_wb_rails(const BaseParams B)
 {
@@ -1087,40 +1106,34 @@ __global__ __launch_bounds__(kWbRailsThreads) void k_wb_rails(const BaseParams B
   }
   __syncthreads();
   const size_t n32 = (size_t)B.n * 32;
-  const size_t lo32 = (size_t)B.lo * 32, len32 = (B.len != 0u) ? (size_t)B.len * 32 : n32;   // the slice of every channel's row
-  const size_t sq = len32 / 4;                           // quads per channel in the slice
-  const size_t quads = sq * B.n_channels;
-  const double two_pi = 6.283185307179586476925286766559;
-  for (size_t q = (size_t)blockIdx.x * kWbRailsThreads + threadIdx.x; q < quads; q += (size_t)gridDim.x * kWbRailsThreads)
+  const uint32_t lo32 = B.lo * 32u, len32 = (B.len != 0u) ? B.len * 32u : (uint32_t)n32;   // the slice of every channel's row
+  const uint32_t sq = len32 / 4;                         // quads per channel in the slice
+  // work items of kWbRailsThreads quads, none across a channel boundary: one 32-bit division per item, none per quad
+  // (the flat 64-bit index of the first version cost three 64-bit divisions per quad: more than the lookups)
+  const uint32_t per_ch = (sq + kWbRailsThreads - 1) / kWbRailsThreads;
+  const uint32_t items = per_ch * B.n_channels;
+  for (uint32_t it = blockIdx.x; it < items; it += gridDim.x)
   {
-    const size_t cq = q / sq;
-    const size_t t = cq * n32 + lo32 + 4 * (q - cq * sq);
-    const uint4 ph = *reinterpret_cast<const uint4 *>(B.wb + t);
+    const uint32_t c = it / per_ch;
+    const uint32_t q = (it - c * per_ch) * kWbRailsThreads + threadIdx.x;   // quad of the channel's slice
+    if (q >= sq)
+    {
+      continue;
+    }
+    uint32_t *cell = B.wb + (size_t)c * n32 + lo32 + 4 * (size_t)q;
+    const uint4 ph = *reinterpret_cast<const uint4 *>(cell);
     const uint32_t pb[4] = {ph.x, ph.y, ph.z, ph.w};
     uint32_t w[4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
     {
-      const float scaled = __builtin_bit_cast(float, pb[j]) * 16384.0f;
-      // (int)(x / two_pi): the product with the reciprocal is within two ulps of the quotient, so the truncation can only
-      // differ when an integer is that close -- then, and only then, the division itself
-      double quot = (double)scaled * (1.0 / two_pi);
-      if (__builtin_fabs(quot - __builtin_rint(quot)) < 1e-6)
-      {
-        quot = (double)scaled / two_pi;
-      }
-      int idx = (int)(short)(int)quot;
-      idx += 8192;
-      idx = max(0, min(16383, idx));
-      w[j] = pack[idx];
+      w[j] = wb_lookup(pack, pb[j]);
     }
-    *reinterpret_cast<uint4 *>(B.wb + t) = make_uint4(w[0], w[1], w[2], w[3]);
-    const size_t k = t % n32;
-    if (k + 4 == n32)
+    *reinterpret_cast<uint4 *>(cell) = make_uint4(w[0], w[1], w[2], w[3]);
+    if ((size_t)lo32 + 4 * (size_t)q + 4 == n32)
     {
-      const size_t c = t / n32;
-      B.wbtail_out[c * 2] = w[2];
-      B.wbtail_out[c * 2 + 1] = w[3];
+      B.wbtail_out[(size_t)c * 2] = w[2];
+      B.wbtail_out[(size_t)c * 2 + 1] = w[3];
     }
   }
 }
