@@ -1036,7 +1036,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     P.run_len = run_len;
     P.n_runs = (n_blocks + run_len - 1) / run_len;
     const uint32_t grid = groups * P.n_runs;
-    P.dbg = (h->d_dbg != nullptr && (size_t)grid * kDbgSlots <= h->dbg_cap && mode == HRFD_MODE_WBFM) ? h->d_dbg : nullptr;
+    P.dbg = (h->d_dbg != nullptr && (size_t)grid * kDbgSlots <= h->dbg_cap && mode >= 0) ? h->d_dbg : nullptr;   // (probe builds: any one mode)
     P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here (the FIR modes: ring tiles read below a generation)
     P.self_finish = 1;                                     // the last workgroup of a channel finishes it (finish_channel)
     P.dbg_flags |= h->expire_once << 16;

@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev)
 pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
 torch.cuda.synchronize()
-rx = api.Rx(C); rx.set_mode(api.WBFM)
+rx = api.Rx(C); rx.set_mode({'wbfm': api.WBFM, 'am': api.AM, 'fm': api.FM, 'ssb': api.LSB}[os.environ.get('HRFD_MODE', 'wbfm')])
 grid = max(256, 8 * ((C + 7) // 8))
 for _ in range(100):
     rx.process_device(x.data_ptr(), B * BLK, BLK, B, pcm.data_ptr())
