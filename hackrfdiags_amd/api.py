@@ -141,7 +141,8 @@ class Rx:
         check(self.L.hrfd_rx_debug_set_stream(self.h, int(kernel)), "hrfd_rx_debug_set_stream")
 
     def debug_set_fir_flow(self, mode: int):
-        """test hook: AM / SSB / FM batches on the flow kernel's FIR modes: -1 automatic, 0 never, 1 always"""
+        """test hook: AM / SSB / FM batches on the flow kernel's FIR modes: -1 automatic, 0 never, 1 always, 2 always and one
+        launch per kind (a bank of several kinds does not take k_rx_flow_bank)"""
         check(self.L.hrfd_rx_debug_set_fir_flow(self.h, int(mode)), "hrfd_rx_debug_set_fir_flow")
 
     def debug_set_gated(self, on: bool):

@@ -626,9 +626,9 @@ extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
 // test hook: AM / SSB / FM batches on the flow kernel's FIR modes: -1 automatic (banks of 48 channels or more per kind), 0 never, 1 always
 extern "C" int hrfd_rx_debug_set_fir_flow(hrfd_rx *h, int mode)
 {
-  if (h == nullptr || mode < -1 || mode > 1)
+  if (h == nullptr || mode < -1 || mode > 2)
   {
-    return fail(HRFD_EINVAL, "hrfd_rx_debug_set_fir_flow: -1, 0 or 1");
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_set_fir_flow: -1, 0, 1 or 2");
   }
   h->fir_flow = mode;
   return HRFD_OK;
@@ -1010,7 +1010,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   const bool flow = flow_shape && n_wb != 0;              // the WBFM channels run on the flow kernel
   const bool fir_shape = flow_shape && h->fir_flow != 0 && n_blocks <= 64u && d_iq256 == nullptr;
   const int kinds = (n_wb != 0) + (n_as != 0) + (n_fm != 0);
-  const bool bank = fir_shape && kinds >= 2 && n_blocks <= 16u && (h->fir_flow > 0 || list_count[9] >= 48u);
+  const bool bank = fir_shape && kinds >= 2 && n_blocks <= 16u && h->fir_flow != 2 && (h->fir_flow > 0 || list_count[9] >= 48u);
   const bool as_flow = !bank && fir_shape && n_as != 0 && (h->fir_flow > 0 || n_as >= 48u);
   const bool fm_flow = !bank && fir_shape && n_fm != 0 && (h->fir_flow > 0 || n_fm >= 48u);
   const bool may_close = (int64_t)h->wbfm_max_threshold > -42 - (int64_t)gain_db;   // can a WBFM gate close at all? (see below)

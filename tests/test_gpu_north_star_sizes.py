@@ -117,3 +117,48 @@ def test_ssb_modulator_1024_channels(oracle):
             assert (got[k] == want).all(), (half, k)
             for c in range(k, C, 16):
                 assert (got[c] == got[k]).all(), (half, c, k)
+
+
+
+def test_soak_flow_shapes_agree_launch_after_launch():
+    """Many full-size launches in a row, streams continuing from launch to launch: 256 channels of all four modes x 16
+    blocks of fresh random input per launch, a real squelch threshold, and per-block levels drawn at random so that gates
+    close and reopen all over the bank (one block in five is a whisper under the threshold).  Two handles demodulate the
+    same input -- the one-launch bank kernel (k_rx_flow_bank) and one flow kernel per mode, each with its gated passes
+    behind it -- and must agree on every PCM sample, n_pcm, magnitude and signal_allowed of every launch, with nothing
+    left uncommitted.  (The oracle is not in this one: the PCM of both shapes is pinned to it by the other tests, gates
+    included; this is about the flow kernels' flag protocol and the device-side repair holding up under load, launch
+    after launch, on input nobody chose.)"""
+    import torch
+    C, B, launches = 256, 16, 60
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260)
+    handles = []
+    for shape in (-1, 2):                                 # the bank kernel; one flow kernel per kind
+        rx = api.Rx(C)
+        for c in range(C):
+            rx.set_mode([api.AM, api.FM, api.WBFM, api.LSB][c % 4], channel=c)
+        rx.set_threshold(-22)
+        rx.debug_set_fir_flow(shape)
+        handles.append(rx)
+    outs = [[torch.zeros((C, B, 512), dtype=torch.int16, device=dev), torch.zeros((C, B), dtype=torch.int32, device=dev),
+             torch.zeros((C, B), dtype=torch.int32, device=dev), torch.zeros((C, B), dtype=torch.uint8, device=dev)] for _ in handles]
+    shift_of = torch.tensor([0, 2, 4, 7, 0], device=dev)
+    closed = 0
+    for it in range(launches):
+        x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev, generator=g)
+        lvl = torch.randint(0, 5, (C, B, 1), device=dev, generator=g)
+        x = (x.to(torch.int16) >> shift_of[lvl].to(torch.int16)).to(torch.int8)   # full scale, -12 dB, -24 dB, a whisper, full scale
+        for o in outs:
+            for t in o:
+                t.fill_(77)
+        torch.cuda.synchronize()
+        for rx, o in zip(handles, outs):
+            rx.process_device(x.data_ptr(), B * BLK, BLK, B, o[0].data_ptr(), d_n_pcm=o[1].data_ptr(), d_magnitude=o[2].data_ptr(),
+                              d_allowed=o[3].data_ptr())
+        assert handles[0].sync() == 0 and handles[1].sync() == 0, it
+        closed += int((outs[0][3] == 0).sum().item())
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b), it
+    assert closed > launches * C                          # gates did close, all over the bank
