@@ -159,11 +159,14 @@ def test_wbfm_modulator_bit_exact(oracle):
     assert _mod_case(oracle, "wbfmmod", api.MOD_WBFM, 0) == 0.0
 
 
-def test_wbfm_modulator_time_slices(oracle):
-    """a long call (16 blocks and a ragged rest) runs its passes in time slices on three streams -- the phase
-    recurrence of slice t + 1 beside the table lookup and the x8 cascade of slice t: bit-exact against the oracle, equal
-    to the unsliced call (hook), and the state a second call continues from"""
-    C, n = 5, 16 * 512 + 77
+@pytest.mark.parametrize("n", [16 * 512 + 77, 2061, 1601, 1537, 4600, 4609], ids=lambda n: "n%d" % n)
+def test_wbfm_modulator_time_slices(oracle, n):
+    """a long call runs its passes in time slices on two streams of the handle's own -- the phase recurrence of slice
+    t + 1 beside the table lookup and the x8 cascade of slice t: bit-exact against the oracle, equal to the unsliced call
+    (hook), and the state a second call continues from.  Lengths: 16 blocks and a ragged rest (nine slices), the
+    shortest call that is sliced at all (25 tiles: 1537 samples) and its neighbours, and both sides of the length from
+    which the slices halve four times at the end instead of twice (72 tiles)."""
+    C = 5
     pcm = np.stack([synth.lcg_pcm(140 + c, 2 * n) for c in range(C)])
     a, b = api.Mod(api.MOD_WBFM, C), api.Mod(api.MOD_WBFM, C)
     a.debug_set_sliced(2)                                   # slices whether or not the recurrence's stream got CUs of its own
