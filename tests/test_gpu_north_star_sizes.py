@@ -2,12 +2,13 @@
 
   config 2 / 4 / north star   256, 512 (config 4's per-GPU shard) and 1024 (>= 1000, the stated target)
                               concurrent WBFM channels x 16 blocks in ONE launch
-  config 3                    64 AM + 64 FM + 64 WBFM + 64 SSB x 16 blocks, per-mode dispatch
+  config 3                    64 AM + 64 FM + 64 WBFM + 64 SSB x 16 blocks, one launch of k_rx_flow_bank
   config 5                    1024 SSB modulators
 
 Each against the sequential CPU oracle on a spread of channels, plus size-independent properties over
 ALL channels: channels fed identical input give identical output, every launch committed (nothing was
-replayed), and the two batch kernels (k_rx_wbfm_flow, k_rx_wbfm_stream) agree."""
+replayed), and the batch kernel (k_rx_wbfm_flow) and the block kernel (k_rx_wbfm) agree; a soak over
+60 launches of random input with gates closing at random."""
 import zlib
 
 import numpy as np
