@@ -136,8 +136,8 @@ class Rx:
         return out
 
     def debug_set_stream(self, kernel):
-        """test hook: WBFM batches on 0 / False = k_rx_wbfm, 1 / True = k_rx_wbfm_stream,
-        2 = k_rx_wbfm_flow where it applies (the default)"""
+        """test hook: WBFM batches on 0 / False = the block kernel k_rx_wbfm, anything else = k_rx_wbfm_flow where it
+        applies (the default)"""
         check(self.L.hrfd_rx_debug_set_stream(self.h, int(kernel)), "hrfd_rx_debug_set_stream")
 
     def debug_set_fir_flow(self, mode: int):

@@ -604,7 +604,7 @@ def test_inner_demod_many_channels(oracle):
 @pytest.mark.parametrize("tab", [False, True], ids=["polynomial", "first_octant_table"])
 def test_arithmetic_atan2_equals_table_everywhere(tab):
     """The WBFM kernels compute theta instead of gathering it from the reference's 256 x 256
-    table -- k_rx_wbfm / k_rx_wbfm_stream: polynomial + 2-bit correction from LDS; k_rx_wbfm_flow:
+    table -- k_rx_wbfm: polynomial + 2-bit correction from LDS; k_rx_wbfm_flow:
     first-octant float table (8385 entries) + octant arithmetic + 2-bit correction.  Every one of
     the 65536 (q, i) entries must be the table's float, bit for bit."""
     rx = api.Rx(1)
