@@ -1486,10 +1486,18 @@ extern "C" int hrfd_rx_reduce_sample_rate(hrfd_rx *h, const int8_t *iq, uint32_t
     }
     h->cfg_dirty = true;
   }
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy2D(tracking.data(), sizeof(uint32_t), &h->d_state->tracking, sizeof(ChanState), sizeof(uint32_t), C, hipMemcpyDeviceToHost));
-  const int rc = hrfd_rx_process_block(h, iq, block_bytes, 1, 0, pcm.data(), npcm.data(), nullptr, nullptr, iq256k);
-  HIP_TRY(hipMemcpy2D(&h->d_state->tracking, sizeof(ChanState), tracking.data(), sizeof(uint32_t), sizeof(uint32_t), C, hipMemcpyHostToDevice));
+  // (from here on every path puts the modes back)
+  int rc = HRFD_OK;
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess)
+  {
+    e = hipMemcpy2D(tracking.data(), sizeof(uint32_t), &h->d_state->tracking, sizeof(ChanState), sizeof(uint32_t), C, hipMemcpyDeviceToHost);
+  }
+  if (e == hipSuccess)
+  {
+    rc = hrfd_rx_process_block(h, iq, block_bytes, 1, 0, pcm.data(), npcm.data(), nullptr, nullptr, iq256k);
+    e = hipMemcpy2D(&h->d_state->tracking, sizeof(ChanState), tracking.data(), sizeof(uint32_t), sizeof(uint32_t), C, hipMemcpyHostToDevice);
+  }
   {
     std::lock_guard<std::mutex> g(h->mu);
     for (uint32_t c = 0; c < C; c++)
@@ -1497,6 +1505,10 @@ extern "C" int hrfd_rx_reduce_sample_rate(hrfd_rx *h, const int8_t *iq, uint32_t
       h->h_cfg[c].mode = modes[c];
     }
     h->cfg_dirty = true;
+  }
+  if (e != hipSuccess)
+  {
+    return fail(HRFD_ENODEV, "hrfd_rx_reduce_sample_rate: %s", hipGetErrorString(e));
   }
   return rc;
 }

@@ -105,7 +105,8 @@ int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t block_bytes,
  * application): one block of every channel through the three half-band stages only -- the decimator pipelines advance,
  * the squelch and the demodulators are left alone.  iq [n_channels][block_bytes]; iq256k [n_channels][block_bytes/8]
  * receives the stream WITH the Fs/4 rotation (the front end is fused with the mixer here; the rotation is exactly
- * invertible, the shim class takes it out again). */
+ * invertible, the shim class takes it out again).  Blocking; not to be called while another thread changes the
+ * handle's modes (it parks them for the duration of the call). */
 int hrfd_rx_reduce_sample_rate(hrfd_rx *h, const int8_t *iq, uint32_t block_bytes, int8_t *iq256k);
 
 /* Same work with every buffer already resident in device memory (HBM); this is
