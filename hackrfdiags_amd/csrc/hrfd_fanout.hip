@@ -33,8 +33,15 @@ struct hrfd_fanout
     int16_t *d_pcm = nullptr;
     uint32_t *d_npcm = nullptr;
     size_t cap_iq = 0, cap_pcm = 0, cap_npcm = 0;
-    hipEvent_t e_src = nullptr;                          // the source data is complete (recorded on the caller's stream)
   };
+  // "the source data is complete": one event per source device seen so far, created ON that device (an event is recorded
+  // on a stream of its own device; any device's stream may wait for it)
+  struct SrcEvent
+  {
+    int device;
+    hipEvent_t ev;
+  };
+  std::vector<SrcEvent> src_events;
   uint32_t n_channels = 0;
   std::vector<Shard> shards;
   uint32_t block_bytes = 0, n_blocks = 0, gain_db = 0;   // of the batch in flight
@@ -71,8 +78,12 @@ static int fanout_free(hrfd_fanout *f)
     if (s.d_iq) (void)hipFree(s.d_iq);
     if (s.d_pcm) (void)hipFree(s.d_pcm);
     if (s.d_npcm) (void)hipFree(s.d_npcm);
-    if (s.e_src) (void)hipEventDestroy(s.e_src);
     rx_free(s.rx);
+  }
+  for (hrfd_fanout::SrcEvent &e : f->src_events)
+  {
+    (void)hipSetDevice(e.device);
+    (void)hipEventDestroy(e.ev);
   }
   delete f;
   return HRFD_OK;
@@ -104,11 +115,7 @@ extern "C" int hrfd_fanout_create(uint32_t n_channels, const int *devices, uint3
     }
     s.device = devices[g];
     (void)hrfd_fanout_channel_range(n_channels, n_devices, g, &s.first, &s.count);
-    int rc = hrfd_rx_create(s.count, s.device, &s.rx);
-    if (rc == HRFD_OK && hipEventCreateWithFlags(&s.e_src, hipEventDisableTiming) != hipSuccess)
-    {
-      rc = fail(HRFD_ENODEV, "hrfd_fanout_create: event creation failed on device %d", s.device);
-    }
+    const int rc = hrfd_rx_create(s.count, s.device, &s.rx);
     if (rc != HRFD_OK)
     {
       fanout_free(f);
@@ -246,17 +253,30 @@ extern "C" int hrfd_fanout_scatter(hrfd_fanout *f, int src_device, const int8_t 
     return rc;
   }
   const size_t per_channel = (size_t)n_blocks * block_bytes;
+  hipEvent_t ready = nullptr;
+  if (src_stream != nullptr)
+  {
+    HIP_TRY(hipSetDevice(src_device));
+    for (hrfd_fanout::SrcEvent &e : f->src_events)
+    {
+      if (e.device == src_device)
+      {
+        ready = e.ev;
+      }
+    }
+    if (ready == nullptr)
+    {
+      HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+      f->src_events.push_back({src_device, ready});
+    }
+    HIP_TRY(hipEventRecord(ready, (hipStream_t)src_stream));
+  }
   for (hrfd_fanout::Shard &s : f->shards)
   {
-    if (src_stream != nullptr)
-    {
-      HIP_TRY(hipSetDevice(src_device));
-      HIP_TRY(hipEventRecord(s.e_src, (hipStream_t)src_stream));
-    }
     HIP_TRY(hipSetDevice(s.device));
-    if (src_stream != nullptr)
+    if (ready != nullptr)
     {
-      HIP_TRY(hipStreamWaitEvent(s.rx->stream, s.e_src, 0));
+      HIP_TRY(hipStreamWaitEvent(s.rx->stream, ready, 0));
     }
     const int8_t *src = d_iq_all + (size_t)s.first * per_channel;
     if (s.device == src_device)
