@@ -611,11 +611,14 @@ extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
 }
 
 // test hook: workgroup 0 of the NEXT k_rx_wbfm_flow launch treats its wait number `where` (1 ring space, 2 blocks
-// finished, 3 a generation's units, 4 partial sums, 5 verification order, 6 integer-stage order) as expired the first
+// finished, 3 a generation's units, 4 partial sums, 5 verification order, 6 integer-stage order, 7 AM / SSB: room in the
+// four-generation rings) as expired the first
 // time it polls it -- the bounded-spin failure path (kFailExpired, abort word, host replay of the channel) on demand
+// (where = 100 + g: no wait expires; the service wave of generation g of workgroup 0 is held up behind its part c instead --
+// AM / SSB on the flow kernel)
 extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
 {
-  if (h == nullptr || where < 0 || where > 6)
+  if (h == nullptr || where < 0 || (where > 7 && where < 100) || where > 163)
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 6");
   }

@@ -1133,6 +1133,25 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
       {
         break;
       }
+      if constexpr (MODE == 14)
+      {
+        // The V ring and SSB's 8 kS/s rings hold FOUR generations, and a generation reads the tail of the one in front
+        // in its third decimator and its Hilbert transformer -- which run outside this ordered section, beside the
+        // part c of the generations behind.  So before generation g writes over what g - 4 left, g - 3 must be through
+        // them: through its part d (gctl[2], in order).  Normally it has been for a long time.  (Without this wait a
+        // wave that is held up between its part c and its 8 kS/s part can be overtaken by the four generations behind
+        // it: seen once, as one SSB channel of a mixed bank with wrong PCM in one launch of many.)
+        FlowSpin sp;
+        while (!(HRFD_ABLATE & 4096) && (int)lds_ld(&gctl[2]) < g - 2 && !sp.expired(P, ctl, fail_code, 7))   // (4096: TEST OF THE TEST ONLY)
+        {
+          __builtin_amdgcn_s_sleep(2);
+        }
+        lds_order();
+        if (fail_code != 0u)
+        {
+          break;
+        }
+      }
       // (FM: U and V in front of position 0 are the carried pipelines -- the history tiles write neither)
       if (have && (MODE == 14 || t >= kHalTiles))
       {
@@ -1176,6 +1195,15 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
         if (lane == 0)
         {
           lds_st(&ctl[2], (uint32_t)g + 1u);
+        }
+        // test hook (hrfd_rx_debug_expire(100 + g)): this generation's wave of workgroup 0 is held up here for ~60 us,
+        // while the generations behind it run on -- the four-generation rings must survive that (the wait above)
+        if ((uint32_t)(P.dbg_flags >> 16) == 100u + (uint32_t)g && blockIdx.x == 0)
+        {
+          for (int z = 0; z < 15; z++)
+          {
+            __builtin_amdgcn_s_sleep(127);
+          }
         }
       }
       const int pp = 128 * g + 2 * lane;                 // the lane's two 8 kS/s samples (even index)

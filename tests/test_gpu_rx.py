@@ -439,6 +439,35 @@ def test_closed_gates_are_redone_on_the_device(oracle, mode, run_len):
     assert any(len(want[c][b][0]) == 0 for c in range(C) for b in range(2 * B))
 
 
+@pytest.mark.parametrize("mode", [AM, LSB], ids=["am", "lsb"])
+@pytest.mark.parametrize("gen", [1, 6, 20])
+def test_a_held_up_service_wave_is_not_overtaken(oracle, mode, gen):
+    """AM / SSB on the flow kernel keep four generations of the second decimator's output (and SSB of its 8 kS/s rails) in
+    rings, and a generation reads the tail of the one in front of it outside the ordered sections.  hrfd_rx_debug_expire(100
+    + g) holds the service wave of generation g of workgroup 0 up for ~60 us right behind its ordered section, while the
+    four generations behind it run on: none of them may write over what the held-up one (and the one behind it) still
+    have to read.  (Found as one SSB channel of a mixed bank with wrong PCM in one launch of many; this hook makes the
+    situation, the PCM must be the oracle's and nothing may be reported as failed.)"""
+    import torch
+    C, B = 2, 8
+    xs = np.stack([synth.make_input("fmtone" if c else "lcg", 70 + c, B).reshape(B, BLK) for c in range(C)])
+    want = [_oracle_stream(oracle, mode, xs[c], B) for c in range(C)]
+    dev = torch.device("cuda:0")
+    rx = api.Rx(C)
+    rx.set_mode(mode)
+    rx.debug_set_fir_flow(1)
+    x = torch.from_numpy(xs).to(dev)
+    out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    rx.debug_expire(100 + gen)
+    rx.process_device(x.data_ptr(), B * BLK, BLK, B, out.data_ptr())
+    assert rx.sync() == 0, rx.failed_channels()
+    got = out.cpu().numpy()
+    for c in range(C):
+        for b in range(B):
+            assert (got[c, b] == want[c][b][0]).all(), (c, b)
+
+
 @pytest.mark.parametrize("run_len", [0, 16], ids=["several_runs_per_channel", "one_workgroup_per_channel"])
 @pytest.mark.parametrize("where", [3, 5, 6, 1])
 def test_expired_wait_fails_the_channel_and_is_replayed(oracle, where, run_len):
