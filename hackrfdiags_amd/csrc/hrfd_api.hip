@@ -614,11 +614,11 @@ extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
 // finished, 3 a generation's units, 4 partial sums, 5 verification order, 6 integer-stage order, 7 AM / SSB: room in the
 // four-generation rings) as expired the first
 // time it polls it -- the bounded-spin failure path (kFailExpired, abort word, host replay of the channel) on demand
-// (where = 100 + g: no wait expires; the service wave of generation g of workgroup 0 is held up behind its part c instead --
-// AM / SSB on the flow kernel)
+// (where = 1000 p + g: no wait expires; the service wave of generation g of workgroup 0 is held up behind hand-over point p
+// of its loop instead: flow_hold_up)
 extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
 {
-  if (h == nullptr || where < 0 || (where > 7 && where < 100) || where > 163)
+  if (h == nullptr || where < 0 || (where > 7 && where < 1000) || where > 6063)
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 6");
   }

@@ -122,6 +122,20 @@ struct FlowSpin
     return true;
   }
 };
+// test hook (hrfd_rx_debug_expire(1000 p + g)): the service wave of generation g of workgroup 0 is held up for ~60 us behind
+// hand-over point p of its loop (1: FIR modes, part b handed over; 2: AM / SSB, part c; 3: SSB, 8 kS/s rails published;
+// 4: WBFM, partial sums published; 5: WBFM, verification; 6: WBFM, integer stages), while the generations behind it run on.
+// Nothing a held-up wave still has to read may be written over meanwhile: the parity tests run with it.
+__device__ __forceinline__ void flow_hold_up(const RxParams &P, const int point, const int g)
+{
+  if ((uint32_t)(P.dbg_flags >> 16) == 1000u * (uint32_t)point + (uint32_t)g && blockIdx.x == 0)
+  {
+    for (int z = 0; z < 15; z++)
+    {
+      __builtin_amdgcn_s_sleep(127);
+    }
+  }
+}
 // A returning LDS atomic whose result is looked at LATER: the compiler would wait for an atomicAdd() at once (and
 // LLVM's atomic optimizer puts a readfirstlane right behind it), i.e. for every LDS operation of the wave that is
 // still queued in front of it -- hundreds of cycles per unit of a stream wave.  `ret` must go through lds_landed()
@@ -1127,6 +1141,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
       {
         lds_st(&ctl[1], (uint32_t)g + 1u);
       }
+      flow_hold_up(P, 1, g);
       // ---- c. in order: the stages behind the first decimator
       wait_for(&ctl[2], (uint32_t)g, 6);
       if (fail_code != 0u)
@@ -1196,15 +1211,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
         {
           lds_st(&ctl[2], (uint32_t)g + 1u);
         }
-        // test hook (hrfd_rx_debug_expire(100 + g)): this generation's wave of workgroup 0 is held up here for ~60 us,
-        // while the generations behind it run on -- the four-generation rings must survive that (the wait above)
-        if ((uint32_t)(P.dbg_flags >> 16) == 100u + (uint32_t)g && blockIdx.x == 0)
-        {
-          for (int z = 0; z < 15; z++)
-          {
-            __builtin_amdgcn_s_sleep(127);
-          }
-        }
+        flow_hold_up(P, 2, g);
       }
       const int pp = 128 * g + 2 * lane;                 // the lane's two 8 kS/s samples (even index)
       if constexpr (MODE == 2)
@@ -1286,6 +1293,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
           {
             lds_st(&gctl[3], (uint32_t)g + 1u);
           }
+          flow_hold_up(P, 3, g);
           if (have)
           {
 #pragma unroll
@@ -1501,6 +1509,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
       {
         lds_st(&pflag[g & 7], (uint32_t)g + 1u);
       }
+      flow_hold_up(P, 4, g);
       SVC_MARK(3)
       if (g > 0 && M > 0)
       {
@@ -1630,6 +1639,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
       {
         lds_st(&ctl[1], (uint32_t)g + 1u);
       }
+      flow_hold_up(P, 5, g);
       // the integer stages follow in a chain of their own
       {
         const unsigned long long tw0 = __builtin_readcyclecounter();
@@ -1788,6 +1798,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
           lds_st(&ctl[2], (uint32_t)g + 1u);
         }
       }
+      flow_hold_up(P, 6, g);
       SVC_MARK(9)
     }
     FLOW_TIME_MAX(45)

@@ -439,15 +439,18 @@ def test_closed_gates_are_redone_on_the_device(oracle, mode, run_len):
     assert any(len(want[c][b][0]) == 0 for c in range(C) for b in range(2 * B))
 
 
-@pytest.mark.parametrize("mode", [AM, LSB], ids=["am", "lsb"])
-@pytest.mark.parametrize("gen", [1, 6, 20])
-def test_a_held_up_service_wave_is_not_overtaken(oracle, mode, gen):
-    """AM / SSB on the flow kernel keep four generations of the second decimator's output (and SSB of its 8 kS/s rails) in
-    rings, and a generation reads the tail of the one in front of it outside the ordered sections.  hrfd_rx_debug_expire(100
-    + g) holds the service wave of generation g of workgroup 0 up for ~60 us right behind its ordered section, while the
-    four generations behind it run on: none of them may write over what the held-up one (and the one behind it) still
-    have to read.  (Found as one SSB channel of a mixed bank with wrong PCM in one launch of many; this hook makes the
-    situation, the PCM must be the oracle's and nothing may be reported as failed.)"""
+@pytest.mark.parametrize("mode,point", [(AM, 1), (AM, 2), (LSB, 1), (LSB, 2), (LSB, 3), (FM, 1), (WBFM, 4), (WBFM, 5), (WBFM, 6)],
+                         ids=["am_b", "am_c", "lsb_b", "lsb_c", "lsb_rails", "fm_b", "wbfm_sums", "wbfm_verify", "wbfm_integer"])
+@pytest.mark.parametrize("gen", [0, 1, 6, 20])
+def test_a_held_up_service_wave_is_not_overtaken(oracle, mode, point, gen):
+    """The service waves of the flow kernel hand generations over to each other at a few points and otherwise run side by
+    side, over rings that hold a few generations (v: six; AM / SSB: four of the second decimator's output and of SSB's
+    8 kS/s rails).  hrfd_rx_debug_expire(1000 p + g) holds the wave of generation g of workgroup 0 up for ~60 us right
+    behind hand-over point p, while the generations behind it run on: none of them may write over what the held-up one
+    (and the one behind it) still have to read.  PCM = the oracle's, nothing reported as failed.  (Found as one SSB
+    channel of a mixed bank with wrong PCM in one launch of many: AM / SSB let the four generations behind a wave that
+    was slow between its part c and its 8 kS/s part write into its ring -- point 2 fails without the wait that was
+    added for it.)"""
     import torch
     C, B = 2, 8
     xs = np.stack([synth.make_input("fmtone" if c else "lcg", 70 + c, B).reshape(B, BLK) for c in range(C)])
@@ -459,7 +462,7 @@ def test_a_held_up_service_wave_is_not_overtaken(oracle, mode, gen):
     x = torch.from_numpy(xs).to(dev)
     out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
     torch.cuda.synchronize()
-    rx.debug_expire(100 + gen)
+    rx.debug_expire(1000 * point + gen)
     rx.process_device(x.data_ptr(), B * BLK, BLK, B, out.data_ptr())
     assert rx.sync() == 0, rx.failed_channels()
     got = out.cpu().numpy()
