@@ -618,7 +618,7 @@ extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
 // of its loop instead: flow_hold_up)
 extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
 {
-  if (h == nullptr || where < 0 || (where > 7 && where < 1000) || where > 6063)
+  if (h == nullptr || where < 0 || (where > 7 && where < 1000) || where > 8063)
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 6");
   }

@@ -124,7 +124,9 @@ struct FlowSpin
 };
 // test hook (hrfd_rx_debug_expire(1000 p + g)): the service wave of generation g of workgroup 0 is held up for ~60 us behind
 // hand-over point p of its loop (1: FIR modes, part b handed over; 2: AM / SSB, part c; 3: SSB, 8 kS/s rails published;
-// 4: WBFM, partial sums published; 5: WBFM, verification; 6: WBFM, integer stages), while the generations behind it run on.
+// 4: WBFM, partial sums published; 5: WBFM, verification; 6: WBFM, integer stages), while the generations behind it run on;
+// 7: a stream wave behind publishing unit g (of every 64); 8: the workgroup of run g in front of its arrival at the channel's
+// count (channels cut into several runs: another workgroup finishes the channel then).
 // Nothing a held-up wave still has to read may be written over meanwhile: the parity tests run with it.
 __device__ __forceinline__ void flow_hold_up(const RxParams &P, const int point, const int g)
 {
@@ -885,6 +887,7 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
       pend = counted;
       pend_slot = slot;
       pend_blk = blk;
+      flow_hold_up(P, 7, u & 63);
       u = un;
       uoff = uoff_n;
       FLOW_MARK(7)
@@ -1950,6 +1953,13 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
       bool last = true;
       if (P.n_runs > 1u)
       {
+        if ((uint32_t)(P.dbg_flags >> 16) == 8000u + run && ci == 0u)
+        {
+          for (int z = 0; z < 15; z++)
+          {
+            __builtin_amdgcn_s_sleep(127);
+          }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t arrived = 0;

@@ -439,15 +439,19 @@ def test_closed_gates_are_redone_on_the_device(oracle, mode, run_len):
     assert any(len(want[c][b][0]) == 0 for c in range(C) for b in range(2 * B))
 
 
-@pytest.mark.parametrize("mode,point", [(AM, 1), (AM, 2), (LSB, 1), (LSB, 2), (LSB, 3), (FM, 1), (WBFM, 4), (WBFM, 5), (WBFM, 6)],
-                         ids=["am_b", "am_c", "lsb_b", "lsb_c", "lsb_rails", "fm_b", "wbfm_sums", "wbfm_verify", "wbfm_integer"])
+@pytest.mark.parametrize("mode,point", [(AM, 1), (AM, 2), (LSB, 1), (LSB, 2), (LSB, 3), (FM, 1), (WBFM, 4), (WBFM, 5), (WBFM, 6),
+                                        (WBFM, 7), (AM, 7), (FM, 7), (WBFM, 8)],
+                         ids=["am_b", "am_c", "lsb_b", "lsb_c", "lsb_rails", "fm_b", "wbfm_sums", "wbfm_verify", "wbfm_integer",
+                              "wbfm_stream", "am_stream", "fm_stream", "wbfm_arrival"])
 @pytest.mark.parametrize("gen", [0, 1, 6, 20])
 def test_a_held_up_service_wave_is_not_overtaken(oracle, mode, point, gen):
     """The service waves of the flow kernel hand generations over to each other at a few points and otherwise run side by
     side, over rings that hold a few generations (v: six; AM / SSB: four of the second decimator's output and of SSB's
     8 kS/s rails).  hrfd_rx_debug_expire(1000 p + g) holds the wave of generation g of workgroup 0 up for ~60 us right
     behind hand-over point p, while the generations behind it run on: none of them may write over what the held-up one
-    (and the one behind it) still have to read.  PCM = the oracle's, nothing reported as failed.  (Found as one SSB
+    (and the one behind it) still have to read.  Also held up: a stream wave behind publishing a unit (point 7), and a
+    workgroup in front of its arrival at its channel's count (point 8; the channels are cut into runs here, one block per
+    workgroup, so that another workgroup finishes the channel).  PCM = the oracle's, nothing reported as failed.  (Found as one SSB
     channel of a mixed bank with wrong PCM in one launch of many: AM / SSB let the four generations behind a wave that
     was slow between its part c and its 8 kS/s part write into its ring -- point 2 fails without the wait that was
     added for it.)"""
