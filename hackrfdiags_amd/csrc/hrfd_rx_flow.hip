@@ -130,6 +130,24 @@ struct FlowSpin
 // Nothing a held-up wave still has to read may be written over meanwhile: the parity tests run with it.
 __device__ __forceinline__ void flow_hold_up(const RxParams &P, const int point, const int g)
 {
+#ifdef HRFD_FLOW_CHAOS
+  // stress build (not shipped): EVERY wave of EVERY workgroup dawdles behind every hand-over point for a pseudo-random
+  // 0 .. ~14 us, differently in every launch -- the parity tests and the soak run against it
+  {
+    uint32_t x = (uint32_t)blockIdx.x * 0x9E3779B1u ^ (uint32_t)g * 0x85EBCA77u ^ (uint32_t)point * 0xC2B2AE3Du ^
+                 (uint32_t)__builtin_amdgcn_s_memrealtime();
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    if ((x & 3u) == 0u)
+    {
+      for (uint32_t z = (x >> 8) & 7u; z != 0u; z--)
+      {
+        __builtin_amdgcn_s_sleep(64);
+      }
+    }
+  }
+#endif
   if ((uint32_t)(P.dbg_flags >> 16) == 1000u * (uint32_t)point + (uint32_t)g && blockIdx.x == 0)
   {
     for (int z = 0; z < 15; z++)
