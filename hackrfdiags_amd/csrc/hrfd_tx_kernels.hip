@@ -734,6 +734,25 @@ constexpr int kPsCompute = HRFD_PS_CWAVE;
 __device__ __forceinline__ uint32_t ps_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void ps_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void ps_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// stress build -DHRFD_FLOW_CHAOS (not shipped): every mover and recurrence wave dawdles 0 .. ~14 us at random behind its hand-overs
+__device__ __forceinline__ void ps_dawdle(const uint32_t seed)
+{
+#ifdef HRFD_FLOW_CHAOS
+  uint32_t x = (uint32_t)blockIdx.x * 0x9E3779B1u ^ seed * 0x85EBCA77u ^ (uint32_t)__builtin_amdgcn_s_memrealtime();
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  if ((x & 7u) == 0u)
+  {
+    for (uint32_t z = (x >> 8) & 7u; z != 0u; z--)
+    {
+      __builtin_amdgcn_s_sleep(64);
+    }
+  }
+#else
+  (void)seed;
+#endif
+}
 
 // the reference's wrap (PhaseAccumulator.cc:166-176).  It does not terminate for an accumulator so large that
 // subtracting 2 pi no longer changes it; this one gives up after 64 turns.
@@ -921,6 +940,7 @@ __global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size
       {
         ps_st(&ctl[0], i);
       }
+      ps_dawdle(3u * i);
       chunk(cur, cur_flag, i);
       return true;
     };
@@ -997,6 +1017,7 @@ __global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size
       {
         ps_st(&ready[slot], (i + 1u) | (marked ? 0x80000000u : 0u));
       }
+      ps_dawdle(3u * i + 1u);
     }
   }
   else
@@ -1025,6 +1046,7 @@ __global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size
       {
         ps_st(&freed[slot], j + 1u);
       }
+      ps_dawdle(3u * j + 2u);
     }
   }
 }
