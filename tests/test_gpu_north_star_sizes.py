@@ -9,6 +9,7 @@ Each against the sequential CPU oracle on a spread of channels, plus size-indepe
 ALL channels: channels fed identical input give identical output, every launch committed (nothing was
 replayed), and the batch kernel (k_rx_wbfm_flow) and the block kernel (k_rx_wbfm) agree; a soak over
 60 launches of random input with gates closing at random."""
+import os
 import zlib
 
 import numpy as np
@@ -131,7 +132,7 @@ def test_soak_flow_shapes_agree_launch_after_launch():
     included; this is about the flow kernels' flag protocol and the device-side repair holding up under load, launch
     after launch, on input nobody chose.)"""
     import torch
-    C, B, launches = 256, 16, 60
+    C, B, launches = 256, 16, int(os.environ.get("HRFD_SOAK_LAUNCHES", "60"))   # (a long soak: HRFD_SOAK_LAUNCHES=2000)
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev)
     g.manual_seed(20260)
@@ -163,3 +164,30 @@ def test_soak_flow_shapes_agree_launch_after_launch():
         for a, b in zip(outs[0], outs[1]):
             assert torch.equal(a, b), it
     assert closed > launches * C                          # gates did close, all over the bank
+
+
+def test_soak_wbfm_flow_against_the_block_kernel():
+    """The same over the two WBFM kernels: 256 channels x 16 blocks of fresh random input per launch through
+    k_rx_wbfm_flow (one continuous stream per channel, tiles verified and repaired in the service waves) and through the
+    block kernel k_rx_wbfm (runs of blocks per workgroup, barriers between its phases) -- two implementations of the
+    speculation that share little code.  PCM and magnitudes identical launch after launch, everything committed."""
+    import torch
+    C, B, launches = 256, 16, int(os.environ.get("HRFD_SOAK_LAUNCHES", "30"))
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(777)
+    flow, block = api.Rx(C), api.Rx(C)
+    for rx in (flow, block):
+        rx.set_mode(api.WBFM)
+    block.debug_set_stream(0)
+    outs = [[torch.zeros((C, B, 512), dtype=torch.int16, device=dev), torch.zeros((C, B), dtype=torch.int32, device=dev)] for _ in range(2)]
+    for it in range(launches):
+        x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev, generator=g)
+        if it % 3 == 1:
+            x[:, :, ::2] = (x[:, :, ::2].to(torch.int16) >> 3).to(torch.int8)      # a weak I rail: other octants, other table rows
+        torch.cuda.synchronize()
+        for rx, o in zip((flow, block), outs):
+            rx.process_device(x.data_ptr(), B * BLK, BLK, B, o[0].data_ptr(), d_magnitude=o[1].data_ptr())
+        assert flow.sync() == 0 and block.sync() == 0, it
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b), it
