@@ -1004,14 +1004,14 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   //     squelch gates may close;
   //  3. the block kernels (one workgroup per channel-block: k_rx_wbfm, k_rx_fir + k_rx_post) with k_rx_finish behind
   //     them: single-block calls (the reference's cadence), the inner demodulator API, the exact replay of a subset,
-  //     block sizes that are not whole units of 512 samples at 256 kS/s, FIR-mode batches with the iq dump, small banks.
+  //     block sizes that are not whole units of 512 samples at 256 kS/s, small banks.
   // The flow shapes need whole units of two 4 KiB pieces per block, at most 64 blocks, and the first-octant table.
   P.dbg = nullptr;
   const uint32_t n_wb = list_count[HRFD_MODE_WBFM], n_as = list_count[7], n_fm = list_count[HRFD_MODE_FM];
   const bool batch = n_blocks > 1 && !opt.serial && !opt.src256 && opt.subset == nullptr;
   const bool flow_shape = batch && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 && (n256 % 512u) == 0 && n256 >= 2048u;
   const bool flow = flow_shape && n_wb != 0;              // the WBFM channels run on the flow kernel
-  const bool fir_shape = flow_shape && h->fir_flow != 0 && n_blocks <= 64u && d_iq256 == nullptr;
+  const bool fir_shape = flow_shape && h->fir_flow != 0 && n_blocks <= 64u;
   const int kinds = (n_wb != 0) + (n_as != 0) + (n_fm != 0);
   const bool bank = fir_shape && kinds >= 2 && n_blocks <= 16u && h->fir_flow != 2 && (h->fir_flow > 0 || list_count[9] >= 48u);
   const bool as_flow = !bank && fir_shape && n_as != 0 && (h->fir_flow > 0 || n_as >= 48u);
@@ -1044,17 +1044,21 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     P.self_finish = 1;                                     // the last workgroup of a channel finishes it (finish_channel)
     P.dbg_flags |= h->expire_once << 16;
     h->expire_once = 0;
+    const bool dump = d_iq256 != nullptr;                   // (`enable iqdump`: the 256 kS/s stream goes out of the stream waves as well)
     if (mode < 0)
     {
-      hipLaunchKernelGGL((k_rx_flow_bank<HRFD_FLOW_SVC>), dim3(grid), dim3(kThreads), 0, s, P);
+      if (dump) hipLaunchKernelGGL((k_rx_flow_bank<HRFD_FLOW_SVC, true>), dim3(grid), dim3(kThreads), 0, s, P);
+      else hipLaunchKernelGGL((k_rx_flow_bank<HRFD_FLOW_SVC, false>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     else if (mode == HRFD_MODE_FM)
     {
-      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 2>), dim3(grid), dim3(kThreads), 0, s, P);
+      if (dump) hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true, 2>), dim3(grid), dim3(kThreads), 0, s, P);
+      else hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 2>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     else if (mode != HRFD_MODE_WBFM)
     {
-      hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 14>), dim3(grid), dim3(kThreads), 0, s, P);
+      if (dump) hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true, 14>), dim3(grid), dim3(kThreads), 0, s, P);
+      else hipLaunchKernelGGL((k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false, 14>), dim3(grid), dim3(kThreads), 0, s, P);
     }
     else if (d_iq256 != nullptr)
     {

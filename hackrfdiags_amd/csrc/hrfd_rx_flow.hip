@@ -326,7 +326,6 @@ template <int SVC, bool GATED, bool DUMP, int MODE>
 __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds)
 {
   static_assert(MODE == 3 || MODE == 2 || MODE == 14, "WBFM, FM, AM / SSB");
-  static_assert(MODE == 3 || !DUMP, "the iq dump is WBFM's here (the block kernels write it for the FIR modes)");
   typedef FlowLds<MODE> Lds;
   constexpr bool kWb = (MODE == 3);
   constexpr bool kAtan = Lds::kAtan;
@@ -831,6 +830,11 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
         uint32_t mx[4];
         quad_front(ra, cy.fe, mx, refill_a);
         store_rails(mx, dst);
+        if (DUMP)
+        {
+          iqb[0] = __builtin_amdgcn_perm(mx[1], mx[0], 0x06040200u) ^ 0x80808080u;   // (as quad_piece forms them)
+          iqb[1] = __builtin_amdgcn_perm(mx[3], mx[2], 0x06040200u) ^ 0x80808080u;
+        }
       }
       if (DUMP)
       {
@@ -862,6 +866,11 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
         uint32_t mx[4];
         quad_front(rb, cy.fe, mx, refill_b);
         store_rails(mx, dst + 4 * kFStride);
+        if (DUMP)
+        {
+          iqb[0] = __builtin_amdgcn_perm(mx[1], mx[0], 0x06040200u) ^ 0x80808080u;
+          iqb[1] = __builtin_amdgcn_perm(mx[3], mx[2], 0x06040200u) ^ 0x80808080u;
+        }
       }
       if (DUMP)
       {
@@ -2029,7 +2038,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_wbfm_flow(const RxParams P)
 // the mode read from the channel's configuration -- no per-mode kernels, no streams to fork and join, no kernel
 // boundaries inside a step.  Every workgroup holds a whole CU and runs for about the same time (the call's blocks of
 // one channel), so a bank of as many channels as the chip has CUs is one round.
-template <int SVC>
+template <int SVC, bool DUMP = false>
 __global__ __launch_bounds__(kThreads, 4) void k_rx_flow_bank(const RxParams P)
 {
   constexpr int kDw = (FlowLds<3>::kTotal > FlowLds<2>::kTotal) ? ((FlowLds<3>::kTotal > FlowLds<14>::kTotal) ? FlowLds<3>::kTotal : FlowLds<14>::kTotal)
@@ -2043,19 +2052,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_rx_flow_bank(const RxParams P)
   const int mode = __builtin_amdgcn_readfirstlane(P.cfg[P.chan_list[ci]].mode);
   if (mode == 3)
   {
-    flow_body<SVC, false, false, 3>(P, lds);
+    flow_body<SVC, false, DUMP, 3>(P, lds);
   }
   else if (mode == 2)
   {
-    flow_body<SVC, false, false, 2>(P, lds);
+    flow_body<SVC, false, DUMP, 2>(P, lds);
   }
   else
   {
-    flow_body<SVC, false, false, 14>(P, lds);
+    flow_body<SVC, false, DUMP, 14>(P, lds);
   }
 }
 
-template __global__ void k_rx_flow_bank<HRFD_FLOW_SVC>(const RxParams);
+template __global__ void k_rx_flow_bank<HRFD_FLOW_SVC, false>(const RxParams);
+template __global__ void k_rx_flow_bank<HRFD_FLOW_SVC, true>(const RxParams);
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true, 2>(const RxParams);
+template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true, 14>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, false>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, false, true>(const RxParams);
 template __global__ void k_rx_wbfm_flow<HRFD_FLOW_SVC, true, false>(const RxParams);

@@ -135,7 +135,7 @@ def test_mixed_mode_bank(oracle, fir_flow):
     for c, m in enumerate(modes):
         rx.set_mode(m, channel=c)
     r1 = rx.process_block(xs[:, :B], B)
-    r2 = rx.process_block(xs[:, B:], B)
+    r2 = rx.process_block(xs[:, B:], B, want_iq256=True)  # (the second call with the iq dump: k_rx_flow_bank<DUMP> / <DUMP, MODE>)
     pcm = np.concatenate([r1[0], r2[0]], axis=1)
     npcm = np.concatenate([r1[1], r2[1]], axis=1)
     for c, m in enumerate(modes):
@@ -143,6 +143,8 @@ def test_mixed_mode_bank(oracle, fir_flow):
         for b in range(2 * B):
             assert npcm[c, b] == len(want[b][0])
             assert (pcm[c, b, :npcm[c, b]] == want[b][0]).all(), (c, m, b)
+            if b >= B:
+                assert (r2[4][c, b - B] == want[b][3]).all(), (c, m, b)      # the 256 kS/s stream of every channel, whatever its mode
 
 
 @pytest.mark.parametrize("mode", [AM, FM, WBFM, LSB])
