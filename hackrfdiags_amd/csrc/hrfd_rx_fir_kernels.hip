@@ -4,7 +4,7 @@
 //
 // These are the kernels of single-block calls (the reference's own cadence: one acceptIqData per 262144-byte block),
 // of the inner demodulator API, of the exact replay, of block sizes that are not whole units of 512 samples at
-// 256 kS/s, of batches with the iq dump and of small banks.  Batches of 48 channels or more run on the FIR modes of
+// 256 kS/s and of small banks.  Batches of 48 channels or more run on the FIR modes of
 // k_rx_wbfm_flow (hrfd_rx_flow.hip): one persistent workgroup per channel, no tail kernel.
 //
 //   k_rx_fir<FM>   tuner D(32,4) on both rails -> atan2 table -> theta[n-2]-theta[n-4]
