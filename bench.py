@@ -36,6 +36,8 @@ sys.path.insert(0, ROOT)
 # modulator take ~50 us instead of ~10 (measured: 5.2 ms per step against 4.7 in the same process);
 # nothing here needs more than two.  Read by the runtime when it starts, reported in the line as `runtime`.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+if "--serial-modes" in sys.argv or any(a.startswith("--force-") for a in sys.argv):
+    os.environ.setdefault("HRFD_DEBUG_HOOKS", "1")      # these flags use test hooks of include/hrfd_debug.h (inert otherwise)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -380,6 +381,33 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   return HRFD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The hrfd_*_debug_* entry points (include/hrfd_debug.h).  Two kinds:
+//   * read-only introspection and measurement (counters, kernel times, table evaluations): always available --
+//     bench.py's roofline figure comes from hrfd_rx_debug_kernel_ms;
+//   * hooks that CHANGE what the product does (another kernel, a shrunk warm-up, an expired wait or a held-up wave on
+//     purpose, the gated pass off, unsliced modulators): the test suite's means of forcing the failure and fallback paths.
+//     They are inert in a process that did not ask for them: without HRFD_DEBUG_HOOKS=1 in the environment (read once, at
+//     the first call) they return HRFD_ESTATE and change nothing, so a host application cannot be flipped onto those paths
+//     through the shipped library by accident or by a stray symbol lookup.
+// ---------------------------------------------------------------------------------------------
+static bool debug_hooks_enabled()
+{
+  static const bool on = [] {
+    const char *e = getenv("HRFD_DEBUG_HOOKS");
+    return e != nullptr && e[0] == '1' && e[1] == 0;
+  }();
+  return on;
+}
+#define HRFD_HOOK_GATE(name)                                                                                         \
+  do                                                                                                                 \
+  {                                                                                                                  \
+    if (!debug_hooks_enabled())                                                                                      \
+    {                                                                                                                \
+      return fail(HRFD_ESTATE, name ": behaviour-changing test hooks are off (set HRFD_DEBUG_HOOKS=1 in the environment)"); \
+    }                                                                                                                \
+  } while (0)
+
 // test hook: the arithmetic atan2 evaluated on the device for all 65536 (q, i) pairs, in the
 // layout of hrfd_atan2_table(); must equal that table bit for bit when the corrections fit
 static int atan_eval(hrfd_rx *h, float *out65536, bool tab);
@@ -427,6 +455,7 @@ static int atan_eval(hrfd_rx *h, float *out65536, bool tab)
 // 1 require the arithmetic kernel (fails if the corrections did not fit)
 extern "C" int hrfd_rx_debug_set_atan(hrfd_rx *h, int mode)
 {
+  HRFD_HOOK_GATE("hrfd_rx_debug_set_atan");
   if (h == nullptr || mode < -1 || mode > 1)
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_set_atan: -1, 0 or 1");
@@ -513,6 +542,7 @@ extern "C" int hrfd_rx_reset_demod(hrfd_rx *h, uint32_t channel, int mode)
 // speculation-failure / repair / replay paths can be exercised.  kWarm restores the default.
 extern "C" int hrfd_rx_debug_set_warm(hrfd_rx *h, int warm)
 {
+  HRFD_HOOK_GATE("hrfd_rx_debug_set_warm");
   if (h == nullptr || warm < 0 || warm > kWarm || (warm & 1))
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_set_warm: even, 0..%d", kWarm);
@@ -590,6 +620,7 @@ extern "C" int hrfd_rx_debug_stamps(hrfd_rx *h, uint32_t cap_groups, unsigned lo
 // test hook: consecutive blocks of a channel that one k_rx_wbfm workgroup walks (0 = automatic)
 extern "C" int hrfd_rx_debug_set_run_len(hrfd_rx *h, int blocks)
 {
+  HRFD_HOOK_GATE("hrfd_rx_debug_set_run_len");
   if (h == nullptr || blocks < 0 || blocks > 64)
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_set_run_len: 0..64");
@@ -602,6 +633,7 @@ extern "C" int hrfd_rx_debug_set_run_len(hrfd_rx *h, int blocks)
 // k_rx_wbfm_flow (one persistent workgroup per CU, a continuous stream); any other value: the default
 extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
 {
+  HRFD_HOOK_GATE("hrfd_rx_debug_set_stream");
   if (h == nullptr)
   {
     return fail(HRFD_EINVAL, "NULL");
@@ -618,6 +650,7 @@ extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
 // of its loop instead: flow_hold_up)
 extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
 {
+  HRFD_HOOK_GATE("hrfd_rx_debug_expire");
   if (h == nullptr || where < 0 || (where > 7 && where < 1000) || where > 8063)
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 6");
@@ -629,6 +662,7 @@ extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
 // test hook: AM / SSB / FM batches on the flow kernel's FIR modes: -1 automatic (banks of 48 channels or more per kind), 0 never, 1 always
 extern "C" int hrfd_rx_debug_set_fir_flow(hrfd_rx *h, int mode)
 {
+  HRFD_HOOK_GATE("hrfd_rx_debug_set_fir_flow");
   if (h == nullptr || mode < -1 || mode > 2)
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_set_fir_flow: -1, 0, 1 or 2");
@@ -640,6 +674,7 @@ extern "C" int hrfd_rx_debug_set_fir_flow(hrfd_rx *h, int mode)
 // test hook: 0 = no gated second pass on the device; a channel with a closed gate in a batch stays failed (the host replays it)
 extern "C" int hrfd_rx_debug_set_gated(hrfd_rx *h, int on)
 {
+  HRFD_HOOK_GATE("hrfd_rx_debug_set_gated");
   if (h == nullptr)
   {
     return fail(HRFD_EINVAL, "NULL");
@@ -650,6 +685,7 @@ extern "C" int hrfd_rx_debug_set_gated(hrfd_rx *h, int on)
 
 extern "C" int hrfd_rx_debug_set_stagger(hrfd_rx *h, int units)
 {
+  HRFD_HOOK_GATE("hrfd_rx_debug_set_stagger");
   if (h == nullptr || units < 0)
   {
     return fail(HRFD_EINVAL, "hrfd_rx_debug_set_stagger: 0..64");
@@ -2231,6 +2267,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
 // test hook: 0 = the WBFM modulator's passes one after the other on the caller's stream (no time slices)
 extern "C" int hrfd_mod_debug_set_sliced(hrfd_mod *h, int on)
 {
+  HRFD_HOOK_GATE("hrfd_mod_debug_set_sliced");
   if (h == nullptr)
   {
     return fail(HRFD_EINVAL, "NULL");

@@ -1,8 +1,12 @@
 // AmDemodulator.h -- drop-in replacement header: same class name and public
 // interface as radioDiags/AmDemodulator/AmDemodulator.h:23-31 of the reference,
 // implemented over the C ABI of libhrfd.so (hrfd_demod_*, include/hrfd.h).
-#ifndef HRFD_SHIM_AMDEMODULATOR_H
-#define HRFD_SHIM_AMDEMODULATOR_H
+// The include guard is the REFERENCE header's own: in a translation unit that has already seen the reference's
+// declaration of this class (Radio.h includes its neighbours by quoted name) this header must be a no-op, and the
+// other way round; the two declarations are interchangeable by construction (hrfd_shim_layout.h).
+#ifndef __AMDEMODULATOR__
+#define __AMDEMODULATOR__
+#define HRFD_SHIM_DECLARES_AMDEMODULATOR 1
 
 #include "hrfd_shim_base.h"
 

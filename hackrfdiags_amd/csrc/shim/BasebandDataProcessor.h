@@ -3,8 +3,12 @@
 // SURVEY 8a row T5), implemented over the C ABI of libhrfd.so: the PCM ring is hrfd_txring_* (same slots, start
 // table and pacing policy as BasebandDataProcessor.cc:416-606), the modulators are the shim's
 // Am/Fm/WbFm/SsbModulator classes (hrfd_mod_*).
-#ifndef HRFD_SHIM_BASEBANDDATAPROCESSOR_H
-#define HRFD_SHIM_BASEBANDDATAPROCESSOR_H
+// The include guard is the REFERENCE header's own: in a translation unit that has already seen the reference's
+// declaration of this class (Radio.h includes its neighbours by quoted name) this header must be a no-op, and the
+// other way round; the two declarations are interchangeable by construction (hrfd_shim_layout.h).
+#ifndef _BASEBANDDATAPROCESSOR_H_
+#define _BASEBANDDATAPROCESSOR_H_
+#define HRFD_SHIM_DECLARES_BASEBANDDATAPROCESSOR 1
 
 #include <stdint.h>
 #include <pthread.h>

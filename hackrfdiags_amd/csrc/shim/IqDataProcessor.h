@@ -2,8 +2,12 @@
 // interface as radioDiags/hdr_diags/IqDataProcessor.h:23-60 of the reference.
 // acceptIqData runs the fused GPU chain of libhrfd.so (hrfd_rx_process_block):
 // x8 half-band decimation, Fs/4 mix, squelch, demodulation in one launch.
-#ifndef HRFD_SHIM_IQDATAPROCESSOR_H
-#define HRFD_SHIM_IQDATAPROCESSOR_H
+// The include guard is the REFERENCE header's own: in a translation unit that has already seen the reference's
+// declaration of this class (Radio.h includes its neighbours by quoted name) this header must be a no-op, and the
+// other way round; the two declarations are interchangeable by construction (hrfd_shim_layout.h).
+#ifndef _IQDATAPROCESSOR_H_
+#define _IQDATAPROCESSOR_H_
+#define HRFD_SHIM_DECLARES_IQDATAPROCESSOR 1
 
 #include <stdint.h>
 
@@ -91,9 +95,17 @@ class IqDataProcessor
   void *signalMagnitudeCallbackContextPtr;
   void (*signalMagnitudeCallbackPtr)(uint32_t signalMagnitude,void *contextPtr);
 
-  float pushedGain[4];
-  int16_t pcmData[512];
-  int8_t decimatedData[32768];
+  // The buffers live in one heap block: every shim class stays within the size of the reference class of the same
+  // name (hrfd_shim_layout.h), so an application object compiled against the reference's hdr_diags/IqDataProcessor.h
+  // -- Radio.h:16 includes it by a quoted name from its own directory, which no -I order overrides -- that does
+  // `new IqDataProcessor` (Radio.cc:175) allocates enough for what the shim's member functions touch.
+  struct Work
+  {
+    float pushedGain[4];
+    int16_t pcmData[512];
+    int8_t decimatedData[32768];
+  };
+  Work *work;
 };
 
 #endif

@@ -1,8 +1,12 @@
 // SsbDemodulator.h -- drop-in replacement header: same class name and public
 // interface as radioDiags/SsbDemodulator/SsbDemodulator.h:24-34 of the reference,
 // implemented over the C ABI of libhrfd.so (hrfd_demod_*, include/hrfd.h).
-#ifndef HRFD_SHIM_SSBDEMODULATOR_H
-#define HRFD_SHIM_SSBDEMODULATOR_H
+// The include guard is the REFERENCE header's own: in a translation unit that has already seen the reference's
+// declaration of this class (Radio.h includes its neighbours by quoted name) this header must be a no-op, and the
+// other way round; the two declarations are interchangeable by construction (hrfd_shim_layout.h).
+#ifndef __SSBDEMODULATOR__
+#define __SSBDEMODULATOR__
+#define HRFD_SHIM_DECLARES_SSBDEMODULATOR 1
 
 #include "hrfd_shim_base.h"
 

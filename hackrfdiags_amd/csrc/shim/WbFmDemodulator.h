@@ -1,8 +1,12 @@
 // WbFmDemodulator.h -- drop-in replacement header: same class name and public
 // interface as radioDiags/WbFmDemodulator/WbFmDemodulator.h:23-31 of the reference,
 // implemented over the C ABI of libhrfd.so (hrfd_demod_*, include/hrfd.h).
-#ifndef HRFD_SHIM_WBFMDEMODULATOR_H
-#define HRFD_SHIM_WBFMDEMODULATOR_H
+// The include guard is the REFERENCE header's own: in a translation unit that has already seen the reference's
+// declaration of this class (Radio.h includes its neighbours by quoted name) this header must be a no-op, and the
+// other way round; the two declarations are interchangeable by construction (hrfd_shim_layout.h).
+#ifndef __WBFMDEMODULATOR__
+#define __WBFMDEMODULATOR__
+#define HRFD_SHIM_DECLARES_WBFMDEMODULATOR 1
 
 #include "hrfd_shim_base.h"
 

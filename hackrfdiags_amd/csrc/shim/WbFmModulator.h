@@ -1,8 +1,12 @@
 // WbFmModulator.h -- drop-in replacement header: same class name and public interface
 // as radioDiags/WbFmModulator/WbFmModulator.h:20-33 of the reference, implemented over
 // the C ABI of libhrfd.so (hrfd_mod_*, include/hrfd.h).
-#ifndef HRFD_SHIM_WBFMMODULATOR_H
-#define HRFD_SHIM_WBFMMODULATOR_H
+// The include guard is the REFERENCE header's own: in a translation unit that has already seen the reference's
+// declaration of this class (Radio.h includes its neighbours by quoted name) this header must be a no-op, and the
+// other way round; the two declarations are interchangeable by construction (hrfd_shim_layout.h).
+#ifndef __WBFMMODULATOR__
+#define __WBFMMODULATOR__
+#define HRFD_SHIM_DECLARES_WBFMMODULATOR 1
 
 #include <stdint.h>
 

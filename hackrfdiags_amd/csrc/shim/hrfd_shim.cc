@@ -22,6 +22,19 @@
 #include "WbFmModulator.h"
 #include "Nco.h"
 #include "DataProvider.h"
+#include "BasebandDataProcessor.h"
+
+// This file defines the member functions of the SHIM's class declarations.  Its quoted includes find the shim's headers
+// beside it before any -I directory; should a build arrange otherwise (the headers share the reference's include
+// guards, so the first one seen wins), stop here instead of compiling member functions against the wrong layout.
+#if !defined(HRFD_SHIM_DECLARES_IQDATAPROCESSOR) || !defined(HRFD_SHIM_DECLARES_BASEBANDDATAPROCESSOR) || \
+    !defined(HRFD_SHIM_DECLARES_DATAPROVIDER) || !defined(HRFD_SHIM_DECLARES_WBFMDEMODULATOR) || \
+    !defined(HRFD_SHIM_DECLARES_FMDEMODULATOR) || !defined(HRFD_SHIM_DECLARES_AMDEMODULATOR) || \
+    !defined(HRFD_SHIM_DECLARES_SSBDEMODULATOR) || !defined(HRFD_SHIM_DECLARES_AMMODULATOR) || \
+    !defined(HRFD_SHIM_DECLARES_FMMODULATOR) || !defined(HRFD_SHIM_DECLARES_WBFMMODULATOR) || \
+    !defined(HRFD_SHIM_DECLARES_SSBMODULATOR) || !defined(HRFD_SHIM_DECLARES_NCO)
+#error "hrfd_shim.cc must see the shim's own class declarations (hackrfdiags_amd/csrc/shim/*.h), not the reference's"
+#endif
 
 // symbols of the host application the reference code also expects
 // (Radio.cc:15, diagUi.cc:2881)
@@ -177,7 +190,9 @@ IqDataProcessor::IqDataProcessor(char *hostIpAddress,int hostPort)
   signalMagnitudeNotificationEnabled = false;
   signalMagnitudeCallbackPtr = NULL;
   signalMagnitudeCallbackContextPtr = NULL;
-  for (int i = 0; i < 4; i++) pushedGain[i] = nanf("");
+  work = new Work();
+  memset(work, 0, sizeof(Work));
+  for (int i = 0; i < 4; i++) work->pushedGain[i] = nanf("");
 }
 
 IqDataProcessor::~IqDataProcessor(void)
@@ -190,6 +205,7 @@ IqDataProcessor::~IqDataProcessor(void)
   {
     hrfd_rx_destroy(handle);
   }
+  delete work;
 }
 
 void IqDataProcessor::ensureHandle(void)
@@ -214,10 +230,10 @@ void IqDataProcessor::pushGains(void)
   const int modes[4] = {HRFD_MODE_AM, HRFD_MODE_FM, HRFD_MODE_WBFM, HRFD_MODE_LSB};
   for (int i = 0; i < 4; i++)
   {
-    if (d[i] != NULL && !(d[i]->currentGain() == pushedGain[i]))
+    if (d[i] != NULL && !(d[i]->currentGain() == work->pushedGain[i]))
     {
-      pushedGain[i] = d[i]->currentGain();
-      int rc = hrfd_rx_set_gain(handle, 0, modes[i], pushedGain[i]);
+      work->pushedGain[i] = d[i]->currentGain();
+      int rc = hrfd_rx_set_gain(handle, 0, modes[i], work->pushedGain[i]);
       if (rc != HRFD_OK) fatal("hrfd_rx_set_gain", rc);
     }
   }
@@ -256,6 +272,8 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
 {
   uint32_t sampleCount = 0, signalMagnitude = 0;
   uint8_t signalAllowed = 0;
+  int16_t *const pcmData = work->pcmData;
+  int8_t *const decimatedData = work->decimatedData;
   (void)timeStamp;
 
   ensureHandle();
@@ -314,9 +332,9 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
 uint32_t IqDataProcessor::reduceSampleRate(int8_t *bufferPtr,uint32_t bufferLength)
 {
   ensureHandle();
-  const int rc = hrfd_rx_reduce_sample_rate(handle, bufferPtr, bufferLength, decimatedData);
+  const int rc = hrfd_rx_reduce_sample_rate(handle, bufferPtr, bufferLength, work->decimatedData);
   if (rc != HRFD_OK) fatal("reduceSampleRate", rc);
-  downconvertByFsOver4(decimatedData, bufferLength / 8);
+  downconvertByFsOver4(work->decimatedData, bufferLength / 8);
   return bufferLength / 8;
 }
 
@@ -726,8 +744,6 @@ void DataProvider::displayInternalInformation(void)
 // ---------------------------------------------------------------------------------------------
 #include <sys/select.h>
 
-#include "BasebandDataProcessor.h"
-
 BasebandDataProcessor::BasebandDataProcessor(void)
     : ring(NULL), running_state(Idle), mode_now(None), am_mod(NULL), fm_mod(NULL),
       wbfm_mod(NULL), ssb_mod(NULL), reader_must_stop(false), reader_running(false),
@@ -867,3 +883,22 @@ void BasebandDataProcessor::displayInternalInformation(void)
   nprintf(stderr, "PCM Writer Index          : %u\n", st[4]);
   nprintf(stderr, "PCM Reader Index          : %u\n", st[5]);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Layout containment (hrfd_shim_layout.h): application objects compiled against the reference's own headers may
+// allocate these classes; what they allocate must be enough for the shim.
+// ---------------------------------------------------------------------------------------------
+#include "hrfd_shim_layout.h"
+
+HRFD_SHIM_FITS(IqDataProcessor);
+HRFD_SHIM_FITS(BasebandDataProcessor);
+HRFD_SHIM_FITS(DataProvider);
+HRFD_SHIM_FITS(AmDemodulator);
+HRFD_SHIM_FITS(FmDemodulator);
+HRFD_SHIM_FITS(WbFmDemodulator);
+HRFD_SHIM_FITS(SsbDemodulator);
+HRFD_SHIM_FITS(AmModulator);
+HRFD_SHIM_FITS(FmModulator);
+HRFD_SHIM_FITS(WbFmModulator);
+HRFD_SHIM_FITS(SsbModulator);
+HRFD_SHIM_FITS(Nco);

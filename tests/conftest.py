@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the suite forces the library's failure and fallback paths through the behaviour-changing hooks of include/hrfd_debug.h;
+# they are inert in a process that did not ask for them (read once by libhrfd, so set before it is loaded)
+os.environ.setdefault("HRFD_DEBUG_HOOKS", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -21,8 +21,8 @@ def lib():
     return _lib.load()
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "hrfd.h")).read()
+def declared_symbols(header="hrfd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(hrfd_[a-z0-9_]+)\s*\(", text)))
 
@@ -32,6 +32,40 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(names) >= 30
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in include/hrfd.h but not exported: {missing}"
+
+
+def test_debug_entry_points_are_declared_and_nothing_else_is_exported(lib):
+    """every hrfd_* symbol the shipped library exports is declared in include/hrfd.h (the drop-in boundary) or in
+    include/hrfd_debug.h (introspection, and test hooks that are inert without HRFD_DEBUG_HOOKS=1)"""
+    import subprocess
+    debug = declared_symbols("hrfd_debug.h")
+    assert all("_debug_" in n for n in debug) and len(debug) >= 15
+    assert not [n for n in debug if not hasattr(lib, n)]
+    assert not [n for n in declared_symbols() if "_debug_" in n], "hrfd.h is the boundary: no debug entry in it"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted(set(re.findall(r" T (hrfd_[a-z0-9_]+)$", out, flags=re.M)))
+    known = set(declared_symbols()) | set(debug)
+    assert not [n for n in exported if n not in known], "exported but declared in neither header"
+
+
+def test_behaviour_changing_hooks_are_inert_without_the_opt_in():
+    """a process that did not start with HRFD_DEBUG_HOOKS=1 cannot flip the library onto its test paths: the hooks
+    return HRFD_ESTATE before they look at their arguments (so this needs no GPU)"""
+    import subprocess, sys
+    code = (
+        "import ctypes, sys; sys.path.insert(0, %r)\n"
+        "from hackrfdiags_amd import _lib\n"
+        "L = _lib.load()\n"
+        "names = ['hrfd_rx_debug_set_atan', 'hrfd_rx_debug_set_warm', 'hrfd_rx_debug_set_run_len', 'hrfd_rx_debug_set_stream',\n"
+        "         'hrfd_rx_debug_expire', 'hrfd_rx_debug_set_fir_flow', 'hrfd_rx_debug_set_gated', 'hrfd_rx_debug_set_stagger',\n"
+        "         'hrfd_mod_debug_set_sliced']\n"
+        "rcs = [getattr(L, n)(None, 0) for n in names]\n"
+        "print(rcs, L.hrfd_last_error().decode())\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "HRFD_DEBUG_HOOKS"}
+    off = subprocess.check_output([sys.executable, "-c", code], env=env, text=True)
+    assert off.startswith("[-4, -4, -4, -4, -4, -4, -4, -4, -4]") and "HRFD_DEBUG_HOOKS" in off
+    on = subprocess.check_output([sys.executable, "-c", code], env={**env, "HRFD_DEBUG_HOOKS": "1"}, text=True)
+    assert on.startswith("[-1, -1, -1, -1, -1, -1, -1, -1, -1]")       # HRFD_EINVAL: they looked at the NULL handle
 
 
 def test_no_cpu_fallback(lib):

@@ -8,6 +8,7 @@ compiler flags; `run` times the WBFM kernel of each variant (own process, HIP
 events) on the default bench workload and checks the PCM digest is identical.
 """
 import os, subprocess, sys
+os.environ.setdefault("HRFD_DEBUG_HOOKS", "1")   # the children use test hooks of include/hrfd_debug.h
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(ROOT, "hackrfdiags_amd", "lib", "variants")
 
