@@ -121,6 +121,10 @@ class Rx:
         """HIP events around the demodulator kernels of every launch (slot = launch % slots)."""
         check(self.L.hrfd_rx_debug_enable_timing(self.h, int(slots)), "hrfd_rx_debug_enable_timing")
 
+    def debug_timing_every(self, n: int):
+        """bracket only every n-th launch with events (the others run back to back, as in a host that does not measure)"""
+        check(self.L.hrfd_rx_debug_timing_every(self.h, int(n)), "hrfd_rx_debug_timing_every")
+
     def debug_kernel_ms(self, slot=0) -> float:
         ms = C.c_float(0)
         check(self.L.hrfd_rx_debug_kernel_ms(self.h, int(slot), C.byref(ms)), "hrfd_rx_debug_kernel_ms")

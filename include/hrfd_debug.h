@@ -25,6 +25,9 @@ int hrfd_rx_debug_counters(hrfd_rx *h, uint32_t *out8);
  * after a sync hrfd_rx_debug_kernel_ms(slot) is that launch's time: bench.py's roofline.achieved */
 int hrfd_rx_debug_enable_timing(hrfd_rx *h, int slots);
 int hrfd_rx_debug_kernel_ms(hrfd_rx *h, int slot, float *ms);
+/* bracket only every n-th launch (an event record costs ~3 us of queue time: bracketing every launch of a back-to-back
+ * sequence puts a gap between kernels that a host which does not measure never sees) */
+int hrfd_rx_debug_timing_every(hrfd_rx *h, int n);
 /* the device's atan2 (arithmetic form / first-octant-table form) for all 65536 (q, i): must equal hrfd_atan2_table() */
 int hrfd_rx_debug_atan_eval(hrfd_rx *h, float *out65536);
 int hrfd_rx_debug_atan_eval_tab(hrfd_rx *h, float *out65536);

@@ -191,3 +191,46 @@ def test_soak_wbfm_flow_against_the_block_kernel():
         assert flow.sync() == 0 and block.sync() == 0, it
         for a, b in zip(outs[0], outs[1]):
             assert torch.equal(a, b), it
+
+
+@pytest.mark.parametrize("kind", ["wbfm", "mixed"])
+def test_realtime_cadence_1024_channels_one_block_per_batch(oracle, kind):
+    """The north star's target in the reference's own cadence (bench.py `also.realtime_1024x1`): 1024 channels, ONE
+    262144-byte block per channel per batch (hackRf/hackrf.c:100-101, DataConsumer.cc:219-262), from pinned host memory
+    through hrfd_ingest_*, PCM back on the host, batch after batch with the streams continuing.  Four batches; PCM,
+    magnitude and gate of a spread of channels against the sequential oracle, and every channel against the channel
+    that was fed the same input."""
+    C, NB = 1024, 4
+    modes = [AM, FM, WBFM, LSB]
+    amodes = [api.AM, api.FM, api.WBFM, api.LSB]
+    base = [synth.make_input("fmtone" if k % 2 else "lcg", 900 + k, NB).reshape(NB, BLK) for k in range(NBASE)]
+    rx = api.Rx(C)
+    if kind == "mixed":
+        for c in range(C):
+            rx.set_mode(amodes[(4 * c) // C], channel=c)
+    else:
+        rx.set_mode(api.WBFM)
+    ing = api.Ingest(rx, BLK, 1, 2)
+    got = []
+    for t in range(NB):
+        slot = ing.acquire()
+        for k in range(NBASE):
+            slot[k::NBASE, 0] = base[k][t]
+        ing.submit(0)
+        got.append(ing.collect())
+    assert ing.replayed() == 0
+    ing.close()
+    quarters = range(4) if kind == "mixed" else [2]
+    for q in quarters:
+        lo, hi = (q * C // 4, (q + 1) * C // 4) if kind == "mixed" else (0, C)
+        for k in range(NBASE):
+            o = oracle.rx()
+            o.set_mode(modes[q])
+            first = lo + ((k - lo) % NBASE)              # the first channel of this quarter with base input k
+            for t in range(NB):
+                p, m, a, _ = o.process(base[k][t])
+                pcm, n_pcm, mag, allowed = got[t]
+                assert n_pcm[first, 0] == 512 and bool(allowed[first, 0]) == a and int(mag[first, 0]) == m, (q, k, t)
+                assert (pcm[first, 0] == p).all(), (q, k, t)
+                same = np.arange(first, hi, NBASE)
+                assert (pcm[same, 0] == pcm[first, 0]).all() and (mag[same, 0] == mag[first, 0]).all(), (q, k, t)
