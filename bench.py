@@ -331,6 +331,81 @@ def bench_ingest(args, api, device, rank, world, dist):
         dist.destroy_process_group()
 
 
+def bench_fanout(args, api, device, rank, world):
+    """BASELINE config 4's shape in ONE process (hrfd_fanout_*: what a C++ host that owns all the radios links against):
+    `channels` WBFM channels in `shards` contiguous shards, the IQ of the whole bank resident on device 0, scattered to
+    the shards' devices (peer copies; a copy on the device itself where a shard sits on the source device), every shard
+    demodulated, the PCM gathered back.  With fewer devices than shards the shards share devices round robin -- on a
+    one-GPU box all of them sit on device 0 and the line says so: the scatter is then device-local copies, NOT xGMI."""
+    C, B, S = args.channels, args.blocks, args.shards
+    n_dev = torch.cuda.device_count()
+    devices = [g % n_dev for g in range(S)]
+    fo = api.Fanout(C, devices)
+    fo.set_mode(api.WBFM)
+    base = make_fm_batch(32, B, device)                  # 32 distinct channels (the tone depends on c mod 32 anyway)
+    idx = torch.arange(C, device=device) % 32
+    x = base[idx]                                        # [C][B][262144] on device 0
+    del base
+    pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=device)
+    n_pcm = torch.zeros((C, B), dtype=torch.int32, device=device)
+    torch.cuda.synchronize()
+
+    def sync_all():
+        for d in sorted(set(devices) | {device.index}):
+            torch.cuda.synchronize(d)
+
+    def step(times=None):
+        t0 = time.perf_counter()
+        fo.scatter(device.index, x.data_ptr(), BLOCK, B)
+        sync_all()
+        t1 = time.perf_counter()
+        fo.process(0)
+        sync_all()
+        t2 = time.perf_counter()
+        replayed = fo.collect(device.index, pcm.data_ptr(), n_pcm.data_ptr())
+        sync_all()
+        t3 = time.perf_counter()
+        if times is not None:
+            times.append((t1 - t0, t2 - t1, t3 - t2, replayed))
+
+    for _ in range(args.warmup):
+        step()
+    times = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(times)
+    elapsed = time.perf_counter() - t0
+    sc, pr, co = (1e3 * float(np.mean([t[i] for t in times])) for i in range(3))
+    samples = C * B * (BLOCK // 2)
+    algo = C * B * (BLOCK + 1024 + 4)
+    produced = int(n_pcm.sum().item())
+    line = {
+        "metric": "IQ MSamples/s demodulated (2.048 MS/s->8 kS/s WBFM), one process over several shards (hrfd_fanout_*)",
+        "value": round(samples * args.steps / elapsed / 1e6, 1), "unit": "MSamples/s", "n_gpus": len(set(devices)),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "int8 IQ -> Q15 int16/int32 + f32 recurrence -> int16 PCM", "data": "synthetic",
+        "config": {"workload": f"{C} WBFM channels in {S} shards of {C // S} (BASELINE config 4's shape), {B} blocks per channel per step, "
+                               f"IQ of the whole bank resident on device {device.index}; shards on devices {devices}"
+                               + ("" if len(set(devices)) == S else
+                                  f" -- {len(set(devices))} device(s) for {S} shards: the scatter is device-local copies here, "
+                                  "NOT xGMI; unmeasured over xGMI until an 8-GPU node runs this"),
+                   "channels": C, "shards": S, "blocks_per_step": B},
+        "phases_ms": {"scatter": round(sc, 4), "process": round(pr, 4), "collect": round(co, 4),
+                      "note": "host clock, every phase closed with a device synchronize; in a pipeline the scatter of batch "
+                              "k+1 runs beside the kernels of batch k (separate streams per shard)"},
+        "scatter_GBps": round(C * B * BLOCK / (sc * 1e-3) / 1e9, 1),
+        "roofline": {"bound": "hbm", "achieved": round(algo / (pr * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS * len(set(devices)),
+                     "unit": "GB/s", "frac": round(algo / (pr * 1e-3) / 1e9 / (HBM_PEAK_GBS * len(set(devices))), 4), "traffic": None,
+                     "kernel": "hrfd::k_rx_wbfm_flow<4, false, false, WBFM>, one launch per shard (process phase, host clock)"},
+        "verification": {"channels_replayed": int(sum(t[3] for t in times)), "pcm_samples": produced, "pcm_expected": C * B * 512},
+    }
+    if produced != C * B * 512 or line["verification"]["channels_replayed"]:
+        line["invalid"] = "PCM count or replays"
+    print(json.dumps(line), flush=True)
+    fo.close()
+
+
 def kernel_source_tag():
     """sha256 (first 16 hex digits) of the kernel sources: ties a committed PMC summary to the code it measured"""
     import hashlib
@@ -708,7 +783,7 @@ def main():
                          "(config 4: 4096 channels over 8 GPUs), 1024 for the modulator workloads (config 5)")
     ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
     ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")
-    ap.add_argument("--workload", choices=["wbfm", "mixed", "am", "fm", "ssb", "ssbmod", "ammod", "fmmod", "wbfmmod", "ingest"], default="wbfm",
+    ap.add_argument("--workload", choices=["wbfm", "mixed", "am", "fm", "ssb", "ssbmod", "ammod", "fmmod", "wbfmmod", "ingest", "fanout"], default="wbfm",
                     help="wbfm = BASELINE config 2 (the headline); mixed = config 3 (AM+FM+WBFM+SSB bank, "
                          "per-mode dispatch); ssbmod = config 5 (SSB modulator, 8-stage x256 interpolator)")
     ap.add_argument("--scatter", action="store_true",
@@ -721,6 +796,7 @@ def main():
                     help="mixed bank: one kernel per mode, one after the other (test hook; default: ONE launch, the mode read per workgroup)")
     ap.add_argument("--stride-pad", type=int, default=0,
                     help="experiment: extra bytes between the channels' input buffers (channel_stride = blocks * 262144 + pad)")
+    ap.add_argument("--shards", type=int, default=8, help="--workload fanout: shards of the bank (config 4: 8)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -730,7 +806,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.channels <= 0:
-        args.channels = 1024 if args.workload in MOD_KINDS else (256 if world == 1 else 512)
+        args.channels = 1024 if args.workload in MOD_KINDS else 4096 if args.workload == "fanout" else (256 if world == 1 else 512)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -758,6 +834,10 @@ def main():
         return bench_mod(args, api, device, rank, world, dist)
     if args.workload == "ingest":
         return bench_ingest(args, api, device, rank, world, dist)
+    if args.workload == "fanout":
+        if world != 1:
+            raise SystemExit("--workload fanout is the one-process path: run it without torchrun")
+        return bench_fanout(args, api, device, rank, world)
 
     C, B = args.channels, args.blocks
     # The clock governor needs ~25 ms of this load before it holds its clock (profiles/README.md): when

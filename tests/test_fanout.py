@@ -62,3 +62,46 @@ def test_fanout_on_one_device_equals_one_handle_and_the_oracle(oracle, n_shards,
                 p = o.process(xs[c, b])[0]
                 if b >= half * B:
                     assert gn[c, b - half * B] == len(p) and (got[c, b - half * B, :len(p)] == p).all(), (half, c, b)
+
+
+@pytest.mark.gpu
+def test_config4_full_size_through_the_fanout_on_one_device(oracle):
+    """BASELINE config 4 as far as one GPU allows: 4096 WBFM channels x 16 blocks (16 GiB of IQ on the source device)
+    through hrfd_fanout_* with EIGHT shards of 512 channels -- all eight on device 0 here; on an 8-GPU node the same
+    calls put one shard on each GPU and the scatter's copies go over xGMI (unmeasured until such a node exists).
+    Two batches (every stream continues).  A spread of channels against the sequential oracle; every one of the 4096
+    against the channel that was fed the same input; nothing replayed."""
+    import torch
+    C, B, NSH = 4096, 16, 8
+    NBASE = 8
+    dev = torch.device("cuda:0")
+    base = np.stack([synth.make_input("fmtone" if k % 2 else "lcg", 800 + k, 2 * B).reshape(2 * B, BLK) for k in range(NBASE)])
+    assert [api.fanout_channel_range(C, NSH, g) for g in range(NSH)] == [(512 * g, 512) for g in range(NSH)]
+    fo = api.Fanout(C, [0] * NSH)
+    fo.set_mode(api.WBFM)
+    idx = (torch.arange(C, device=dev) % NBASE)
+    out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+    npcm = torch.zeros((C, B), dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    for half in range(2):
+        with torch.cuda.stream(s):
+            bdev = torch.from_numpy(base[:, half * B:(half + 1) * B].copy()).to(dev)      # [NBASE, B, BLK]
+            x = bdev[idx]                                                                  # [4096, 16, 262144]: 16 GiB
+        fo.scatter(0, x.data_ptr(), BLK, B, src_stream=s.cuda_stream)
+        fo.process(0)
+        assert fo.collect(0, out.data_ptr(), npcm.data_ptr()) == 0, "a channel was replayed"
+        torch.cuda.synchronize()
+        del x
+        assert int(npcm.sum().item()) == C * B * 512
+        # every channel equals the first channel with its input, on the device (64 MiB of PCM)
+        assert bool((out.view(C // NBASE, NBASE, B, 512) == out[:NBASE].unsqueeze(0)).all())
+        got = out[:NBASE].cpu().numpy()
+        for k in range(NBASE):
+            o = oracle.rx()
+            o.set_mode(WBFM)
+            for b in range((half + 1) * B):
+                p = o.process(base[k, b])[0]
+                if b >= half * B:
+                    assert (got[k, b - half * B] == p).all(), (half, k, b)
+    fo.close()
+    torch.cuda.empty_cache()

@@ -86,3 +86,65 @@ def test_scatter_demodulate_gather_gloo(world, n_channels):
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(world))
     assert all(results[r] for r in range(world)), results
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The same path with libhrfd in the middle (GPU box).  A one-GPU box cannot run RCCL between two ranks (RCCL refuses
+# two ranks on one device), so the ranks meet over gloo with host-staged shards -- rendezvous, sharding, scatter,
+# every rank's hrfd_rx on its own channels with its own resident state, gather, MAX over ranks are the code of
+# bench.py --gpus N / shard.py -- and share GPU 0.  What a multi-GPU node adds is the transport (RCCL instead of
+# gloo) and one device per rank: unmeasured over xGMI until the driver has such a node.
+# ---------------------------------------------------------------------------------------------------------------
+def _gpu_worker(rank, world, port, n_channels, blocks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hackrfdiags_amd import api
+    BLK = synth.BLOCK_BYTES
+    lo, hi = shard.channel_range(rank, world, n_channels)
+    ref = _inputs(n_channels, 2 * blocks) if rank == 0 else None
+    mine = torch.zeros((hi - lo, blocks, BLK), dtype=torch.int8)
+    allpcm = torch.zeros((n_channels, blocks, 512), dtype=torch.int16) if rank == 0 else None
+    rx = api.Rx(hi - lo, device=0)                          # this rank's shard: its channels' state lives here for the whole stream
+    rx.set_mode(api.WBFM)
+    ok = True
+    got = []
+    for step in range(2):                                   # two consecutive batches: the shards' streams continue
+        iq_all = torch.from_numpy(ref[:, step * blocks:(step + 1) * blocks].copy()).contiguous() if rank == 0 else None
+        shard.scatter_iq(iq_all, mine, n_channels)
+        pcm = rx.process_block(mine.numpy(), blocks)[0]      # libhrfd on the rank's shard (flow kernel: blocks > 1)
+        shard.gather_pcm(torch.from_numpy(np.ascontiguousarray(pcm)), allpcm, n_channels)
+        if rank == 0:
+            got.append(allpcm.numpy().copy())
+    if rank == 0:
+        one = api.Rx(n_channels, device=0)                  # ONE handle over the whole bank, same batches
+        one.set_mode(api.WBFM)
+        for step in range(2):
+            want = one.process_block(ref[:, step * blocks:(step + 1) * blocks], blocks)[0]
+            ok = ok and bool((got[step] == want).all())
+        full = _oracle_pcm(ref)                              # and the sequential CPU oracle
+        ok = ok and bool((np.concatenate(got, axis=1) == full).all())
+    t = shard.max_over_ranks(0.25 * (rank + 1), torch.device("cpu"))
+    ok = ok and abs(t - 0.25 * world) < 1e-9
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_channels", [(2, 6), (3, 7)])
+def test_ranks_run_libhrfd_on_their_shards(world, n_channels):
+    from tests.reflib import build_oracle
+    build_oracle()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + world * 7 + n_channels
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n_channels, 3, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=10) for _ in range(world))
+    assert all(results[r] for r in range(world)), results
