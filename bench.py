@@ -43,7 +43,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 BLOCK = 262144
-SETTLE_STEPS = 100        # untimed launches in front of the timed region, at least (clock settling)
+# untimed launches in front of the timed region, at least (clock settling); HRFD_BENCH_SETTLE=0 for counter passes,
+# where every dispatch is serialized by the profiler and the clock is not what is measured
+SETTLE_STEPS = int(os.environ.get("HRFD_BENCH_SETTLE", "100"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -242,7 +244,9 @@ def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle,
     algo_bytes = C * n * (2 + 512)
     mean_ms = float(np.mean(kernel_ms))
     achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
-    fill = stream_fill_gbs(device, out) if (rank == 0 and extras) else None
+    fill = stream_gbs(device, 1, out) if (rank == 0 and extras) else None
+    if fill is not None:
+        assert achieved <= fill, f"the modulator writes faster ({achieved:.0f} GB/s) than a kernel that does nothing else ({fill:.0f}): a denominator is wrong"
     m.close()
     del out, pcm
     torch.cuda.empty_cache()                             # the next workload of the line starts from a clean allocator
@@ -250,8 +254,8 @@ def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle,
         "kname": kname, "value": world * samples * steps / elapsed / 1e6, "ms_per_step": 1e3 * elapsed / steps,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "measured_stream_fill_GBps": None if fill is None else round(fill, 1),
-                     "frac_of_measured_fill": None if fill is None else round(achieved / fill, 4),
+                     "measured_stream_write_GBps": None if fill is None else round(fill, 1),
+                     "frac_of_measured_write": None if fill is None else round(achieved / fill, 4),
                      "kernel": MOD_KERNELS.get(workload, "k_am_rails / k_fm_phase + k_fm_rails, then hrfd::k_mod<100>"),
                      "kernel_ms_mean": round(mean_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
                      "algorithmic_bytes_per_launch": algo_bytes},
@@ -265,6 +269,10 @@ def bench_mod(args, api, device, rank, world, dist):
     r = measure_mod(api, shard, device, dist, args.workload, C, B, args.steps, args.warmup, settle, rank, world,
                     extras=not args.no_extras)
     kname = r["kname"]
+    t, src = pmc_traffic(f"{args.workload}_{C}x{B}")
+    r["roofline"]["traffic"] = t
+    r["roofline"]["traffic_source"] = src
+    r["roofline"]["traffic_over_algorithmic"] = None if t is None else round(t / r["roofline"]["algorithmic_bytes_per_launch"], 4)
     if rank == 0:
         print(json.dumps({
             "metric": f"IQ MSamples/s modulated (8 kS/s PCM -> 2.048 MS/s int8 IQ, {kname}) per GPU; % HBM roofline",
@@ -406,8 +414,32 @@ def bench_fanout(args, api, device, rank, world):
     fo.close()
 
 
+def kernel_code_tag():
+    """sha256 (first 16 hex digits) of the DEVICE CODE libhrfd.so carries -- the .hip_fatbin section, i.e. the compiled
+    gfx950 code objects -- so that a committed PMC summary is tied to the code it measured and to nothing else (until
+    round 4 the tag hashed the sources: a comment edit invalidated every summary)."""
+    import hashlib
+    import struct
+    from hackrfdiags_amd import _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        elf = f.read()
+    assert elf[:4] == b"\x7fELF" and elf[4] == 2, "libhrfd.so: not a 64-bit ELF"
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", elf, 0x3A)
+    def sec(i):
+        name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", elf, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sec(shstrndx)
+    names = elf[stroff:stroff + strsize]
+    for i in range(shnum):
+        name, off, size = sec(i)
+        if names[name:names.index(b"\0", name)] == b".hip_fatbin":
+            return hashlib.sha256(elf[off:off + size]).hexdigest()[:16]
+    raise RuntimeError("libhrfd.so has no .hip_fatbin section")
+
+
 def kernel_source_tag():
-    """sha256 (first 16 hex digits) of the kernel sources: ties a committed PMC summary to the code it measured"""
+    """(kept as a second field of the line: sha256 of the kernel sources, comments included)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "hackrfdiags_amd", "csrc")
@@ -418,59 +450,61 @@ def kernel_source_tag():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic_bytes(args, C, B):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile_round.sh
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs of this same command; the summary
-    is committed under profiles/).  gfx950: FETCH_SIZE counts 64 B per 128-B request for wide
-    coalesced reads, hence the factor 2 (MI355X_MICROARCH.md).  None when the workload differs
-    from the profiled one OR when the kernel sources have changed since that profile (the summary
-    carries the source tag it was taken with)."""
-    if args.workload != "wbfm" or (C, B) != (256, 16):
-        return None, None
-    path = os.path.join(ROOT, "profiles", "latest_pmc_traffic_wbfm256x16.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t.get("kernel_source_tag") != kernel_source_tag():
-            return None, t.get("kernel_source_tag")
-        return int(t["FETCH_SIZE"]["mean"] * 1024 * 2 + t["WRITE_SIZE"]["mean"] * 1024), t.get("kernel_source_tag")
-    except (OSError, KeyError, ValueError):
-        return None, None
+_PMC = None
 
 
-def stream_copy_gbs(device):
-    """Second denominator: what a plain device-to-device copy of 1 GiB reaches on this GPU in this
-    run, read + write bytes over the time of the copy kernel (HIP events, 10 copies after 3 warm-ups)."""
+def pmc_traffic(name):
+    """(HBM bytes per launch, note) of workload `name` from the PMC passes of tools/pmc_round.sh (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, each in a run of its own of this same bench command; the summary is committed as
+    profiles/latest_pmc_traffic.json).  gfx950: FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at
+    64 bytes -- doubled here, as MI355X_MICROARCH.md prescribes; WRITE_SIZE is exact for 16-byte-per-lane streaming
+    stores.  Both are in KiB.  Reported only when the summary was taken with THIS device code (kernel_code_tag)."""
+    global _PMC
+    if _PMC is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "latest_pmc_traffic.json")) as f:
+                _PMC = json.load(f)
+        except (OSError, ValueError):
+            _PMC = {}
+    if not _PMC:
+        return None, "no PMC summary"
+    if _PMC.get("kernel_code_tag") != kernel_code_tag():
+        return None, f"the PMC summary is of device code {_PMC.get('kernel_code_tag')}, this run is {kernel_code_tag()}: not reported"
+    w = _PMC.get("workloads", {}).get(name)
+    if not w:
+        return None, "no PMC summary for this workload"
+    return int(w["FETCH_SIZE_KiB"] * 1024 * 2 + w["WRITE_SIZE_KiB"] * 1024), f"profiles/latest_pmc_traffic.json[{name}], device code {_PMC['kernel_code_tag']}"
+
+
+def stream_gbs(device, kind, buf=None):
+    """The measured denominators: what a kernel that does nothing but READ (kind 0) or nothing but WRITE
+    (kind 1) 1 GiB reaches on this GPU in this run -- libhrfd's own two plain stream kernels (csrc/hrfd_membw.hip:
+    16 bytes per lane, 32 KiB per workgroup, every XCD one contiguous eighth), HIP events on the launch stream, 10
+    launches after 3 warm-ups.  (Until round 4 this was a torch copy_, i.e. read + write, compared with a read-only
+    kernel: a fraction above 1 said the denominator was wrong.)"""
+    import ctypes
+    from hackrfdiags_amd import _lib
+    L = _lib.load()
     n = 1 << 30
-    a = torch.empty(n, dtype=torch.int8, device=device)
-    b = torch.empty(n, dtype=torch.int8, device=device)
-    a.random_(0, 127)
+    own = buf is None
+    if own:
+        buf = torch.empty(n, dtype=torch.int8, device=device)
+        buf.random_(0, 127)
+    nbytes = (buf.numel() * buf.element_size()) // (1 << 18) * (1 << 18)
+    st = torch.cuda.current_stream(device)
+    torch.cuda.synchronize()
     for _ in range(3):
-        b.copy_(a)
+        assert L.hrfd_debug_membw(kind, ctypes.c_void_p(buf.data_ptr()), nbytes, None, ctypes.c_void_p(st.cuda_stream)) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    e0.record(st)
     for _ in range(10):
-        b.copy_(a)
-    e1.record()
+        L.hrfd_debug_membw(kind, ctypes.c_void_p(buf.data_ptr()), nbytes, None, ctypes.c_void_p(st.cuda_stream))
+    e1.record(st)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    del a, b
-    return 2 * n / (ms * 1e-3) / 1e9
-
-
-def stream_fill_gbs(device, out):
-    """The write-side counterpart: what the library's fill of the modulators' own output buffer reaches on this GPU in
-    this run (bytes written over the time of the fill kernel, HIP events, 10 fills after 3 warm-ups)."""
-    for _ in range(3):
-        out.fill_(1)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        out.fill_(1)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    return out.numel() * out.element_size() / (ms * 1e-3) / 1e9
+    if own:
+        del buf
+    return nbytes / (ms * 1e-3) / 1e9
 
 
 def end_to_end(api, device, C):
@@ -585,6 +619,18 @@ def make_quiet_batch(channels, blocks, device, first_channel=0):
     gen = torch.Generator(device=device)
     gen.manual_seed(99 + first_channel)
     return torch.randint(-1, 2, (channels, blocks, BLOCK), dtype=torch.int8, device=device, generator=gen)
+
+
+def rx_workload_name(workload, C, B, signal="fmtone", quiet_fraction=0.0, iqdump=False):
+    """the key of a workload in the line's `also` object and in profiles/latest_pmc_traffic.json"""
+    name = f"{workload}_{C}x{B}"
+    if signal != "fmtone":
+        name += "_" + signal
+    if quiet_fraction > 0:
+        name += f"_quiet{int(round(100 * quiet_fraction))}"
+    if iqdump:
+        name += "_iqdump"
+    return name
 
 
 def rx_workload_text(workload, C, B, world, signal, scatter, quiet_fraction=0.0, threshold=None, iqdump=False):
@@ -735,6 +781,12 @@ def brief(r, text, extra=None):
             d["invalid"] = f"PCM samples produced {r['pcm_produced']} != {r['pcm_expected']}"
     if extra:
         d.update(extra)
+    if "name" in d:
+        t, src = pmc_traffic(d.pop("name"))
+        d["traffic"] = t
+        d["traffic_over_algorithmic"] = None if t is None else round(t / d["algorithmic_bytes_per_launch"], 4)
+        if t is None:
+            d["traffic_source"] = src
     return d
 
 
@@ -750,7 +802,9 @@ def also_lines(api, shard, device, args):
         text_kw = {k: kw[k] for k in ("quiet_fraction", "threshold", "iqdump") if k in kw}
         r = measure_rx(api, shard, device, None, **{**common, **kw})
         out[name] = brief(r, rx_workload_text(kw["workload"], kw["C"], kw["B"], 1, kw["signal"], False, **text_kw),
-                          {"steps": kw.get("steps", K), "warmup": kw.get("warmup", W), "settle_steps": kw.get("settle", settle)})
+                          {"steps": kw.get("steps", K), "warmup": kw.get("warmup", W), "settle_steps": kw.get("settle", settle),
+                           "name": rx_workload_name(kw["workload"], kw["C"], kw["B"], kw["signal"], kw.get("quiet_fraction", 0.0),
+                                                    kw.get("iqdump", False))})
         return r
 
     rx("wbfm_1024x16", workload="wbfm", C=1024, B=16, signal="fmtone")
@@ -765,7 +819,7 @@ def also_lines(api, shard, device, args):
     for name, wl, C in (("ssbmod_1024x16", "ssbmod", 1024), ("wbfmmod_1024x16", "wbfmmod", 1024)):
         r = measure_mod(api, shard, device, None, wl, C, 16, K, W, settle, 0, 1, extras=False)
         out[name] = brief(r, f"{C} {r['kname']} modulator channels, 16 blocks of 512 PCM samples per step"
-                          + (" (BASELINE config 5)" if wl == "ssbmod" else ""), {"steps": K, "warmup": W, "settle_steps": settle})
+                          + (" (BASELINE config 5)" if wl == "ssbmod" else ""), {"steps": K, "warmup": W, "settle_steps": settle, "name": name})
     # the north star's target at its own cadence (>= 1000 channels in real time: one block per channel per 64 ms)
     out["realtime_1024x1"] = realtime_cadence(api, device, 1024, "wbfm")
     out["realtime_mixed_1024x1"] = realtime_cadence(api, device, 1024, "mixed", batches=24)
@@ -851,10 +905,12 @@ def main():
                    serial_modes=args.serial_modes, stride_pad=args.stride_pad)
     counters = r["counters"]
     assert r["pcm_produced"] == r["pcm_expected"], f"PCM samples produced {r['pcm_produced']} != {r['pcm_expected']}"
-    traffic, ptag = pmc_traffic_bytes(args, C, B)
-    if args.quiet_fraction > 0 or args.iqdump:
-        traffic = None
-    copy_gbs = stream_copy_gbs(device)
+    wname = rx_workload_name(args.workload, C, B, args.signal, args.quiet_fraction, args.iqdump)
+    traffic, traffic_src = pmc_traffic(wname)
+    read_gbs = stream_gbs(device, 0)
+    write_gbs = stream_gbs(device, 1)
+    # a read-only kernel cannot read faster than the kernel that does nothing else: if it does, a denominator is wrong
+    assert r["achieved"] <= read_gbs, f"{r['achieved']:.0f} GB/s algorithmic > {read_gbs:.0f} GB/s of the plain read kernel"
     value, achieved = r["value"], r["achieved"]
 
     if rank == 0:
@@ -888,11 +944,11 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "traffic_source": (f"profiles/latest_pmc_traffic_wbfm256x16.json, kernel sources {ptag}" if traffic is not None else
-                                   ("no PMC summary for this workload" if ptag is None else
-                                    f"PMC summary is of kernel sources {ptag}, this run is {kernel_source_tag()}: not reported")),
-                "measured_stream_copy_GBps": round(copy_gbs, 1),
-                "frac_of_measured_copy": round(achieved / copy_gbs, 4),
+                "traffic_source": traffic_src,
+                "traffic_over_algorithmic": None if traffic is None else round(traffic / r["algo_bytes"], 4),
+                "measured_stream_read_GBps": round(read_gbs, 1),
+                "frac_of_measured_read": round(achieved / read_gbs, 4),
+                "measured_stream_write_GBps": round(write_gbs, 1),
                 "kernel": ("hrfd::k_rx_wbfm_flow<4, GATED=false, DUMP=%s, WBFM> (one persistent workgroup per CU, LDS ring, "
                            "first-octant-table atan2)%s" % ("true" if args.iqdump else "false",
                                                             ", the gated pass behind it" if args.quiet_fraction > 0 else "")
@@ -910,6 +966,7 @@ def main():
             },
             "verification": {"uncommitted_launches": counters[5], "tiles_repaired_in_place": counters[4],
                              "launches": counters[6]},
+            "kernel_code_tag": kernel_code_tag(),
             "kernel_source_tag": kernel_source_tag(),
             "runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         }

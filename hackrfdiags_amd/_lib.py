@@ -99,6 +99,7 @@ def load() -> C.CDLL:
     L.hrfd_rx_debug_enable_timing.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_kernel_ms.argtypes = [_vp, C.c_int, _f32p]
     L.hrfd_rx_debug_timing_every.argtypes = [_vp, C.c_int]
+    L.hrfd_debug_membw.argtypes = [C.c_int, _vp, C.c_size_t, _vp, _vp]
     L.hrfd_demod_create.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(_vp)]
     L.hrfd_demod_destroy.argtypes = [_vp]
     L.hrfd_demod_reset.argtypes = [_vp, C.c_uint32]

@@ -11,3 +11,4 @@
 #include "hrfd_fanout.hip"
 #include "hrfd_txring.hip"
 #include "hrfd_play.hip"
+#include "hrfd_membw.hip"

@@ -35,6 +35,11 @@ int hrfd_rx_debug_atan_eval_tab(hrfd_rx *h, float *out65536);
 int hrfd_rx_debug_stamps(hrfd_rx *h, uint32_t cap_groups, unsigned long long *host_out);
 int hrfd_rx_debug_chk(hrfd_rx *h, float *pub, float *spec, uint32_t n);
 
+/* two plain stream kernels -- kind 0 reads `bytes` of d_buf (d_sink: one dword that is never written, may be NULL),
+ * kind 1 overwrites them; bytes a multiple of 256 KiB; asynchronous on `stream`.  bench.py times them in the same run
+ * as the measured denominators beside the 8 TB/s spec peak (`measured_stream_read_GBps` / `_write_GBps`). */
+int hrfd_debug_membw(int kind, void *d_buf, size_t bytes, void *d_sink, void *stream);
+
 /* ------------------------------------------------------------------ behaviour-changing hooks (HRFD_DEBUG_HOOKS=1) */
 int hrfd_rx_debug_set_atan(hrfd_rx *h, int mode);        /* -1 automatic, 0 table gather, 1 arithmetic */
 int hrfd_rx_debug_set_warm(hrfd_rx *h, int warm);        /* shrink the de-emphasis warm-up, seeds off: forces repairs */
