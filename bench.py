@@ -599,6 +599,39 @@ def realtime_cadence(api, device, C, kind="wbfm", batches=48):
     return out
 
 
+def host_replay_cost(api, device):
+    """A batch of more than 64 blocks with closed squelch gates is the one case the device does not repair by itself
+    (the gated pass holds a run's block list in 64 LDS words): hrfd_rx_process_block replays the channels concerned on
+    the host's side, block by block through the exact per-block kernel.  64 WBFM channels x 80 blocks from host memory
+    through the blocking entry, a quarter of the channels silent: with the threshold at its default (no gate can close)
+    and at -30 dBFS (their gates close)."""
+    C, B = 64, 80
+    x = make_fm_batch(C, B, device)
+    x[::4] = make_quiet_batch(C // 4, B, device)
+    xh = x.cpu().numpy()
+    del x
+    res = {}
+    for name, thr in (("gates_open", None), ("gates_closing", -30)):
+        rx = api.Rx(C, device=device.index)
+        rx.set_mode(api.WBFM)
+        if thr is not None:
+            rx.set_threshold(thr)
+        rx.process_block(xh, B)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = rx.process_block(xh, B)
+            ts.append(time.perf_counter() - t0)
+        res[name + "_ms"] = round(1e3 * min(ts), 2)
+        res[name + "_pcm_blocks"] = int((out[1] > 0).sum())
+        rx.close()
+    res["workload"] = (f"{C} WBFM channels x {B} blocks (> 64) through hrfd_rx_process_block from pageable host memory "
+                       f"({C * B * BLOCK / 2**30:.2f} GiB per call), a quarter of the channels silent; best of 3 calls")
+    res["replay_cost_ms"] = round(res["gates_closing_ms"] - res["gates_open_ms"], 2)
+    torch.cuda.empty_cache()
+    return res
+
+
 def single_block_latency_ms(api, device):
     """The reference's real cadence: ONE channel, ONE 262144-byte block (64 ms of signal) per call, host buffer in,
     PCM out, through hrfd_rx_process_block (what the IqDataProcessor shim's acceptIqData does).  Median of 30."""
@@ -659,7 +692,8 @@ def rx_workload_text(workload, C, B, world, signal, scatter, quiet_fraction=0.0,
 
 
 def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmup, settle, rank, world,
-               scatter=False, quiet_fraction=0.0, threshold=None, iqdump=False, idle_s=0.0, serial_modes=False, stride_pad=0):
+               scatter=False, quiet_fraction=0.0, threshold=None, iqdump=False, idle_s=0.0, serial_modes=False, stride_pad=0,
+               blk=BLOCK):
     """K timed steps of the receive path over one resident batch [C][B][262144]; returns the figures of a bench line.
     The dominant kernels' time comes from HIP events the library records on its launch stream(s) around the
     demodulator kernels of every launch (hrfd_rx_debug_enable_timing)."""
@@ -673,14 +707,16 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
         q = make_quiet_batch(n_quiet, B, device, first_channel=rank * C)
         iq[torch.tensor(quiet, device=device)] = q
         del q
-    stride = B * BLOCK + stride_pad
+    if blk != BLOCK:                                     # a shorter block: the front of every 262144-byte block
+        iq = iq[:, :, :blk].contiguous()
+    stride = B * blk + stride_pad
     if stride_pad:
         padded = torch.zeros((C, stride), dtype=torch.int8, device=device)
-        padded[:, :B * BLOCK] = iq.reshape(C, B * BLOCK)
+        padded[:, :B * blk] = iq.reshape(C, B * blk)
         iq = padded
-    pcm = torch.zeros((C, B, 512), dtype=torch.int16, device=device)
+    pcm = torch.zeros((C, B, blk // 512), dtype=torch.int16, device=device)
     n_pcm = torch.zeros((C, B), dtype=torch.int32, device=device)
-    iq256 = torch.zeros((C, B, BLOCK // 8), dtype=torch.int8, device=device) if iqdump else None
+    iq256 = torch.zeros((C, B, blk // 8), dtype=torch.int8, device=device) if iqdump else None
     torch.cuda.synchronize()                             # inputs and outputs were written on torch's stream
     rx = api.Rx(C, device=device.index)
     rx.set_mode(api.WBFM)
@@ -713,7 +749,7 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
         if scatter:
             with torch.cuda.stream(stream):
                 shard.scatter_iq(iq_root, iq, world * C)     # one group of sends out of rank 0, straight into `iq`
-        rx.process_device(iq.data_ptr(), stride, BLOCK, B, pcm.data_ptr(), d_n_pcm=n_pcm.data_ptr(),
+        rx.process_device(iq.data_ptr(), stride, blk, B, pcm.data_ptr(), d_n_pcm=n_pcm.data_ptr(),
                           d_iq256=None if iq256 is None else iq256.data_ptr(), stream=stream.cuda_stream)
 
     if idle_s > 0:
@@ -744,9 +780,9 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
     produced = int(n_pcm.sum().item())
     # a closed gate produces no PCM (the tracker lets one "tail" block through after a signal: none here, the quiet
     # channels are quiet from the start)
-    expect = (C - n_quiet) * B * 512
-    samples_per_step = C * B * (BLOCK // 2)
-    algo_bytes = C * B * (BLOCK + 1024 + 4) + (C * B * (BLOCK // 8) if iqdump else 0)   # 2.0078 B / IQ sample
+    expect = (C - n_quiet) * B * (blk // 512)
+    samples_per_step = C * B * (blk // 2)
+    algo_bytes = C * B * (blk + blk // 256 + 4) + (C * B * (blk // 8) if iqdump else 0)   # 2.0078 B / IQ sample
     mean_ms = float(np.mean(kernel_ms))
     achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
     out = {
@@ -820,6 +856,16 @@ def also_lines(api, shard, device, args):
         r = measure_mod(api, shard, device, None, wl, C, 16, K, W, settle, 0, 1, extras=False)
         out[name] = brief(r, f"{C} {r['kname']} modulator channels, 16 blocks of 512 PCM samples per step"
                           + (" (BASELINE config 5)" if wl == "ssbmod" else ""), {"steps": K, "warmup": W, "settle_steps": settle, "name": name})
+    # What the fallbacks cost: shapes the flow kernels do not take run on the round-1/2 block kernels
+    # (one workgroup per channel-block, k_rx_finish behind them).
+    r = measure_rx(api, shard, device, None, **{**common, "workload": "am", "C": 32, "B": 16, "signal": "fmtone"})
+    out["fallback_am_32x16"] = brief(r, "32 AM channels x 16 blocks: a FIR-mode bank under 48 channels runs on the block kernels "
+                                        "k_rx_fir<14> + k_rx_post<14> + k_rx_finish (a whole-CU workgroup per channel would leave 7/8 of the chip idle)",
+                                     {"steps": K, "warmup": W, "settle_steps": settle})
+    r = measure_rx(api, shard, device, None, **{**common, "workload": "wbfm", "C": 256, "B": 16, "signal": "fmtone", "blk": 258048})
+    out["fallback_wbfm_256x16_blk258048"] = brief(r, "256 WBFM channels x 16 blocks of 258048 bytes (31.5 units of 8 KiB: not whole units): "
+                                                     "the block kernel k_rx_wbfm + k_rx_finish", {"steps": K, "warmup": W, "settle_steps": settle})
+    out["fallback_wbfm_64x80_host_replay"] = host_replay_cost(api, device)
     # the north star's target at its own cadence (>= 1000 channels in real time: one block per channel per 64 ms)
     out["realtime_1024x1"] = realtime_cadence(api, device, 1024, "wbfm")
     out["realtime_mixed_1024x1"] = realtime_cadence(api, device, 1024, "mixed", batches=24)

@@ -1914,6 +1914,28 @@ extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_m
     }
 
   }
+  if (kind == HRFD_MOD_FM)
+  {
+    // The FM modulator's 8 kS/s phase recurrence (8192 serial steps per 16-block call: ~0.14 ms whatever the bank) runs
+    // slice by slice on a stream of its own BESIDE the x256 cascade of the slice in front (hrfd_mod_process_device).  That
+    // stream has the device's highest priority: the recurrence is one wave per workgroup running a dependent chain, and
+    // among the cascade's thousands of workgroups it is served last and takes twice its time (measured: 108 us instead of
+    // 49 for a 36-tile slice, the cascade then waits for it); with priority it runs at the rate it has alone.  (A
+    // priority level also has hardware queues of its own: the stream cannot end up sharing one with the caller's stream,
+    // where the two would run in submission order.)
+    int lo_prio = 0, hi_prio = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+    if (e == hipSuccess && hipStreamCreateWithPriority(&h->s_scan, hipStreamNonBlocking, hi_prio) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      h->s_scan = nullptr;                                 // (no second stream: the call runs unsliced)
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    for (int k = 0; k < 4 && e == hipSuccess; k++)
+    {
+      e = hipEventCreateWithFlags(&h->ev_scan[k], hipEventDisableTiming);
+    }
+  }
   if (e != hipSuccess)
   {
     const int rc = fail(HRFD_ENOMEM, "hrfd_mod_create: %s", hipGetErrorString(e));
@@ -2223,12 +2245,66 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     }
     else
     {
-      hipLaunchKernelGGL(k_fm_step, dim3(gs), dim3(256), 0, s, B);
-      phase_scan(h, reinterpret_cast<uint32_t *>(h->d_phase), (size_t)n_per_channel, (size_t)n_per_channel, h->d_acc, h->n_channels, s);
-      hipLaunchKernelGGL(k_fm_rails, dim3(gs), dim3(256), 0, s, B);
+      // FmModulator::modulateSignal (FmModulator.cc:586-627) sets the Nco's frequency and runs it once per PCM sample: the
+      // step of every sample in parallel (k_fm_step), the phase recurrence (serial per channel: k_phase_scan), cos / sin of
+      // every phase in parallel (k_fm_rails), then the cascade.  Only the recurrence is serial in time, and it is a quarter
+      // of the cascade's time per sample: a long call is cut into three TIME SLICES and the recurrence and rails of slice
+      // k + 1 run on a stream of their own beside the cascade of slice k.  What stays exposed is the first slice's
+      // recurrence and rails.  (Round 3 ran the four passes one after the other: the recurrence's 0.14 ms and the rails'
+      // 0.04 sat in front of the cascade's 0.81.)
+      const uint32_t nt = tiles;
+      const bool fm_sliced = h->sliced != 0 && nt >= 64u && h->s_scan != nullptr;
+      if (!fm_sliced)
+      {
+        hipLaunchKernelGGL(k_fm_step, dim3(gs), dim3(256), 0, s, B);
+        phase_scan(h, reinterpret_cast<uint32_t *>(h->d_phase), (size_t)n_per_channel, (size_t)n_per_channel, h->d_acc, h->n_channels, s);
+        hipLaunchKernelGGL(k_fm_rails, dim3(gs), dim3(256), 0, s, B);
+        M.in = h->d_rails;
+        hipLaunchKernelGGL(k_mod<HRFD_MOD_RAILS>, dim3(grid), dim3(kModThreads), 0, s, M);
+      }
+      else
+      {
+        // Slice lengths in tiles of 64 samples: the recurrence + cos / sin of a slice take ~1.9 us per tile, the cascade
+        // ~5.9 us per tile: a slice may be three times the one in front.  The recurrences and rails of ALL slices follow
+        // each other on s_scan; the caller's stream carries the steps and the cascade launches, each behind its slice's
+        // event.  Order matters more than priority here: a recurrence workgroup is seven waves, a cascade workgroup four,
+        // and once a cascade launch has filled the CUs the slots it frees are retaken four waves at a time -- the
+        // recurrence launched BEHIND a cascade launch waits for room and takes twice its time (measured: 108 us for a
+        // 36-tile slice instead of 49, whatever the stream's priority).  This way slice k + 1's recurrence is resident
+        // before the cascade of slice k starts (its event takes ~13 us to cross queues): timeline of a step in
+        // profiles/r4_fmmod_timeline.txt.  Exposed: two event hops, the first slice's recurrence and rails.
+        const uint32_t l0 = std::max(8u, nt / 16u), l1 = std::min(3u * l0 + l0 / 2u, nt - l0 - 1u);
+        const uint32_t cut[4] = {0u, l0 * kModTile, (l0 + l1) * kModTile, n_per_channel};
+        hipLaunchKernelGGL(k_fm_step, dim3(gs), dim3(256), 0, s, B);
+        HIP_TRY(hipEventRecord(h->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(h->s_scan, h->ev_fork, 0));
+        for (int k = 0; k < 3; k++)
+        {
+          const uint32_t lo = cut[k], len = cut[k + 1] - lo;
+          // (the slices' recurrences follow each other in stream order: the accumulators carry over in d_acc)
+          phase_scan(h, reinterpret_cast<uint32_t *>(h->d_phase) + lo, (size_t)len, (size_t)n_per_channel, h->d_acc, h->n_channels, h->s_scan);
+          B.lo = lo;
+          B.len = len;
+          hipLaunchKernelGGL(k_fm_rails, dim3((uint32_t)(((size_t)len * h->n_channels + 255) / 256)), dim3(256), 0, h->s_scan, B);
+          HIP_TRY(hipEventRecord(h->ev_scan[k], h->s_scan));
+        }
+        M.in = h->d_rails;
+        for (int k = 0; k < 3; k++)
+        {
+          HIP_TRY(hipStreamWaitEvent(s, h->ev_scan[k], 0));
+          M.tile0 = cut[k] / kModTile;
+          M.tiles_launch = (cut[k + 1] - cut[k] + kModTile - 1) / kModTile;
+          hipLaunchKernelGGL(k_mod<HRFD_MOD_RAILS>, dim3(groups8 * M.tiles_launch), dim3(kModThreads), 0, s, M);
+        }
+        M.tile0 = 0;
+        M.tiles_launch = 0;
+      }
     }
-    M.in = h->d_rails;
-    hipLaunchKernelGGL(k_mod<HRFD_MOD_RAILS>, dim3(grid), dim3(kModThreads), 0, s, M);
+    if (h->kind == HRFD_MOD_AM)
+    {
+      M.in = h->d_rails;
+      hipLaunchKernelGGL(k_mod<HRFD_MOD_RAILS>, dim3(grid), dim3(kModThreads), 0, s, M);
+    }
   }
   else if (h->kind >= HRFD_MOD_SIG_AM)
   {

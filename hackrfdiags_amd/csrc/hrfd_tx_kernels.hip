@@ -1080,10 +1080,17 @@ __global__ void k_phase_scan_plain(uint32_t *cells, size_t steps, size_t row_str
 // int8 output are within 1 LSB: the float-trig tolerance of BASELINE.json), times 16000, (int16_t).
 __global__ void k_fm_rails(const BaseParams B)
 {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)B.n * B.n_channels)
+  // (B.len != 0: the samples [lo, lo + len) of every channel -- a time slice of the call)
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t len = (B.len != 0u) ? B.len : B.n;
+  if (t >= (size_t)len * B.n_channels)
   {
     return;
+  }
+  if (B.len != 0u)
+  {
+    const size_t c = t / len;
+    t = c * B.n + B.lo + (t - c * len);
   }
   const float phase = B.phase[t];
   float iv = (float)cos((double)phase), qv = (float)sin((double)phase);

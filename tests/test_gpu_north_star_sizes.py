@@ -132,7 +132,7 @@ def test_soak_flow_shapes_agree_launch_after_launch():
     included; this is about the flow kernels' flag protocol and the device-side repair holding up under load, launch
     after launch, on input nobody chose.)"""
     import torch
-    C, B, launches = 256, 16, int(os.environ.get("HRFD_SOAK_LAUNCHES", "60"))   # (a long soak: HRFD_SOAK_LAUNCHES=2000)
+    C, B, launches = 256, 16, int(os.environ.get("HRFD_SOAK_LAUNCHES", "300"))   # (a long soak: HRFD_SOAK_LAUNCHES=2000)
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev)
     g.manual_seed(20260)
@@ -172,7 +172,7 @@ def test_soak_wbfm_flow_against_the_block_kernel():
     block kernel k_rx_wbfm (runs of blocks per workgroup, barriers between its phases) -- two implementations of the
     speculation that share little code.  PCM and magnitudes identical launch after launch, everything committed."""
     import torch
-    C, B, launches = 256, 16, int(os.environ.get("HRFD_SOAK_LAUNCHES", "30"))
+    C, B, launches = 256, 16, int(os.environ.get("HRFD_SOAK_LAUNCHES", "150"))
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev)
     g.manual_seed(777)

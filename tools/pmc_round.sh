@@ -56,8 +56,7 @@ for d in sorted(glob.glob(O + "/raw_*_FETCH_SIZE")):
                     acc[k].append(float(r["Counter_Value"]))
         if not acc:
             continue
-        # dispatches per step: relative to the kernel with the fewest dispatches that still runs every step
-        steps_total = min(len(v) for v in acc.values() if len(v) >= STEPS)
+        steps_total = STEPS + WARM                      # HRFD_BENCH_SETTLE=0: these are all the steps the bench ran
         tot = 0.0
         for k, v in sorted(acc.items()):
             per_step = len(v) / steps_total
