@@ -322,239 +322,291 @@ struct FlowLds
                 (kFinWords % 4) == 0, "16-byte alignment of what is accessed as 128-bit words");
 };
 
+// The flow kernel as an object: what the sections below share -- the workgroup's LDS arrays, the channel, the run's
+// geometry, the carried state, the failure code -- are its members, set once by setup(); the sections are member
+// functions, each readable by itself:
+//   setup()                 map the workgroup to (channel, run), GATED: build the block list; tables, flags and carried
+//                           pipelines into LDS (the kernel's only two workgroup barriers)
+//   stream_waves()          waves SVC .. 15: raw IQ -> the ring (phase A; every mode)
+//   service_waves_fir()     waves 0 .. SVC-1, FM and AM / SSB: rails -> decimators -> PCM
+//   service_waves_wbfm()    waves 0 .. SVC-1, WBFM: v -> recurrence tiles -> integer stages -> PCM
+//   finish()                the channel's verdict and commit (from LDS when the channel was this workgroup's alone)
+// Everything is inlined into the kernel; the object is scalarised by the compiler (no scratch: tools/kinfo.sh).
 template <int SVC, bool GATED, bool DUMP, int MODE>
-__device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds)
+struct Flow
 {
   static_assert(MODE == 3 || MODE == 2 || MODE == 14, "WBFM, FM, AM / SSB");
   typedef FlowLds<MODE> Lds;
-  constexpr bool kWb = (MODE == 3);
-  constexpr bool kAtan = Lds::kAtan;
-  constexpr int kRails = Lds::kRails;
-  constexpr int kVDw = Lds::kVDw;
-  uint32_t *const ring = lds + Lds::oRing;                  // kFRingTiles * kFStride
-  uint8_t *const atcorr = reinterpret_cast<uint8_t *>(lds + Lds::oAtcorr);   // theta_tab: correction bytes ...
-  float *const att0 = reinterpret_cast<float *>(lds + Lds::oAtt0);           // ... and the first-octant table
-  uint32_t *const uring = lds + Lds::oUring;                // kRails * kFUDw
-  uint32_t *const vring = lds + Lds::oVring;                // kRails * kVDw
-  // AM / SSB at 8 kS/s: four generations of the last decimator's outputs per rail (SSB: the Hilbert transformer reads 30
-  // back), a generation's recurrence input and output, and the recurrence's carried x[n-1], y[n-1]
-  int16_t (*const r8k)[Lds::k8k] = reinterpret_cast<int16_t (*)[Lds::k8k]>(lds + Lds::oR8k);
-  float *const xs8k = reinterpret_cast<float *>(lds + Lds::oXs), *const ys8k = reinterpret_cast<float *>(lds + Lds::oYs);
-  float *const rcar = reinterpret_cast<float *>(lds + Lds::oRcar);
-  uint32_t *const thfin = lds + Lds::oThfin;                // FM: theta of the last four 64 kS/s samples of the last finished generation
-  uint32_t (*const edges)[4] = reinterpret_cast<uint32_t (*)[4]>(lds + Lds::oEdges);   // per unit: theta of its first two and last two samples
-  uint32_t *const uflag = lds + Lds::oUflag;                // unit u is complete in the ring: u + 1
-  float *const parr = reinterpret_cast<float *>(lds + Lds::oParr);   // per tile: geometric partial sum of v
-  uint32_t *const pflag = lds + Lds::oPflag;                // partial sums of generation g are in parr: g + 1
-  uint32_t *const ctl = lds + Lds::oCtl;                    // 0 next unit, 1 generations verified (their v is released), 2 generations complete (U, V, PCM), 3 blocks finished,
-                                                          // 4 next generation, 5 waves of the workgroup that are through,
-                                                          // 8..23 units done (per block, mod 16)
-  uint32_t (*const magl)[64] = reinterpret_cast<uint32_t (*)[64]>(lds + Lds::oMagl);   // per block (mod 16: more blocks than the ring
-                                           // can span) and lane: sum of the sample magnitudes.  One word per lane: a
-                                           // same-address atomic from 64 lanes becomes a 64-step scalar loop (LLVM's atomic
-                                           // optimizer), measured at half of the kernel's time
-  int8_t *const dbfs8 = reinterpret_cast<int8_t *>(lds + Lds::oDbfs);   // the reachable part of the dBFS table
-  uint32_t *const blkout = lds + Lds::oBlkout;              // per block of the run: mean magnitude | present << 31 (written out at the end:
-                                           // a global store inside the unit loop costs the loop its counted vmcnt waits)
-  uint32_t *const wfin = lds + Lds::oWfin;                  // the last finished generation's last lane: y, its last two S pairs
-  uint32_t *const finl = lds + Lds::oFinl;                  // a channel that is ONE workgroup's is finished from here (no memory round trip behind
-                                           // the last sample): 0..63 y in front of block b, 128..159 the pending WBFM state
-                                           // section, 160 tracking, 161 poison, 162..165 the pending fe_tail
-  uint8_t *const blist = reinterpret_cast<uint8_t *>(lds + Lds::oBlist);   // GATED: the blocks of the stream, in order (the allowed ones)
-  uint32_t *const gctl = lds + Lds::oGctl;                  // GATED: 0 number of allowed blocks, 1 `present` of the call's last block; AM / SSB: 2 generations through their 8 kS/s part
+  static constexpr bool kWb = (MODE == 3);
+  static constexpr bool kAtan = Lds::kAtan;
+  static constexpr int kRails = Lds::kRails;
+  static constexpr int kVDw = Lds::kVDw;
 
-  uint32_t ci, run;
-  if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
+  const RxParams &P;
+  uint32_t *const lds;
+  // LDS arrays (dword offsets: FlowLds<MODE>)
+  uint32_t *ring;
+  uint8_t *atcorr;
+  float *att0;
+  uint32_t *uring, *vring;
+  int16_t (*r8k)[Lds::k8k];
+  float *xs8k, *ys8k, *rcar;
+  uint32_t *thfin;
+  uint32_t (*edges)[4];
+  uint32_t *uflag;
+  float *parr;
+  uint32_t *pflag, *ctl;
+  uint32_t (*magl)[64];
+  int8_t *dbfs8;
+  uint32_t *blkout, *wfin, *finl;
+  uint8_t *blist;
+  uint32_t *gctl;
+  // the workgroup's place: channel, run, lane
+  uint32_t ci, run, c;
+  int n256, tid, lane, wave;
+  uint32_t n_stream_blocks, b_first, b_end;
+  bool first, local;
+  int hal, L, n_units, n_tiles, n_gens, upb, wt, M;
+  const ChanState *st;
+  ChanState *so;
+  ChanCfg cfg;
+  float kgain;
+  bool small_y;
+  unsigned long long t_kernel, waited;
+  uint32_t fail_code;
+
+  __device__ __forceinline__ Flow(const RxParams &P_, uint32_t *const lds_) : P(P_), lds(lds_) {}
+
+  // ------------------------------------------------------------------------------------------------- setup
+  __device__ __forceinline__ bool setup()
   {
-    return;
-  }
-  const uint32_t c = P.chan_list[ci];
-  const int n256 = (int)P.n256;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint32_t n_stream_blocks = 0;                          // GATED: blocks of the stream
-  if (GATED)
-  {
-    // only the channels whose one and only failure in the batch launch was a closed gate (the host launches this
-    // variant with one run per channel and at most 64 blocks)
-    if (P.fin.chan_fail[c] != kFailGate)
+    ring = lds + Lds::oRing;                  // kFRingTiles * kFStride
+    atcorr = reinterpret_cast<uint8_t *>(lds + Lds::oAtcorr);   // theta_tab: correction bytes ...
+    att0 = reinterpret_cast<float *>(lds + Lds::oAtt0);           // ... and the first-octant table
+    uring = lds + Lds::oUring;                // kRails * kFUDw
+    vring = lds + Lds::oVring;                // kRails * kVDw
+    // AM / SSB at 8 kS/s: four generations of the last decimator's outputs per rail (SSB: the Hilbert transformer reads 30
+    // back), a generation's recurrence input and output, and the recurrence's carried x[n-1], y[n-1]
+    r8k = reinterpret_cast<int16_t (*)[Lds::k8k]>(lds + Lds::oR8k);
+    xs8k = reinterpret_cast<float *>(lds + Lds::oXs), ys8k = reinterpret_cast<float *>(lds + Lds::oYs);
+    rcar = reinterpret_cast<float *>(lds + Lds::oRcar);
+    thfin = lds + Lds::oThfin;                // FM: theta of the last four 64 kS/s samples of the last finished generation
+    edges = reinterpret_cast<uint32_t (*)[4]>(lds + Lds::oEdges);   // per unit: theta of its first two and last two samples
+    uflag = lds + Lds::oUflag;                // unit u is complete in the ring: u + 1
+    parr = reinterpret_cast<float *>(lds + Lds::oParr);   // per tile: geometric partial sum of v
+    pflag = lds + Lds::oPflag;                // partial sums of generation g are in parr: g + 1
+    ctl = lds + Lds::oCtl;                    // 0 next unit, 1 generations verified (their v is released), 2 generations complete (U, V, PCM), 3 blocks finished,
+                                                            // 4 next generation, 5 waves of the workgroup that are through,
+                                                            // 8..23 units done (per block, mod 16)
+    magl = reinterpret_cast<uint32_t (*)[64]>(lds + Lds::oMagl);   // per block (mod 16: more blocks than the ring
+                                             // can span) and lane: sum of the sample magnitudes.  One word per lane: a
+                                             // same-address atomic from 64 lanes becomes a 64-step scalar loop (LLVM's atomic
+                                             // optimizer), measured at half of the kernel's time
+    dbfs8 = reinterpret_cast<int8_t *>(lds + Lds::oDbfs);   // the reachable part of the dBFS table
+    blkout = lds + Lds::oBlkout;              // per block of the run: mean magnitude | present << 31 (written out at the end:
+                                             // a global store inside the unit loop costs the loop its counted vmcnt waits)
+    wfin = lds + Lds::oWfin;                  // the last finished generation's last lane: y, its last two S pairs
+    finl = lds + Lds::oFinl;                  // a channel that is ONE workgroup's is finished from here (no memory round trip behind
+                                             // the last sample): 0..63 y in front of block b, 128..159 the pending WBFM state
+                                             // section, 160 tracking, 161 poison, 162..165 the pending fe_tail
+    blist = reinterpret_cast<uint8_t *>(lds + Lds::oBlist);   // GATED: the blocks of the stream, in order (the allowed ones)
+    gctl = lds + Lds::oGctl;                  // GATED: 0 number of allowed blocks, 1 `present` of the call's last block; AM / SSB: 2 generations through their 8 kS/s part
+
+    if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
     {
-      return;
+      return false;
     }
-    if (wave == 0)
+    c = P.chan_list[ci];
+    n256 = (int)P.n256;
+    tid = threadIdx.x;
+    lane = tid & 63;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    n_stream_blocks = 0;                          // GATED: blocks of the stream
+    if (GATED)
     {
-      const uint32_t nb = P.n_blocks;
-      const uint32_t pres = ((uint32_t)lane < nb) ? (uint32_t)(P.present[(size_t)c * nb + lane] != 0) : 0u;
-      const uint32_t prev = shr1(pres, (P.state[c].tracking != 0) ? 1u : 0u);
-      const bool allowed = (uint32_t)lane < nb && (pres | prev) != 0u;
-      const unsigned long long m = __ballot(allowed);
-      if (allowed)
+      // only the channels whose one and only failure in the batch launch was a closed gate (the host launches this
+      // variant with one run per channel and at most 64 blocks)
+      if (P.fin.chan_fail[c] != kFailGate)
       {
-        blist[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        return false;
       }
-      if (lane == 0)
+      if (wave == 0)
       {
-        gctl[0] = (uint32_t)__popcll(m);
-        gctl[1] = (uint32_t)__builtin_amdgcn_readlane((int)pres, (int)nb - 1);
-      }
-      // squelched blocks hand back silence, not what the batch launch left there
-      const uint32_t npcm2 = (uint32_t)n256 >> 6;        // PCM pairs per block
-      uint32_t *pz = reinterpret_cast<uint32_t *>(P.pcm + ((size_t)c * P.out_blocks + P.out_b0) * (size_t)(n256 >> 5));
-      for (uint32_t b = 0; b < nb; b++)
-      {
-        if (!((m >> b) & 1ull))
+        const uint32_t nb = P.n_blocks;
+        const uint32_t pres = ((uint32_t)lane < nb) ? (uint32_t)(P.present[(size_t)c * nb + lane] != 0) : 0u;
+        const uint32_t prev = shr1(pres, (P.state[c].tracking != 0) ? 1u : 0u);
+        const bool allowed = (uint32_t)lane < nb && (pres | prev) != 0u;
+        const unsigned long long m = __ballot(allowed);
+        if (allowed)
         {
-          for (uint32_t i = (uint32_t)lane; i < npcm2; i += 64u)
+          blist[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        }
+        if (lane == 0)
+        {
+          gctl[0] = (uint32_t)__popcll(m);
+          gctl[1] = (uint32_t)__builtin_amdgcn_readlane((int)pres, (int)nb - 1);
+        }
+        // squelched blocks hand back silence, not what the batch launch left there
+        const uint32_t npcm2 = (uint32_t)n256 >> 6;        // PCM pairs per block
+        uint32_t *pz = reinterpret_cast<uint32_t *>(P.pcm + ((size_t)c * P.out_blocks + P.out_b0) * (size_t)(n256 >> 5));
+        for (uint32_t b = 0; b < nb; b++)
+        {
+          if (!((m >> b) & 1ull))
           {
-            pz[(size_t)b * npcm2 + i] = 0u;
+            for (uint32_t i = (uint32_t)lane; i < npcm2; i += 64u)
+            {
+              pz[(size_t)b * npcm2 + i] = 0u;
+            }
           }
         }
       }
+      __syncthreads();
+      n_stream_blocks = gctl[0];
+    }
+    b_first = GATED ? 0u : run * P.run_len;
+    b_end = GATED ? n_stream_blocks : min(P.n_blocks, b_first + P.run_len);
+    first = (b_first == 0);                     // the stream continues from the carried state: exact start
+    local = GATED || (kWb && P.self_finish != 0 && P.n_runs == 1u && P.n_blocks <= 64u);   // the channel is this workgroup's alone
+    // history in front of the run (samples): WBFM re-derives it from the input when the run does not start the call; the
+    // FIR modes always have one unit, from the carried tail (their runs start the call)
+    hal = kWb ? (first ? 0 : P.flow_hal) : 512;
+    L = hal + (int)(b_end - b_first) * n256;     // samples of the stream
+    n_units = L >> 9, n_tiles = L >> 6, n_gens = (n_tiles + 63) >> 6;
+    upb = n256 >> 9;                             // units per block
+    wt = P.warm_tiles, M = P.seed_terms;
+    st = P.state + c;
+    so = P.state_out + c;
+    cfg = P.cfg[c];
+    kgain = cfg.gain_wbfm / 75000.0f;                // K = (gain/75000)*32767 in float, that order (WbFmDemodulator.cc:392-395)
+    kgain = kgain * 32767.0f;
+    small_y = fabsf(kgain) * 3.3f < 2147483000.0f;   // |y| <= |K| pi: the int32 cast cannot overflow
+    t_kernel = __builtin_readcyclecounter();
+    waited = 0;
+    fail_code = 0;                                // which wait expired, if any (diagnostics)
+    FLOW_TIME_SET(42)
+
+    // tables and control words
+    magl[0][tid] = 0u;
+    if (kAtan)
+    {
+      for (int i = tid; i < kCorrBytes / 4; i += kThreads)
+      {
+        reinterpret_cast<uint4 *>(att0)[i] = reinterpret_cast<const uint4 *>(P.at_t0)[i];
+      }
+    }
+    if (kAtan && tid < kCorrBytes / 16)
+    {
+      reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr2)[tid];
+    }
+    else if (tid >= 640 && tid < 640 + kFEdges)
+    {
+      uflag[tid - 640] = 0u;
+    }
+    else if (tid >= 768 && tid < 792)
+    {
+      ctl[tid - 768] = 0u;
+    }
+
+    else if (tid >= 800 && tid < 808)
+    {
+      pflag[tid - 800] = 0u;
+    }
+    else if (tid >= 840 && tid < 872)
+    {
+      reinterpret_cast<uint32_t *>(dbfs8)[tid - 840] = 0u;
+    }
+    else if (kWb && tid >= 832 && tid < 836 && first)
+    {
+      // what the lane in front of tile 0 would have left: the carried y and the last four S samples
+      wfin[tid - 832] = (tid == 832) ? f2u(st->wb_y) : (tid == 833) ? reinterpret_cast<const uint32_t *>(st->wb_s)[0]
+                                                     : (tid == 834) ? reinterpret_cast<const uint32_t *>(st->wb_s)[1] : 0u;
+    }
+    else if (kWb && tid >= 896 && tid < 900 && first)
+    {
+      uring[kFUDw - 4 + (tid - 896)] = reinterpret_cast<const uint32_t *>(st->wb_u)[tid - 896];     // U[-8 .. -1]
+    }
+    else if (tid == 904 && local)
+    {
+      finl[160] = st->tracking;
+      finl[161] = P.fin.chan_poison[c];
+    }
+    else if (tid >= 908 && tid < 912 && (GATED || b_end == P.n_blocks))
+    {
+      // front-end carry for the next call: the last 16 raw bytes of the channel's input (pending, like the rest of state_out)
+      const int8_t *endp = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)P.n_blocks * P.block_bytes;
+      const uint32_t w = reinterpret_cast<const uint32_t *>(endp - 16)[tid - 908];
+      reinterpret_cast<uint32_t *>(so->fe_tail)[tid - 908] = w;
+      finl[162 + (tid - 908)] = w;
+    }
+    else if (kWb && tid >= 960 && tid < 979 && first)
+    {
+      vring[kFVDw - 19 + (tid - 960)] = reinterpret_cast<const uint32_t *>(st->wb_v)[tid - 960];    // V[-38 .. -1]
     }
     __syncthreads();
-    n_stream_blocks = gctl[0];
-  }
-  const uint32_t b_first = GATED ? 0u : run * P.run_len;
-  const uint32_t b_end = GATED ? n_stream_blocks : min(P.n_blocks, b_first + P.run_len);
-  const bool first = (b_first == 0);                     // the stream continues from the carried state: exact start
-  const bool local = GATED || (kWb && P.self_finish != 0 && P.n_runs == 1u && P.n_blocks <= 64u);   // the channel is this workgroup's alone
-  // history in front of the run (samples): WBFM re-derives it from the input when the run does not start the call; the
-  // FIR modes always have one unit, from the carried tail (their runs start the call)
-  const int hal = kWb ? (first ? 0 : P.flow_hal) : 512;
-  const int L = hal + (int)(b_end - b_first) * n256;     // samples of the stream
-  const int n_units = L >> 9, n_tiles = L >> 6, n_gens = (n_tiles + 63) >> 6;
-  const int upb = n256 >> 9;                             // units per block
-  const int wt = P.warm_tiles, M = P.seed_terms;
-  const ChanState *st = P.state + c;
-  ChanState *so = P.state_out + c;
-  const ChanCfg cfg = P.cfg[c];
-  float kgain = cfg.gain_wbfm / 75000.0f;                // K = (gain/75000)*32767 in float, that order (WbFmDemodulator.cc:392-395)
-  kgain = kgain * 32767.0f;
-  const bool small_y = fabsf(kgain) * 3.3f < 2147483000.0f;   // |y| <= |K| pi: the int32 cast cannot overflow
-  const unsigned long long t_kernel = __builtin_readcyclecounter();
-  unsigned long long waited = 0;
-  uint32_t fail_code = 0;                                // which wait expired, if any (diagnostics)
-  FLOW_TIME_SET(42)
-
-  // tables and control words
-  magl[0][tid] = 0u;
-  if (kAtan)
-  {
-    for (int i = tid; i < kCorrBytes / 4; i += kThreads)
+    if (!kWb)
     {
-      reinterpret_cast<uint4 *>(att0)[i] = reinterpret_cast<const uint4 *>(P.at_t0)[i];
-    }
-  }
-  if (kAtan && tid < kCorrBytes / 16)
-  {
-    reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr2)[tid];
-  }
-  else if (tid >= 640 && tid < 640 + kFEdges)
-  {
-    uflag[tid - 640] = 0u;
-  }
-  else if (tid >= 768 && tid < 792)
-  {
-    ctl[tid - 768] = 0u;
-  }
-
-  else if (tid >= 800 && tid < 808)
-  {
-    pflag[tid - 800] = 0u;
-  }
-  else if (tid >= 840 && tid < 872)
-  {
-    reinterpret_cast<uint32_t *>(dbfs8)[tid - 840] = 0u;
-  }
-  else if (kWb && tid >= 832 && tid < 836 && first)
-  {
-    // what the lane in front of tile 0 would have left: the carried y and the last four S samples
-    wfin[tid - 832] = (tid == 832) ? f2u(st->wb_y) : (tid == 833) ? reinterpret_cast<const uint32_t *>(st->wb_s)[0]
-                                                   : (tid == 834) ? reinterpret_cast<const uint32_t *>(st->wb_s)[1] : 0u;
-  }
-  else if (kWb && tid >= 896 && tid < 900 && first)
-  {
-    uring[kFUDw - 4 + (tid - 896)] = reinterpret_cast<const uint32_t *>(st->wb_u)[tid - 896];     // U[-8 .. -1]
-  }
-  else if (tid == 904 && local)
-  {
-    finl[160] = st->tracking;
-    finl[161] = P.fin.chan_poison[c];
-  }
-  else if (tid >= 908 && tid < 912 && (GATED || b_end == P.n_blocks))
-  {
-    // front-end carry for the next call: the last 16 raw bytes of the channel's input (pending, like the rest of state_out)
-    const int8_t *endp = P.iq + (uint64_t)c * P.ch_stride + (uint64_t)P.n_blocks * P.block_bytes;
-    const uint32_t w = reinterpret_cast<const uint32_t *>(endp - 16)[tid - 908];
-    reinterpret_cast<uint32_t *>(so->fe_tail)[tid - 908] = w;
-    finl[162 + (tid - 908)] = w;
-  }
-  else if (kWb && tid >= 960 && tid < 979 && first)
-  {
-    vring[kFVDw - 19 + (tid - 960)] = reinterpret_cast<const uint32_t *>(st->wb_v)[tid - 960];    // V[-38 .. -1]
-  }
-  __syncthreads();
-  if (!kWb)
-  {
-    // The FIR modes' stream begins with one unit of HISTORY (tiles 0 .. 7 = positions -512 .. -1): the tail of the
-    // 256 kS/s stream this demodulator consumed last (ChanState: offset-binary bytes i, q per sample -- the ring's own
-    // number format), zeros (0x80) in front of it.  The decimators warm up over it (they reach 260 samples back,
-    // FM's tuner 28); what they produce there is discarded.  Stage pipelines that carry samples scaled with the gain
-    // of their time (FM: U, V) and the 8 kS/s histories come from the state instead, as in the reference's objects.
-    const bool am = (MODE == 14) && cfg.mode == 1;
-    const uint8_t *tail = (MODE == 2) ? st->fm_tail + 2 * (kFmTail - 512) : am ? st->am_tail : st->ssb_tail;
-    constexpr int kHave = (MODE == 2) ? 512 : kAmTail;   // samples of history the state holds (of the 512)
-    if (tid < 256)
-    {
-      // pair k = samples 2k, 2k + 1 of the history unit
-      const int k0 = tid - (512 - kHave) / 2;
-      uint32_t ip = 0x00800080u, qp = 0x00800080u;
-      if (k0 >= 0)
+      // The FIR modes' stream begins with one unit of HISTORY (tiles 0 .. 7 = positions -512 .. -1): the tail of the
+      // 256 kS/s stream this demodulator consumed last (ChanState: offset-binary bytes i, q per sample -- the ring's own
+      // number format), zeros (0x80) in front of it.  The decimators warm up over it (they reach 260 samples back,
+      // FM's tuner 28); what they produce there is discarded.  Stage pipelines that carry samples scaled with the gain
+      // of their time (FM: U, V) and the 8 kS/s histories come from the state instead, as in the reference's objects.
+      const bool am = (MODE == 14) && cfg.mode == 1;
+      const uint8_t *tail = (MODE == 2) ? st->fm_tail + 2 * (kFmTail - 512) : am ? st->am_tail : st->ssb_tail;
+      constexpr int kHave = (MODE == 2) ? 512 : kAmTail;   // samples of history the state holds (of the 512)
+      if (tid < 256)
       {
-        const uint32_t w = reinterpret_cast<const uint32_t *>(tail)[k0];   // i0 q0 i1 q1
-        ip = (w & 0xffu) | ((w & 0x00ff0000u));
-        qp = ((w >> 8) & 0xffu) | ((w >> 8) & 0x00ff0000u);
+        // pair k = samples 2k, 2k + 1 of the history unit
+        const int k0 = tid - (512 - kHave) / 2;
+        uint32_t ip = 0x00800080u, qp = 0x00800080u;
+        if (k0 >= 0)
+        {
+          const uint32_t w = reinterpret_cast<const uint32_t *>(tail)[k0];   // i0 q0 i1 q1
+          ip = (w & 0xffu) | ((w & 0x00ff0000u));
+          qp = ((w >> 8) & 0xffu) | ((w >> 8) & 0x00ff0000u);
+        }
+        ring[(tid >> 5) * kFStride + (tid & 31)] = ip;
+        ring[(tid >> 5) * kFStride + 32 + (tid & 31)] = qp;
       }
-      ring[(tid >> 5) * kFStride + (tid & 31)] = ip;
-      ring[(tid >> 5) * kFStride + 32 + (tid & 31)] = qp;
+      else if (MODE == 2 && tid >= 256 && tid < 260)
+      {
+        uring[8 * 8 - 4 + (tid - 256)] = reinterpret_cast<const uint32_t *>(st->fm_u)[tid - 256];          // U[-8 .. -1] (tile 8 is position 0)
+      }
+      else if (MODE == 2 && tid >= 320 && tid < 339)
+      {
+        vring[(2 * 8 - 19 + (tid - 320)) & (kFVDw - 1)] = reinterpret_cast<const uint32_t *>(st->fm_v)[tid - 320];   // V[-38 .. -1]
+      }
+      else if (MODE == 14 && tid >= 384 && tid < 400 && !am)
+      {
+        // SSB: the last 32 samples of the 8 kS/s rails in front of sample 0 (index 16 here: the history unit yields 16)
+        reinterpret_cast<uint32_t *>(r8k[0])[(tid - 384 + 248) & 255] = reinterpret_cast<const uint32_t *>(st->ssb_i)[tid - 384];
+        reinterpret_cast<uint32_t *>(r8k[1])[(tid - 384 + 248) & 255] = reinterpret_cast<const uint32_t *>(st->ssb_q)[tid - 384];
+      }
+      else if (MODE == 14 && tid == 448)
+      {
+        rcar[0] = am ? st->am_x1 : st->ssb_x1;
+        rcar[1] = am ? st->am_y1 : st->ssb_y1;
+      }
+      else if (tid == 512)
+      {
+        gctl[2] = 0u;                                       // AM / SSB: generations through their 8 kS/s recurrence
+        gctl[3] = 0u;                                       // SSB: generations whose 8 kS/s rails are in their rings
+        ctl[0] = 1u;                                        // the stream waves start with unit 1
+        uflag[0] = 1u;                                      // unit 0, the history, is in the ring
+        thfin[0] = thfin[1] = thfin[2] = thfin[3] = 0u;
+      }
     }
-    else if (MODE == 2 && tid >= 256 && tid < 260)
+    if (tid < 128)
     {
-      uring[8 * 8 - 4 + (tid - 256)] = reinterpret_cast<const uint32_t *>(st->fm_u)[tid - 256];          // U[-8 .. -1] (tile 8 is position 0)
+      dbfs8[tid] = (int8_t)P.dbfs[tid];
     }
-    else if (MODE == 2 && tid >= 320 && tid < 339)
-    {
-      vring[(2 * 8 - 19 + (tid - 320)) & (kFVDw - 1)] = reinterpret_cast<const uint32_t *>(st->fm_v)[tid - 320];   // V[-38 .. -1]
-    }
-    else if (MODE == 14 && tid >= 384 && tid < 400 && !am)
-    {
-      // SSB: the last 32 samples of the 8 kS/s rails in front of sample 0 (index 16 here: the history unit yields 16)
-      reinterpret_cast<uint32_t *>(r8k[0])[(tid - 384 + 248) & 255] = reinterpret_cast<const uint32_t *>(st->ssb_i)[tid - 384];
-      reinterpret_cast<uint32_t *>(r8k[1])[(tid - 384 + 248) & 255] = reinterpret_cast<const uint32_t *>(st->ssb_q)[tid - 384];
-    }
-    else if (MODE == 14 && tid == 448)
-    {
-      rcar[0] = am ? st->am_x1 : st->ssb_x1;
-      rcar[1] = am ? st->am_y1 : st->ssb_y1;
-    }
-    else if (tid == 512)
-    {
-      gctl[2] = 0u;                                       // AM / SSB: generations through their 8 kS/s recurrence
-      gctl[3] = 0u;                                       // SSB: generations whose 8 kS/s rails are in their rings
-      ctl[0] = 1u;                                        // the stream waves start with unit 1
-      uflag[0] = 1u;                                      // unit 0, the history, is in the ring
-      thfin[0] = thfin[1] = thfin[2] = thfin[3] = 0u;
-    }
-  }
-  if (tid < 128)
-  {
-    dbfs8[tid] = (int8_t)P.dbfs[tid];
-  }
-  __syncthreads();                                       // the only workgroup barriers of the kernel
-  FLOW_TIME_SET(43)
+    __syncthreads();                                       // the only workgroup barriers of the kernel
+    FLOW_TIME_SET(43)
 
-  if (wave >= SVC)
+    return true;
+  }
+
+  // ------------------------------------------------------------------------------------------ stream waves
+  __device__ __forceinline__ void stream_waves()
   {
     // =================================================================== stream waves: raw IQ -> v
 #if HRFD_FLOW_STREAM_PRIO == 1
@@ -956,10 +1008,10 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
     }
 #endif
   }
-  else
+
+  // --------------------------------------------------------------------------- service waves, FIR modes
+  __device__ __forceinline__ void service_waves_fir()
   {
-    if constexpr (!kWb)
-    {
     // =================================================================== service waves, FIR modes: rails -> PCM
     // Generations of 64 tiles as for WBFM, one tile (64 samples of both rails) per lane:
     //   a. the lane's tile through the FIRST decimator, straight out of the ring with the few samples of the tile in
@@ -1441,9 +1493,11 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
         lds_st((MODE == 14) ? &gctl[2] : &ctl[2], (uint32_t)g + 1u);
       }
     }
-    }
-    else
-    {
+  }
+
+  // -------------------------------------------------------------------------------- service waves, WBFM
+  __device__ __forceinline__ void service_waves_wbfm()
+  {
     // =================================================================== service waves: v -> PCM
     __builtin_amdgcn_s_setprio(HRFD_FLOW_SVC_PRIO);      // long dependent chains, few issue slots
     const float a1 = DEEMPH_A1;
@@ -1846,185 +1900,212 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
       atomicAdd(&P.counters[kCntRepair], repairs);
       atomicAdd(&P.sticky[kCntTotRepair], repairs);
     }
-    }
   }
-  // The last wave of the last workgroup of a channel finishes the channel (finish_channel: squelch tracker, checks
-  // of both speculations, n_pcm / allowed outputs, commit of the pending state): no kernel behind this one.
-  // Release / acquire at agent scope around the two counters (MI355X_MICROARCH, "Workgroup dispatch ... visibility").
-  if (GATED)
+
+  // ------------------------------------------------------------------------------------------------ finish
+  __device__ __forceinline__ void finish()
   {
-    // The exact pass over the allowed blocks is through.  The channel's last wave writes the squelch outputs of every
-    // block, commits the pending state -- the demodulator's section when any block was demodulated (it is the state
-    // behind the LAST ALLOWED block: a closed gate freezes it), the front end's 16 bytes and the tracker always --
-    // and takes the channel's failure back: nothing is left for the host to replay.  A wait that expired keeps it.
-    if (fail_code != 0u && lane == 0)
+    // The last wave of the last workgroup of a channel finishes the channel (finish_channel: squelch tracker, checks
+    // of both speculations, n_pcm / allowed outputs, commit of the pending state): no kernel behind this one.
+    // Release / acquire at agent scope around the two counters (MI355X_MICROARCH, "Workgroup dispatch ... visibility").
+    if (GATED)
     {
-      lds_st(&ctl[6], 1u);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the FIR modes' pending state went to memory: complete before the count)
-    uint32_t prev = 0;
-    if (lane == 0)
-    {
-      prev = atomicAdd(&ctl[5], 1u);
-    }
-    if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
-    {
-      lds_order();
-      if (lds_ld(&ctl[6]) == 0u)
+      // The exact pass over the allowed blocks is through.  The channel's last wave writes the squelch outputs of every
+      // block, commits the pending state -- the demodulator's section when any block was demodulated (it is the state
+      // behind the LAST ALLOWED block: a closed gate freezes it), the front end's 16 bytes and the tracker always --
+      // and takes the channel's failure back: nothing is left for the host to replay.  A wait that expired keeps it.
+      if (fail_code != 0u && lane == 0)
       {
-        const uint32_t nb = P.n_blocks;
-        const EpilogueParams &E = P.fin;
-        ChanState *dst = P.state + c;
-        // allowed[b]: b is in the list
-        bool allowed = false;
-        for (uint32_t k = 0; k < n_stream_blocks; k++)
-        {
-          allowed = allowed || (uint32_t)blist[k] == (uint32_t)lane;
-        }
-        if ((uint32_t)lane < nb)
-        {
-          const size_t ounit = (size_t)c * E.out_blocks + E.out_b0 + lane;
-          if (E.allowed != nullptr)
-          {
-            E.allowed[ounit] = allowed ? 1 : 0;
-          }
-          if (E.n_pcm != nullptr)
-          {
-            E.n_pcm[ounit] = allowed ? E.n_pcm_per_block : 0u;
-          }
-        }
-        if (lane < 4)
-        {
-          reinterpret_cast<uint32_t *>(dst->fe_tail)[lane] = lds_ld(&finl[162 + lane]);
-        }
-        if (kWb && n_stream_blocks != 0u && lane < 30)
-        {
-          reinterpret_cast<uint32_t *>(&dst->wb_theta)[lane] = lds_ld(&finl[128 + lane]);
-        }
-        if (!kWb && n_stream_blocks != 0u)
-        {
-          // the mode's section of the pending state, as the service waves left it in memory (written on this CU)
-          int off, nd;
-          state_section(cfg.mode, off, nd);
-          const uint32_t *ssec = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(P.state_out + c) + off);
-          uint32_t *dsec = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(dst) + off);
-          for (int i = lane; i < nd; i += 64)
-          {
-            dsec[i] = ssec[i];
-          }
-        }
-        if (lane == 0)
-        {
-          dst->tracking = lds_ld(&gctl[1]) != 0u ? 1u : 0u;
-          E.chan_fail[c] = 0u;
-          E.chan_poison[c] = 0u;
-          atomicSub(&E.counters[kCntFail], 1u);
-          atomicSub(&E.sticky[kCntTotViol], 1u);
-          atomicAdd(&E.sticky[kCntTotGated], 1u);
-        }
+        lds_st(&ctl[6], 1u);
       }
-    }
-  }
-  else if (local)
-  {
-    // the channel was this workgroup's alone: every input of the verdict is in LDS, nothing is read back from memory
-    // (no wait for this wave's stores either: the end of the kernel is their fence)
-    if (fail_code != 0u && lane == 0)
-    {
-      lds_st(&ctl[6], 1u);
-    }
-    uint32_t prev = 0;
-    if (lane == 0)
-    {
-      prev = atomicAdd(&ctl[5], 1u);
-    }
-    if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
-    {
-      lds_order();
-      const uint32_t nb = P.n_blocks;
-      FinishIn<3> I;
-      I.mode = 3;
-      I.tracking = lds_ld(&finl[160]);
-      I.poison = lds_ld(&finl[161]);
-      I.expired = lds_ld(&ctl[6]);
-      I.pres0 = ((uint32_t)lane < nb) ? (lds_ld(&blkout[lane]) >> 31) : 0u;
-      I.pl_raw = lds_ld(&blkout[(nb - 1u) & 63u]) >> 31;
-      I.pp_raw = lds_ld(&blkout[(nb - 2u) & 63u]) >> 31;  // n_blocks >= 2 here
-      // one run: the value published in front of a block IS the one the block started from (a NaN fails, as ever)
-      I.spec0 = (lane > 0 && (uint32_t)lane < nb) ? u2f(lds_ld(&finl[lane])) : 0.0f;
-      I.pub0 = I.spec0;
-      I.fe = (lane < 4) ? lds_ld(&finl[162 + lane]) : 0u;
-      I.sec[0] = (lane < 30) ? lds_ld(&finl[128 + lane]) : 0u;
-      finish_apply<3>(P.fin, c, lane, I);
-    }
-  }
-  else if (P.self_finish)
-  {
-    if (fail_code != 0u && lane == 0)
-    {
-      P.fin.chan_expired[c] = 1u;
-    }
-    // this wave's global stores are done (they are in the XCD's L2, which every wave of this CU reads through) ...
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t prev = 0;
-    if (lane == 0)
-    {
-      prev = atomicAdd(&ctl[5], 1u);
-    }
-    if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
-    {
-      // ... and this is the last wave of the workgroup.  A channel cut into several runs is finished by the workgroup
-      // that arrives last; what the others wrote comes from other CUs, possibly other XCDs: one agent-scope release
-      // per workgroup in front of the arrival count, one acquire behind it (MI355X_MICROARCH, "Workgroup dispatch,
-      // XCD placement & inter-workgroup visibility").  One run per channel (the usual case): nothing to fence.
-      bool last = true;
-      if (P.n_runs > 1u)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the FIR modes' pending state went to memory: complete before the count)
+      uint32_t prev = 0;
+      if (lane == 0)
       {
-        if ((uint32_t)(P.dbg_flags >> 16) == 8000u + run && ci == 0u)
+        prev = atomicAdd(&ctl[5], 1u);
+      }
+      if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
+      {
+        lds_order();
+        if (lds_ld(&ctl[6]) == 0u)
         {
-          for (int z = 0; z < 15; z++)
+          const uint32_t nb = P.n_blocks;
+          const EpilogueParams &E = P.fin;
+          ChanState *dst = P.state + c;
+          // allowed[b]: b is in the list
+          bool allowed = false;
+          for (uint32_t k = 0; k < n_stream_blocks; k++)
           {
-            __builtin_amdgcn_s_sleep(127);
+            allowed = allowed || (uint32_t)blist[k] == (uint32_t)lane;
           }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        uint32_t arrived = 0;
-        if (lane == 0)
-        {
-          arrived = __hip_atomic_fetch_add(&P.fin.chan_arrived[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        last = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived) == P.n_runs - 1u;
-        if (last)
-        {
+          if ((uint32_t)lane < nb)
+          {
+            const size_t ounit = (size_t)c * E.out_blocks + E.out_b0 + lane;
+            if (E.allowed != nullptr)
+            {
+              E.allowed[ounit] = allowed ? 1 : 0;
+            }
+            if (E.n_pcm != nullptr)
+            {
+              E.n_pcm[ounit] = allowed ? E.n_pcm_per_block : 0u;
+            }
+          }
+          if (lane < 4)
+          {
+            reinterpret_cast<uint32_t *>(dst->fe_tail)[lane] = lds_ld(&finl[162 + lane]);
+          }
+          if (kWb && n_stream_blocks != 0u && lane < 30)
+          {
+            reinterpret_cast<uint32_t *>(&dst->wb_theta)[lane] = lds_ld(&finl[128 + lane]);
+          }
+          if (!kWb && n_stream_blocks != 0u)
+          {
+            // the mode's section of the pending state, as the service waves left it in memory (written on this CU)
+            int off, nd;
+            state_section(cfg.mode, off, nd);
+            const uint32_t *ssec = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(P.state_out + c) + off);
+            uint32_t *dsec = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(dst) + off);
+            for (int i = lane; i < nd; i += 64)
+            {
+              dsec[i] = ssec[i];
+            }
+          }
           if (lane == 0)
           {
-            __hip_atomic_store(&P.fin.chan_arrived[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero between launches
+            dst->tracking = lds_ld(&gctl[1]) != 0u ? 1u : 0u;
+            E.chan_fail[c] = 0u;
+            E.chan_poison[c] = 0u;
+            atomicSub(&E.counters[kCntFail], 1u);
+            atomicSub(&E.sticky[kCntTotViol], 1u);
+            atomicAdd(&E.sticky[kCntTotGated], 1u);
           }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
       }
-      if (last)
+    }
+    else if (local)
+    {
+      // the channel was this workgroup's alone: every input of the verdict is in LDS, nothing is read back from memory
+      // (no wait for this wave's stores either: the end of the kernel is their fence)
+      if (fail_code != 0u && lane == 0)
       {
-        finish_channel<kWb ? 3 : -1>(P.fin, c, lane);
+        lds_st(&ctl[6], 1u);
+      }
+      uint32_t prev = 0;
+      if (lane == 0)
+      {
+        prev = atomicAdd(&ctl[5], 1u);
+      }
+      if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
+      {
+        lds_order();
+        const uint32_t nb = P.n_blocks;
+        FinishIn<3> I;
+        I.mode = 3;
+        I.tracking = lds_ld(&finl[160]);
+        I.poison = lds_ld(&finl[161]);
+        I.expired = lds_ld(&ctl[6]);
+        I.pres0 = ((uint32_t)lane < nb) ? (lds_ld(&blkout[lane]) >> 31) : 0u;
+        I.pl_raw = lds_ld(&blkout[(nb - 1u) & 63u]) >> 31;
+        I.pp_raw = lds_ld(&blkout[(nb - 2u) & 63u]) >> 31;  // n_blocks >= 2 here
+        // one run: the value published in front of a block IS the one the block started from (a NaN fails, as ever)
+        I.spec0 = (lane > 0 && (uint32_t)lane < nb) ? u2f(lds_ld(&finl[lane])) : 0.0f;
+        I.pub0 = I.spec0;
+        I.fe = (lane < 4) ? lds_ld(&finl[162 + lane]) : 0u;
+        I.sec[0] = (lane < 30) ? lds_ld(&finl[128 + lane]) : 0u;
+        finish_apply<3>(P.fin, c, lane, I);
+      }
+    }
+    else if (P.self_finish)
+    {
+      if (fail_code != 0u && lane == 0)
+      {
+        P.fin.chan_expired[c] = 1u;
+      }
+      // this wave's global stores are done (they are in the XCD's L2, which every wave of this CU reads through) ...
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      uint32_t prev = 0;
+      if (lane == 0)
+      {
+        prev = atomicAdd(&ctl[5], 1u);
+      }
+      if (__builtin_amdgcn_readfirstlane((int)prev) == kWaves - 1)
+      {
+        // ... and this is the last wave of the workgroup.  A channel cut into several runs is finished by the workgroup
+        // that arrives last; what the others wrote comes from other CUs, possibly other XCDs: one agent-scope release
+        // per workgroup in front of the arrival count, one acquire behind it (MI355X_MICROARCH, "Workgroup dispatch,
+        // XCD placement & inter-workgroup visibility").  One run per channel (the usual case): nothing to fence.
+        bool last = true;
+        if (P.n_runs > 1u)
+        {
+          if ((uint32_t)(P.dbg_flags >> 16) == 8000u + run && ci == 0u)
+          {
+            for (int z = 0; z < 15; z++)
+            {
+              __builtin_amdgcn_s_sleep(127);
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          uint32_t arrived = 0;
+          if (lane == 0)
+          {
+            arrived = __hip_atomic_fetch_add(&P.fin.chan_arrived[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          last = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived) == P.n_runs - 1u;
+          if (last)
+          {
+            if (lane == 0)
+            {
+              __hip_atomic_store(&P.fin.chan_arrived[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero between launches
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+        if (last)
+        {
+          finish_channel<kWb ? 3 : -1>(P.fin, c, lane);
+        }
+      }
+    }
+    FLOW_TIME_MAX(46)
+    if (P.dbg != nullptr && lane == 0)
+    {
+      // per wave: cycles spent waiting (ring full / units not there yet / generation order); slot 0: the workgroup's cycles
+      P.dbg[(size_t)blockIdx.x * kDbgSlots + 8 + wave] = waited;
+      if (fail_code != 0u)
+      {
+        P.dbg[(size_t)blockIdx.x * kDbgSlots + 7] = 0x100000000ull * fail_code + (unsigned)wave + 1u;
+      }
+      if (tid == 0)
+      {
+        P.dbg[(size_t)blockIdx.x * kDbgSlots + 0] = __builtin_readcyclecounter() - t_kernel;
       }
     }
   }
-  FLOW_TIME_MAX(46)
-  if (P.dbg != nullptr && lane == 0)
+};
+
+template <int SVC, bool GATED, bool DUMP, int MODE>
+__device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds)
+{
+  Flow<SVC, GATED, DUMP, MODE> F(P, lds);
+  if (!F.setup())
   {
-    // per wave: cycles spent waiting (ring full / units not there yet / generation order); slot 0: the workgroup's cycles
-    P.dbg[(size_t)blockIdx.x * kDbgSlots + 8 + wave] = waited;
-    if (fail_code != 0u)
-    {
-      P.dbg[(size_t)blockIdx.x * kDbgSlots + 7] = 0x100000000ull * fail_code + (unsigned)wave + 1u;
-    }
-    if (tid == 0)
-    {
-      P.dbg[(size_t)blockIdx.x * kDbgSlots + 0] = __builtin_readcyclecounter() - t_kernel;
-    }
+    return;
   }
+  if (F.wave >= SVC)
+  {
+    F.stream_waves();
+  }
+  else if constexpr (MODE != 3)
+  {
+    F.service_waves_fir();
+  }
+  else
+  {
+    F.service_waves_wbfm();
+  }
+  F.finish();
 }
 
 template <int SVC, bool GATED, bool DUMP, int MODE = 3>
