@@ -7,6 +7,8 @@
 #include "../../include/hrfd.h"
 #include "hrfd_tx_kernels.hip"
 #include "hrfd_api.hip"
+#include "hrfd_api_tx.hip"
+#include "hrfd_api_debug.hip"
 #include "hrfd_ingest.hip"
 #include "hrfd_fanout.hip"
 #include "hrfd_txring.hip"
