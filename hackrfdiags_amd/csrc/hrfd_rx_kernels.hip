@@ -88,22 +88,32 @@ __device__ __forceinline__ uint32_t lane63(uint32_t v)
 // no field goes negative; the (int8_t) narrowing of IqDataProcessor.cc:458,489
 // keeps the low byte only, which that does not touch.
 // Checked exhaustively against the direct form in tests/test_abi_and_tables.py.
-// b2 = 2 b' (form_b2 of the previous stage)
+// Round 4: the kernel is bound by the NUMBER of vector instructions it issues (SQ counters: one VALU instruction per
+// SIMD and ~4 cycles, whatever its encoding -- profiles/r4_sq_counters.txt), so a (shift, mask) pair on both fields is
+// ONE packed shift (v_pk_lshrrev_b16: the fields cannot leak into each other, nothing to mask), stage 3's constant rides
+// on the three-input add that forms T, and the doubled centre tap of stage 3 on a shift-and-add.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_shr(uint32_t v, unsigned short k)
+{
+  return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, v) >> k));
+}
+// b2 = 2 b' (the centre tap, doubled)
 __device__ __forceinline__ uint32_t hb2_sum(uint32_t a, uint32_t b2, uint32_t c)
 {
   const uint32_t t = a + c;
-  const uint32_t k = (as_u32(as_s2(t) * (short)57 + (short)1792) >> 13) & 0x00070007u;
+  const uint32_t k = pk_shr(as_u32(as_s2(t) * (short)57 + (short)1792), 13);    // 0..3 per field
   return t + b2 + k;
 }
-__device__ __forceinline__ uint32_t hb3_sum(uint32_t a, uint32_t b2, uint32_t c)
+// b = b' (the centre tap as the previous stage's output, NOT doubled).  T' = T + (-8 + 4*256) per field feeds the
+// multiply as well: 29 T' + 38888 = 29 T + 2816 + 65536, and the packed multiply-add keeps 16 bits.
+__device__ __forceinline__ uint32_t hb3_sum(uint32_t a, uint32_t b, uint32_t c)
 {
-  const uint32_t t = a + c;
-  const uint32_t k = (as_u32(as_s2(t) * (short)29 + (short)2816) >> 10) & 0x003f003fu;
-  return t + b2 + k + 0x03f803f8u;                       // (-8 + 4*256) per field
+  const uint32_t t = a + c + 0x03f803f8u;
+  const uint32_t k = pk_shr(as_u32(as_s2(t) * (short)29 + (short)38888), 10);   // 2..17 per field
+  return ((b << 1) + t) + k;
 }
-// a stage's sum as the next stage's outer tap (y') or centre tap (2 y')
-__device__ __forceinline__ uint32_t form_ac(uint32_t s) { return (s >> 2) & 0x00ff00ffu; }
-__device__ __forceinline__ uint32_t form_b2(uint32_t s) { return (s >> 1) & 0x01fe01feu; }
+// a stage-2 sum (<= 1023 per field) as the next stage's tap y'
+__device__ __forceinline__ uint32_t form_ac(uint32_t s) { return pk_shr(s, 2); }
 
 // Stage 1 (h0 = 8206) works on BYTES, four at a time, with the pixel-average instruction
 // v_lerp_u8 (per byte (x + y + r) >> 1, r = bit 0 of the matching byte of the third operand).
@@ -154,7 +164,7 @@ __device__ __forceinline__ uint32_t frontend(const uint4 raw, FeCarry &c)
 
   const uint32_t y1m1 = shr1(y13, c.y13);
   c.y13 = ror1(y13);
-  const uint32_t y20b = form_b2(hb2_sum(y1m1, y10 << 1, y11));
+  const uint32_t y20b = form_ac(hb2_sum(y1m1, y10 << 1, y11));
   const uint32_t y21 = form_ac(hb2_sum(y11, y12 << 1, y13));
 
   const uint32_t y2m1 = shr1(y21, c.y21);
@@ -1802,21 +1812,23 @@ __global__ __launch_bounds__(kThreads, 8) void k_rx_wbfm(const RxParams P)
 template <int ROT>
 __device__ __forceinline__ uint32_t mix_fs4_const(uint32_t y3)
 {
-  // rot 0 (I,Q), 1 (-Q,I), 2 (-I,-Q), 3 (Q,-I) in offset-binary index form, see mix_fs4
+  // rot 0 (I,Q), 1 (-Q,I), 2 (-I,-Q), 3 (Q,-I) in offset-binary index form, see mix_fs4.  Negation of an index is
+  // (256 - idx) & 255; the fields of y3 may carry anything above their low byte (the mask comes last), so the packed
+  // forms below act modulo 256 per field: one packed subtract negates both, one packed multiply-add (-1, +1) one of them.
   if (ROT == 0)
   {
     return y3 & 0x00ff00ffu;
   }
   if (ROT == 2)
   {
-    return ((y3 ^ 0x00ff00ffu) + 0x00010001u) & 0x00ff00ffu;
+    return as_u32(as_s2(0x01000100u) - as_s2(y3)) & 0x00ff00ffu;
   }
-  const uint32_t sw = __builtin_amdgcn_alignbit(y3, y3, 16);
+  const s2 sw = as_s2(__builtin_amdgcn_alignbit(y3, y3, 16));
   if (ROT == 1)
   {
-    return ((sw ^ 0x000000ffu) + 0x00000001u) & 0x00ff00ffu;
+    return as_u32(sw * s2{(short)-1, (short)1} + s2{(short)256, (short)0}) & 0x00ff00ffu;
   }
-  return ((sw ^ 0x00ff0000u) + 0x00010000u) & 0x00ff00ffu;
+  return as_u32(sw * s2{(short)1, (short)-1} + s2{(short)0, (short)256}) & 0x00ff00ffu;
 }
 
 struct QuadCarry
@@ -1875,7 +1887,7 @@ __device__ __forceinline__ void quad_front(const uint4 (&raw)[4], FeCarry &fe, u
   for (int j = 0; j < 4; j++)
   {
     const uint32_t y1m1 = (j == 0) ? y1m1_0 : y1[j > 0 ? j - 1 : 0][3];
-    y20b[j] = form_b2(hb2_sum(y1m1, y1[j][0] << 1, y1[j][1]));
+    y20b[j] = form_ac(hb2_sum(y1m1, y1[j][0] << 1, y1[j][1]));
     y21[j] = form_ac(hb2_sum(y1[j][1], y1[j][2] << 1, y1[j][3]));
   }
   // stage 3, mixer

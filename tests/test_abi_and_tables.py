@@ -146,3 +146,23 @@ def test_halfband_offset_domain_formula():
     y = s3 >> M(2)
     assert ((y & M(0xFF)).astype(np.int64) == ((direct(8424, a, b, c) + 128) & 0xFF)).all()
     assert (((y >> M(16)) & M(0xFF)).astype(np.int64) == ((direct(8424, qa, qb, qc) + 128) & 0xFF)).all()
+
+    # Round 4 forms (hb2_sum / hb3_sum / form_ac with v_pk_lshrrev_b16: a shift per 16-bit field, nothing to mask):
+    def pk_shr(v, k):
+        return (((v & M(0xFFFF)) >> M(k)) | (((v >> M(16)) >> M(k)) << M(16))).astype(np.uint32)
+
+    def pk_mad_wrap(t, d, k):                              # v_pk_mad_u16 keeps the low 16 bits of every field
+        lo = ((t & M(0xFFFF)).astype(np.int64) * d + k) & 0xFFFF
+        hi = ((t >> M(16)).astype(np.int64) * d + k) & 0xFFFF
+        return (lo | (hi << 16)).astype(np.uint32)
+
+    s2n = t + (pb << M(1)) + pk_shr(pk_mad(t, 57, 1792), 13)
+    assert (s2n == s2).all() and (pk_shr(s2n, 2) == ac).all()
+    tp = t + M(0x03F803F8)                                 # T' = T - 8 + 4 * 256 per field: no field overflows
+    assert ((tp & M(0xFFFF)) < 2048).all() and ((tp >> M(16)) < 2048).all()
+    s3n = ((pb << M(1)) + tp) + pk_shr(pk_mad_wrap(tp, 29, 38888), 10)
+    assert (s3n == s3).all()
+    # the mixer's packed negations act modulo 256 per field, whatever sits above the low byte (s3 >> 2 carries the
+    # neighbour's low bits in bits 14..15 of the low field): (0x0100 - field) & 0xFF == (256 - (field & 0xFF)) & 0xFF
+    lo = (y & M(0xFFFF)).astype(np.int64)
+    assert (((0x100 - lo) & 0xFF) == ((256 - (lo & 0xFF)) & 0xFF)).all()

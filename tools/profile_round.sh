@@ -1,8 +1,7 @@
 #!/bin/bash
-# Runs on the GPU box: rocprofv3 kernel-trace stats of the default bench (and of the other bench workloads when
-# a second argument is given), then the HBM traffic counters in separate PMC passes (MI355X_MICROARCH.md,
-# "rocprofv3 PMC slots").  The PMC summary carries the tag of the kernel sources it was taken with
-# (bench.kernel_source_tag), so that bench.py reports it only for the code it measured.
+# Runs on the GPU box: rocprofv3 --kernel-trace --stats of the default bench (and of the other bench workloads when
+# a second argument is given): per-kernel call counts and durations.  (The HBM traffic counters are tools/pmc_round.sh,
+# the SQ counters tools/sq_round.sh: counters are collected in runs of their own, never with --stats.)
 # usage: tools/profile_round.sh <tag> [all]
 TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp
@@ -38,26 +37,6 @@ if [ "$2" = "all" ]; then
   stats am256x16 --steps 100 --warmup 50 --workload am
   stats fm256x16 --steps 100 --warmup 50 --workload fm
   stats ssb256x16 --steps 100 --warmup 50 --workload ssb
+  stats ammod1024 --steps 100 --warmup 50 --workload ammod
+  stats fmmod1024 --steps 100 --warmup 50 --workload fmmod
 fi
-for CNT in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc_$CNT -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extras > /dev/null 2> $O/pmc_$CNT.log
-done
-python3 - "$O" "$R" <<'PY'
-import csv, glob, collections, json, sys
-O, R = sys.argv[1], sys.argv[2]
-sys.path.insert(0, R)
-acc = collections.defaultdict(list)
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(O + "/pmc_" + c + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "k_rx_wbfm" in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-summ = {k: {"n": len(v), "mean": sum(v) / len(v)} for k, v in acc.items()}
-import importlib.util
-spec = importlib.util.spec_from_file_location("bench", R + "/bench.py"); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
-summ["kernel_source_tag"] = b.kernel_source_tag()
-summ["kernel"] = "hrfd::k_rx_wbfm_flow"
-json.dump(summ, open(O + "/pmc_traffic.json", "w"), indent=1)
-print(summ)
-PY
-rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
