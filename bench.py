@@ -53,22 +53,27 @@ def make_fm_batch(channels, blocks, device, first_channel=0):
     """FM test signal of SURVEY.md 8(d), generated on the GPU: carrier at -64 kHz,
     +-30 kHz deviation by a (300 + 100*(c mod 32)) Hz tone, amplitude 100, uniform
     noise in [-3,4].  (Same signal family as hackrfdiags_amd/synth.py; the noise
-    comes from torch's generator here, so the bytes differ from the test vectors.)"""
+    comes from torch's generator here, so the bytes differ from the test vectors.)
+    Thirty-two channels per pass (round 4; one channel per pass before): a 1024-channel batch is ~400 torch dispatches
+    instead of ~12 000 -- a counter pass of rocprofv3 segfaulted inside this function at the larger number."""
     n = blocks * (BLOCK // 2)
     out = torch.empty((channels, blocks, BLOCK), dtype=torch.int8, device=device)
     k = torch.arange(n, dtype=torch.float64, device=device)
     gen = torch.Generator(device=device)
-    for c in range(channels):
-        ch = first_channel + c
-        f_c = 300.0 + 100.0 * (ch % 32)
+    G = 32
+    for g0 in range(0, channels, G):
+        g = min(G, channels - g0)
+        ch = first_channel + g0 + torch.arange(g, device=device)
+        f_c = (300.0 + 100.0 * (ch % 32)).to(torch.float64)[:, None]
         beta = 30000.0 / f_c
-        phi = (2.0 * np.pi * (-64000.0) / 2048000.0) * k - beta * (torch.cos((2.0 * np.pi * f_c / 2048000.0) * k) - 1.0)
-        gen.manual_seed(12345 + ch)
-        noise = torch.randint(-3, 5, (2, n), device=device, generator=gen, dtype=torch.int32)
-        i = torch.round(100.0 * torch.cos(phi)).to(torch.int32) + noise[0]
-        q = torch.round(100.0 * torch.sin(phi)).to(torch.int32) + noise[1]
-        iq = torch.stack([i, q], dim=1).to(torch.int8)          # [n, 2] interleaved
-        out[c] = iq.reshape(blocks, BLOCK)
+        phi = (2.0 * np.pi * (-64000.0) / 2048000.0) * k[None, :] - beta * (torch.cos((2.0 * np.pi / 2048000.0) * f_c * k[None, :]) - 1.0)
+        gen.manual_seed(12345 + first_channel + g0)
+        noise = torch.randint(-3, 5, (g, 2, n), device=device, generator=gen, dtype=torch.int32)
+        i = torch.round(100.0 * torch.cos(phi)).to(torch.int32) + noise[:, 0]
+        q = torch.round(100.0 * torch.sin(phi)).to(torch.int32) + noise[:, 1]
+        del phi, noise
+        out[g0:g0 + g] = torch.stack([i, q], dim=2).to(torch.int8).reshape(g, blocks, BLOCK)   # [g, n, 2] interleaved
+        del i, q
     return out
 
 
@@ -246,7 +251,7 @@ def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle,
     achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
     fill = stream_gbs(device, 1, out) if (rank == 0 and extras) else None
     if fill is not None:
-        assert achieved <= fill, f"the modulator writes faster ({achieved:.0f} GB/s) than a kernel that does nothing else ({fill:.0f}): a denominator is wrong"
+        assert under_profiler() or achieved <= fill, f"the modulator writes faster ({achieved:.0f} GB/s) than a kernel that does nothing else ({fill:.0f}): a denominator is wrong"
     m.close()
     del out, pcm
     torch.cuda.empty_cache()                             # the next workload of the line starts from a clean allocator
@@ -474,6 +479,14 @@ def pmc_traffic(name):
     if not w:
         return None, "no PMC summary for this workload"
     return int(w["FETCH_SIZE_KiB"] * 1024 * 2 + w["WRITE_SIZE_KiB"] * 1024), f"profiles/latest_pmc_traffic.json[{name}], device code {_PMC['kernel_code_tag']}"
+
+
+def under_profiler():
+    """rocprofv3 preloads its tool library into the process: counter passes serialize every dispatch and change the
+    clocks, so timings taken there are not comparable with each other (a 32768-workgroup stream kernel suffers more than a
+    256-workgroup persistent one) -- the bandwidth assertion below is for plain runs."""
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("HSA_TOOLS_LIB", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    return "rocprof" in pre.lower() or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ)
 
 
 def stream_gbs(device, kind, buf=None):
@@ -956,7 +969,8 @@ def main():
     read_gbs = stream_gbs(device, 0)
     write_gbs = stream_gbs(device, 1)
     # a read-only kernel cannot read faster than the kernel that does nothing else: if it does, a denominator is wrong
-    assert r["achieved"] <= read_gbs, f"{r['achieved']:.0f} GB/s algorithmic > {read_gbs:.0f} GB/s of the plain read kernel"
+    assert under_profiler() or r["achieved"] <= read_gbs, \
+        f"{r['achieved']:.0f} GB/s algorithmic > {read_gbs:.0f} GB/s of the plain read kernel"
     value, achieved = r["value"], r["achieved"]
 
     if rank == 0:
@@ -1014,7 +1028,7 @@ def main():
                              "launches": counters[6]},
             "kernel_code_tag": kernel_code_tag(),
             "kernel_source_tag": kernel_source_tag(),
-            "runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+            "runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "under_profiler": under_profiler()},
         }
         if counters[5] != 0:
             # a launch that did not commit means later launches started from a stale state and the batch path was

@@ -214,6 +214,33 @@ def test_fm_modulator_within_one_lsb(oracle):
 ARR_MOD, MAN_MOD = G.load_mod()
 
 
+@pytest.mark.parametrize("n", [8192, 4096, 4096 + 64 + 3, 4032, 8192 + 512 + 7])
+def test_fm_modulator_time_slices(oracle, n):
+    """Round 4: a call of 64 tiles or more (4096 PCM samples) runs in three time slices -- the phase recurrence and the
+    cos / sin pass of every slice on the handle's own stream ahead of the cascade launch of the slice in front.  The
+    sliced call must equal the unsliced one (hook) BYTE FOR BYTE (same kernels, same arithmetic, only the order of
+    launches differs), the oracle within the +-1 LSB of the trig path, and leave the state a second call continues from.
+    Lengths: 16 blocks, the shortest call that is sliced and its lower neighbour (unsliced), ragged tails (the last
+    slice's recurrence then runs on the plain kernel)."""
+    C = 5
+    pcm = np.stack([synth.lcg_pcm(170 + c, 2 * n) for c in range(C)])
+    a, b = api.Mod(api.MOD_FM, C), api.Mod(api.MOD_FM, C)
+    b.debug_set_sliced(0)
+    for m in (a, b):
+        m.set_param(2500.0, channel=1)
+    os_ = [oracle.fmmod() for _ in range(C)]
+    os_[1].set_param(2500.0)
+    for call in range(2):
+        x = pcm[:, call * n:(call + 1) * n]
+        ga, gb = a.process(x), b.process(x)
+        assert (ga == gb).all(), call
+        for c in range(C):
+            want = os_[c].process(x[c])
+            d = np.abs(ga[c].astype(np.int16) - want.astype(np.int16))
+            d = np.minimum(d, 256 - d)
+            assert d.max() <= 1 and (d != 0).mean() < 0.02, (call, c)
+
+
 @pytest.mark.parametrize("case", MAN_MOD["am"], ids=lambda c: c["key"])
 def test_golden_am_modulator(engine, case):
     G.check_am_mod(engine, ARR_MOD, case)
