@@ -902,3 +902,54 @@ def test_setters_from_a_second_thread(oracle):
         for b in range(4):
             p = o.process(xs[c, B + b])[0]
             assert (tail[c, b, :len(p)] == p).all(), (c, B + b)
+
+
+import os as _os
+
+
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(_os.environ.get("HRFD_WALK_SEEDS", "8")))))
+def test_random_walk_of_calls_against_the_oracle(oracle, seed):
+    """A differential walk nobody chose: a bank of 3..70 channels in random modes (NONE included), and a sequence of
+    calls with random block counts (1 = the reference's cadence and the exact per-block kernels, 2..20 = the batch
+    kernels), block sizes (whole units, half units, the 1024-byte minimum), input kinds, and -- between calls -- mode
+    switches, gain changes and squelch thresholds that do and do not close gates.  Every channel against its own
+    sequential oracle: PCM, n_pcm, magnitude, signal_allowed of every block, bit for bit, state carried across
+    everything."""
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.integers(3, 71))
+    all_modes = [NONE, AM, FM, WBFM, LSB, USB]
+    modes = [all_modes[int(rng.integers(0, 6))] for _ in range(C)]
+    if seed % 2:
+        modes = [WBFM if m in (AM, NONE) else m for m in modes]     # (odd seeds: mostly the flow kernels' banks)
+    rx = api.Rx(C)
+    orc = []
+    for c in range(C):
+        rx.set_mode(modes[c], channel=c)
+        o = oracle.rx(); o.set_mode(modes[c]); orc.append(o)
+    kinds = ["fmtone", "lcg", "amtone", "zeros", "dc_neg", "dc_pos", "impulse"]
+    seeds = [int(rng.integers(0, 10000)) for _ in range(C)]
+    ckind = [kinds[int(rng.integers(0, len(kinds)))] if rng.random() < 0.5 else "fmtone" for _ in range(C)]
+    for call in range(5):
+        bb = int(rng.choice([262144, 262144, 131072, 65536, 36864, 258048, 8192, 1024]))
+        B = int(rng.choice([1, 1, 2, 3, 5, 16, 20])) if bb >= 8192 else int(rng.choice([1, 2, 7]))
+        need = (B * bb + BLK - 1) // BLK
+        xs = np.stack([synth.make_input(ckind[c], seeds[c] + 17 * call, need)[:B * bb].reshape(B, bb) for c in range(C)])
+        # between calls: what the CLI thread does to a running radio (diagUi.cc: set demodmode / gains / squelch)
+        for c in range(C):
+            r = rng.random()
+            if r < 0.10:
+                modes[c] = all_modes[int(rng.integers(1, 6))]
+                rx.set_mode(modes[c], channel=c); orc[c].set_mode(modes[c])
+            elif r < 0.20 and modes[c] != NONE:
+                g = float(rng.choice([1.0, 300.0, 4000.0, 40743.6, 2.5e5]))
+                gm = LSB if modes[c] == USB else modes[c]
+                rx.set_gain(gm, g, channel=c); orc[c].set_gain(gm, g)
+            elif r < 0.30:
+                t = int(rng.choice([-200, -60, -30, -22, -10]))
+                rx.set_threshold(t, channel=c); orc[c].set_threshold(t)
+        pcm, n_pcm, mag, allowed, _ = rx.process_block(xs, B)
+        for c in range(C):
+            for b in range(B):
+                p, m, a, _ = orc[c].process(xs[c, b])
+                assert n_pcm[c, b] == len(p) and int(mag[c, b]) == m and bool(allowed[c, b]) == a, (seed, call, c, b, modes[c], bb, B)
+                assert (pcm[c, b, :len(p)] == p).all(), (seed, call, c, b, modes[c], bb, B)
