@@ -254,3 +254,50 @@ def test_golden_fm_modulator(engine, case):
 @pytest.mark.parametrize("case", MAN_MOD["wbfm"], ids=lambda c: c["key"])
 def test_golden_wbfm_modulator(engine, case):
     G.check_wbfm_mod(engine, ARR_MOD, case)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(__import__("os").environ.get("HRFD_WALK_SEEDS", "6")))))
+def test_random_walk_of_modulator_calls(oracle, seed):
+    """The transmit mirror of the receive side's random walk: banks of 1..40 modulators of one kind, calls of random length
+    (1 sample .. beyond the 64-tile mark from which the FM and WBFM modulators run in time slices), parameter changes,
+    sideband switches and resets between calls; every channel against its own oracle object.  Bit-exact, FM within the
+    +-1 LSB of the trig path."""
+    rng = np.random.default_rng(5000 + seed)
+    kind = ["ssb", "am", "fm", "wbfm"][seed % 4]
+    C = int(rng.integers(1, 41))
+    amod = {"ssb": api.MOD_SSB, "am": api.MOD_AM, "fm": api.MOD_FM, "wbfm": api.MOD_WBFM}[kind]
+    m = api.Mod(amod, C)
+    if kind == "ssb":
+        lsb = [True] * C
+        os_ = [oracle.ssbmod(True) for _ in range(C)]
+    else:
+        os_ = [getattr(oracle, kind + "mod")() for _ in range(C)]
+    total = 0
+    for call in range(5):
+        n = int(rng.choice([1, 33, 512, 700, 1537, 4096, 4163, 6000, 8192]))
+        if kind == "wbfm":
+            n = min(n, 4163)                               # (the oracle's x32 stage is slow: keep the walk short)
+        pcm = np.stack([synth.lcg_pcm(int(rng.integers(0, 10000)), n) if rng.random() < 0.8 else np.full(n, int(rng.integers(-32768, 32768)), dtype=np.int16)
+                        for _ in range(C)])
+        for c in range(C):
+            r = rng.random()
+            if r < 0.15:
+                m.reset(channel=c); os_[c].reset()
+            elif r < 0.35:
+                if kind == "ssb":
+                    lsb[c] = not lsb[c]
+                    m.set_sideband(lsb[c], channel=c); os_[c].set_sideband(lsb[c])
+                else:
+                    v = {"am": float(rng.choice([0.0, 0.3, 0.8, 1.0])), "fm": float(rng.choice([500.0, 1200.0, 3500.0])),
+                         "wbfm": float(rng.choice([10000.0, 30000.0, 70000.0, 112000.0]))}[kind]
+                    m.set_param(v, channel=c); os_[c].set_param(v)
+        got = np.atleast_2d(m.process(pcm))                 # (one channel: api.Mod.process returns its row)
+        for c in range(C):
+            if kind == "ssb":
+                want = np.concatenate([os_[c].process(pcm[c, s:min(s + 512, n)]) for s in range(0, n, 512)])
+            else:
+                want = os_[c].process(pcm[c])
+            d = np.abs(got[c].astype(np.int16) - want.astype(np.int16))
+            d = np.minimum(d, 256 - d)
+            assert d.max() <= (1 if kind == "fm" else 0), (seed, kind, call, c, n)
+        total += n
