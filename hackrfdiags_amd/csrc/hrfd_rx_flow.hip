@@ -38,14 +38,8 @@
 #ifndef HRFD_FLOW_SVC
 #define HRFD_FLOW_SVC 4
 #endif
-#ifndef HRFD_FLOW_EARLY_GRAB
-#define HRFD_FLOW_EARLY_GRAB 1      /* take the next unit before piece 0 (its LDS round trip hides behind the piece) instead of behind it */
-#endif
 #ifndef HRFD_FLOW_WARM_TILES
 #define HRFD_FLOW_WARM_TILES 2      /* warm-up of the recurrence tiles, in tiles of 64 samples (2: ~7e-4 of the tiles are repaired in place) */
-#endif
-#ifndef HRFD_FLOW_STREAM_PRIO
-#define HRFD_FLOW_STREAM_PRIO 3      /* 0 none, 1 / 2 static by wave age, 3 by lag (a wave that has fallen behind gets priority) */
 #endif
 #ifndef HRFD_FLOW_SVC_PRIO
 #define HRFD_FLOW_SVC_PRIO 3
@@ -609,14 +603,6 @@ struct Flow
   __device__ __forceinline__ void stream_waves()
   {
     // =================================================================== stream waves: raw IQ -> v
-#if HRFD_FLOW_STREAM_PRIO == 1
-    // the arbiter serves the oldest wave of a SIMD first: the young ones lag, hold the ring's completed frontier back and
-    // the old ones run into the ring limit.  Static priorities the other way round.
-    if (wave >= 12) __builtin_amdgcn_s_setprio(2);
-    else if (wave >= 8) __builtin_amdgcn_s_setprio(1);
-#elif HRFD_FLOW_STREAM_PRIO == 2
-    if (wave >= 12) __builtin_amdgcn_s_setprio(1);
-#endif
     StreamCtx X;
     X.P = &P;
     X.kgain = kgain;
@@ -816,23 +802,21 @@ struct Flow
       uint32_t v[4], mag4, magsum;
       uint32_t iqb[2] = {0u, 0u};
       float theta[4];
-#if HRFD_FLOW_EARLY_GRAB
+      // the next unit is taken BEFORE piece 0 (the counter's LDS round trip hides behind the piece; taking it behind the
+      // piece was measured slower in round 2 and is gone)
       uint32_t un_v = 0;
       if (lane == 0)
       {
         lds_add_async(un_v, &ctl[0], 1u);
       }
-#endif
       // (the next unit's loads go out from inside the pieces, as soon as a piece's raw registers are free:
       //  almost two pieces of lead without a register more)
       int un = 0;
       VM_WAIT(4, "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]));
       // what happens at the point where a piece's raw registers are free: the next unit's first loads
       auto refill_a = [&](const uint32_t (&y1)[4][4]) {
-#if HRFD_FLOW_EARLY_GRAB
         lds_landed(un_v);
         un = __builtin_amdgcn_readfirstlane((int)un_v);
-#if HRFD_FLOW_STREAM_PRIO == 3
         // fairness: the arbiter serves the oldest wave of a SIMD first, so the young ones fall behind, hold the
         // ring's completed frontier back and the old ones run into the ring limit.  A wave that sees more units
         // taken since its own than there are stream waves is late: it gets priority until its next unit.
@@ -851,10 +835,6 @@ struct Flow
             __builtin_amdgcn_s_setprio(0);
           }
         }
-#endif
-#else
-        un = grab();
-#endif
         uoff_n = (un < n_units) ? unit_off(un) : 0u;
         load_c16(c16, uoff_n, un < n_units);
         load_piece(qa, uoff_n, 0, un < n_units, y1);
