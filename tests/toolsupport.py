@@ -81,3 +81,19 @@ def playback_model(image: np.ndarray, index: int, nbytes: int):
     """DataProvider::retrieveIqDataFromBuffer as index arithmetic."""
     idx = (index + np.arange(nbytes, dtype=np.int64)) % len(image)
     return image[idx], int((index + nbytes) % len(image))
+
+
+def retune_minus_64k(iq: np.ndarray) -> np.ndarray:
+    """The channel between the reference's transmitter and its receiver: int8 IQ at 2.048 MS/s moved DOWN by 64 kHz.
+    The radio tunes its receiver 64 kHz (a quarter of the 256 kS/s rate) high and IqDataProcessor::upconvertByFsOver4
+    brings the signal back to 0 Hz (Radio.cc:1187-1191, IqDataProcessor.cc:771-815): a transmitter's baseband therefore
+    reaches the demodulators only through this shift.  exp(-j pi n / 16), rounded to the nearest integer, clipped to
+    int8.  Test infrastructure (numpy, float64); the golden manifest holds the sha256 of what it produced there."""
+    x = np.ascontiguousarray(iq, dtype=np.int8).astype(np.float64)
+    z = x[0::2] + 1j * x[1::2]
+    n = np.arange(z.size, dtype=np.int64) % 32
+    z = z * np.exp(-1j * np.pi * n / 16.0)
+    out = np.empty(iq.size, dtype=np.int8)
+    out[0::2] = np.clip(np.rint(z.real), -128, 127).astype(np.int8)
+    out[1::2] = np.clip(np.rint(z.imag), -128, 127).astype(np.int8)
+    return out
