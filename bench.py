@@ -969,7 +969,7 @@ def main():
     read_gbs = stream_gbs(device, 0)
     write_gbs = stream_gbs(device, 1)
     # a read-only kernel cannot read faster than the kernel that does nothing else: if it does, a denominator is wrong
-    assert under_profiler() or r["achieved"] <= read_gbs, \
+    assert under_profiler() or rehearse or r["achieved"] <= read_gbs, \
         f"{r['achieved']:.0f} GB/s algorithmic > {read_gbs:.0f} GB/s of the plain read kernel"
     value, achieved = r["value"], r["achieved"]
 
