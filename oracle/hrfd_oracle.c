@@ -25,10 +25,11 @@
 #include "hrfd_oracle_tables.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-#define ORC_MAXTAPS 64
+#define ORC_MAXTAPS 128      /* the longest table of the path has 40 taps; the reference's own Decimator_int16 test program uses 80 */
 
 /* ------------------------------------------------------------------ helpers */
 
@@ -109,8 +110,18 @@ static void q15_reset(q15_t *s)
   s->phase = 0;
 }
 
+static void taps_fit(int n)
+{
+  if (n < 1 || n > ORC_MAXTAPS)
+  {
+    fprintf(stderr, "hrfd oracle: %d taps (1..%d)\n", n, ORC_MAXTAPS);
+    abort();
+  }
+}
+
 static void q15_init(q15_t *s, const float *h, int n, int m)
 {
+  taps_fit(n);
   memset(s, 0, sizeof(*s));
   s->n = n;
   s->m = m;
@@ -159,6 +170,7 @@ typedef struct
 
 static void q15i_init(q15i_t *s, const float *h, int n, int l)
 {
+  taps_fit(n);
   memset(s, 0, sizeof(*s));
   s->n = n;
   s->l = l;
@@ -210,6 +222,7 @@ typedef struct
 
 static void firf_init(firf_t *s, const float *h, int n)
 {
+  taps_fit(n);
   memset(s, 0, sizeof(*s));
   s->n = n;
   memcpy(s->h, h, (size_t)n * sizeof(float));
@@ -244,6 +257,7 @@ static void iirf_init(iirf_t *s, const float *b, int nb, const float *a, int na)
 {
   memset(s, 0, sizeof(*s));
   firf_init(&s->num, b, nb);
+  taps_fit(na);
   s->na = na;
   memcpy(s->a, a, (size_t)na * sizeof(float));
 }

@@ -1,5 +1,7 @@
 """The CPU oracle against the committed golden vectors (which were produced by
 the reference's own compiled sources -- tests/golden/make_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -77,3 +79,20 @@ def test_fm_modulator(oracle, case):
 @pytest.mark.parametrize("case", MAN_MOD["wbfm"], ids=lambda c: c["key"])
 def test_wbfm_modulator(oracle, case):
     G.check_wbfm_mod(oracle, ARR_MOD, case)
+
+
+def test_oracle_reproduces_the_references_decimate_audio_program(oracle):
+    """The reference's own test program of Decimator_int16 (Filters/Int16/decimateAudio.cc: original32000.raw through an
+    80-tap prototype, M = 4), run HERE by the reference itself on the head of its own input file
+    (tests/golden/make_golden_decimate_audio.py).  The oracle's D(N, M, h) -- the primitive every receive chain is made of
+     -- must give the program's 80 000 output samples."""
+    import json
+    arr = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_decimate_audio.npz"))
+    man = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_decimate_audio.json")))
+    x = np.zeros(320000, dtype=np.int16)                    # the program's static buffer: what the file does not fill is zero
+    x[:arr["input_head"].size] = arr["input_head"]
+    y = oracle.decimate(arr["taps"], 4, x)
+    assert y.size == man["output_samples"] == 80000
+    assert (y[:12000] == arr["output_head"]).all()
+    from hackrfdiags_amd import synth
+    assert synth.digest(y) == man["output_sha256"]
