@@ -1515,6 +1515,17 @@ void orc_interpolate(const float *coeffs, int taps, int factor,
   q15i_run(&s, in, count, out);
 }
 
+/* FirFilter over a buffer (FirFilter.cc:144-185), from a cleared state. */
+void orc_fir(const float *h, int n, const float *in, uint32_t count, float *out)
+{
+  firf_t s;
+  firf_init(&s, h, n);
+  for (uint32_t k = 0; k < count; k++)
+  {
+    out[k] = firf_step(&s, in[k]);
+  }
+}
+
 void orc_iir(const float *b, int nb, const float *a, int na,
              const float *in, uint32_t count, float *out)
 {

@@ -111,6 +111,7 @@ uint32_t orc_decimate(const float *coeffs, int taps, int factor,
                       const int16_t *in, uint32_t count, int16_t *out);
 void orc_interpolate(const float *coeffs, int taps, int factor,
                      const int16_t *in, uint32_t count, int16_t *out);
+void orc_fir(const float *h, int n, const float *in, uint32_t count, float *out);
 void orc_iir(const float *b, int nb, const float *a, int na,
              const float *in, uint32_t count, float *out);
 int16_t orc_float_to_int16(float v);

@@ -102,6 +102,7 @@ class Oracle:
         L.orc_decimate.argtypes = [_f32p, C.c_int, C.c_int, _i16p, C.c_uint32, _i16p]
         L.orc_interpolate.argtypes = [_f32p, C.c_int, C.c_int, _i16p, C.c_uint32, _i16p]
         L.orc_iir.argtypes = [_f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_uint32, _f32p]
+        L.orc_fir.argtypes = [_f32p, C.c_int, _f32p, C.c_uint32, _f32p]
         L.orc_float_to_int16.restype = C.c_int16
         L.orc_float_to_int16.argtypes = [C.c_float]
         L.orc_atan2_lut.argtypes = [_f32p]
@@ -134,6 +135,13 @@ class Oracle:
         x = np.ascontiguousarray(x, dtype=np.int16)
         out = np.zeros(len(x) * factor, dtype=np.int16)
         self.lib.orc_interpolate(_p(c, _f32p), len(c), factor, _p(x, _i16p), len(x), _p(out, _i16p))
+        return out
+
+    def fir(self, h, x) -> np.ndarray:
+        h = np.ascontiguousarray(h, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros(len(x), dtype=np.float32)
+        self.lib.orc_fir(_p(h, _f32p), len(h), _p(x, _f32p), len(x), _p(out, _f32p))
         return out
 
     def iir(self, b, a, x) -> np.ndarray:

@@ -96,3 +96,23 @@ def test_oracle_reproduces_the_references_decimate_audio_program(oracle):
     assert (y[:12000] == arr["output_head"]).all()
     from hackrfdiags_amd import synth
     assert synth.digest(y) == man["output_sha256"]
+
+
+def _filter_program_sections():
+    import json
+    man = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_filter_programs.json")))
+    return [pytest.param(s, id=f"{prog}-{k}") for prog, secs in man.items() for k, s in enumerate(secs)]
+
+
+@pytest.mark.parametrize("sec", _filter_program_sections())
+def test_oracle_prints_what_the_references_filter_programs_print(oracle, sec):
+    """The reference's own smoke programs of FirFilter and IirFilter (Filters/testFirFilter.cc:25-67, testIirFilter.cc:
+    26-108: impulse and step through {1,2,3,4,1,1,1,8}, {1}/{0.5} and the dc-removal pair {1,-1}/{-0.95} of the AM and SSB
+    demodulators), run HERE by the reference itself (tests/golden/make_golden_filter_programs.py).  The oracle's float
+    filter -- the one under every demodulator's de-emphasis, differentiator and dc removal -- printed the same way must
+    give the same text."""
+    if sec["denominator"]:
+        y = oracle.iir(sec["numerator"], sec["denominator"], sec["input"])
+    else:
+        y = oracle.fir(sec["numerator"], sec["input"])
+    assert ["%f" % float(v) for v in y] == sec["printed"]
