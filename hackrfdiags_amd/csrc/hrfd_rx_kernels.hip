@@ -349,6 +349,24 @@ __device__ __forceinline__ AtanApprox atan2_from_t0(float t0, bool swap, bool ne
 
 __device__ __forceinline__ float theta_tab(uint32_t mixed, const uint8_t *corr, const float *t0tab)
 {
+#if (HRFD_ABLATE_EARLY & 8192)
+  // TIMING EXPERIMENT ONLY (wrong values): the instruction shape of a first-QUADRANT table whose words carry the 2-bit
+  // correction of the i < 0 half in their two free top bits
+  {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const s2 d = as_s2(mixed) - as_s2(0x00800080u);
+    const s2 nd = as_s2(0u) - d;
+    const s2 ad = __builtin_elementwise_max(d, nd);
+    const uint32_t off = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, ad), __builtin_bit_cast(us2, (65u * 4u) << 16 | 4u), 0u, false);
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(t0tab) + off);
+    const uint32_t t = w & 0x3fffffffu;
+    const int32_t fix = (int32_t)w >> 30;
+    const uint32_t pv = f2u(kPiF - u2f(t)) + (uint32_t)fix;
+    const uint32_t m = (uint32_t)((int32_t)(mixed << 24) >> 31);   // all ones: i >= 0
+    const uint32_t sel = __builtin_amdgcn_bitop3_b32(t, pv, m, 0xE4);   // m ? t : pv
+    return u2f(__builtin_amdgcn_bitop3_b32(sel, mixed << 8, 0x80000000u, 0xF2));
+  }
+#endif
   const s2 d = as_s2(mixed) - as_s2(0x00800080u);
   const s2 nd = as_s2(0u) - d;
   const s2 ad = __builtin_elementwise_max(d, nd);
