@@ -139,6 +139,7 @@ def load() -> C.CDLL:
     L.hrfd_mod_process_device.argtypes = [_vp, _vp, C.c_uint32, _vp, _vp]
     L.hrfd_mod_sync.argtypes = [_vp]
     L.hrfd_mod_debug_set_sliced.argtypes = [_vp, C.c_int]
+    L.hrfd_mod_debug_set_scan.argtypes = [_vp, C.c_int]
     L.hrfd_play_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(_vp)]
     L.hrfd_play_destroy.argtypes = [_vp]
     L.hrfd_play_load_file.argtypes = [_vp, C.c_char_p]

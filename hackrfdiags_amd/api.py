@@ -392,6 +392,10 @@ class Mod:
         stream has CUs of its own (the default), 2 = always"""
         check(self.L.hrfd_mod_debug_set_sliced(self.h, int(mode)), "hrfd_mod_debug_set_sliced")
 
+    def debug_set_scan(self, kind: int):
+        """test hook (FM, WBFM): 1 = the phase recurrence on round 2's k_phase_scan<64> (0: k_phase_rows, the default)"""
+        check(self.L.hrfd_mod_debug_set_scan(self.h, int(kind)), "hrfd_mod_debug_set_scan")
+
     def process_device(self, d_pcm, n, d_out, stream=None):
         check(self.L.hrfd_mod_process_device(self.h, _ptr(d_pcm), n, _ptr(d_out), _ptr(stream)),
               "hrfd_mod_process_device")

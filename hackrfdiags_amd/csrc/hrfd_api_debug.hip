@@ -296,3 +296,15 @@ extern "C" int hrfd_mod_debug_set_sliced(hrfd_mod *h, int on)
   h->sliced = on;                                          // 0 off, 1 when the recurrence's stream has CUs of its own, 2 always
   return HRFD_OK;
 }
+
+// test hook: 1 = the recurrence on k_phase_scan<64> / k_phase_scan_plain whatever the bank size (0: k_phase_rows up to 8192 channels)
+extern "C" int hrfd_mod_debug_set_scan(hrfd_mod *h, int kind)
+{
+  HRFD_HOOK_GATE("hrfd_mod_debug_set_scan");
+  if (h == nullptr || (kind != 0 && kind != 1))
+  {
+    return fail(HRFD_EINVAL, "hrfd_mod_debug_set_scan: kind 0 | 1");
+  }
+  h->scan_kind = kind;
+  return HRFD_OK;
+}

@@ -35,30 +35,26 @@ struct hrfd_mod
   bool cu_masked = false;               // the recurrence's stream has CUs of its own
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_head[kMaxSlices] = {}, ev_scan[kMaxSlices] = {};
   int sliced = 1;                        // test hook: 0 = one pass after the other on the caller's stream
+  int scan_kind = 0;                     // test hook: 1 = k_phase_scan<64> / k_phase_scan_plain whatever the bank size
   // staging for the host entry
   int16_t *d_in = nullptr;
   int8_t *d_out = nullptr;
   size_t cap_in = 0, cap_out = 0;
 };
 
-// the Nco phase recurrence over `steps` cells per channel, rows `row_stride` cells apart (k_phase_scan: 16-byte pieces)
+// the Nco phase recurrence over `steps` cells per channel, rows `row_stride` cells apart: k_phase_rows (four channels per
+// wave, a lone wave per SIMD up to 4096 channels, two up to 8192: the wave's time per step is the same; whole chunks of 16
+// steps, which every call and every time slice is); banks beyond that put more waves on a SIMD than that shape likes and
+// keep round 2's k_phase_scan<64> (64 channels per recurrence wave)
 static void phase_scan(hrfd_mod *h, uint32_t *cells, size_t steps, size_t row_stride, float *d_acc, uint32_t n_channels, hipStream_t s)
 {
-  if ((steps & 3) == 0 && (row_stride & 3) == 0)
+  if (h->scan_kind != 1 && n_channels <= 8192u && (steps & 15) == 0 && row_stride < ((size_t)1 << 28))
   {
-    // channels per workgroup: as few as still fit the chip in one round (one workgroup per CU)
-    if (n_channels <= 16u * 256u)
-    {
-      hipLaunchKernelGGL(k_phase_scan<16>, dim3((n_channels + 15) / 16), dim3(kPsThreads), 0, s, cells, steps, row_stride, d_acc, n_channels, h->d_err);
-    }
-    else if (n_channels <= 32u * 256u)
-    {
-      hipLaunchKernelGGL(k_phase_scan<32>, dim3((n_channels + 31) / 32), dim3(kPsThreads), 0, s, cells, steps, row_stride, d_acc, n_channels, h->d_err);
-    }
-    else
-    {
-      hipLaunchKernelGGL(k_phase_scan<64>, dim3((n_channels + 63) / 64), dim3(kPsThreads), 0, s, cells, steps, row_stride, d_acc, n_channels, h->d_err);
-    }
+    hipLaunchKernelGGL(k_phase_rows, dim3((n_channels + 15) / 16), dim3(kPrThreads), 0, s, cells, steps, row_stride, d_acc, n_channels);
+  }
+  else if ((steps & 3) == 0 && (row_stride & 3) == 0)
+  {
+    hipLaunchKernelGGL(k_phase_scan<64>, dim3((n_channels + 63) / 64), dim3(kPsThreads), 0, s, cells, steps, row_stride, d_acc, n_channels, h->d_err);
   }
   else
   {

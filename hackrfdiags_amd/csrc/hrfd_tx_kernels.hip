@@ -1051,9 +1051,244 @@ __global__ __launch_bounds__(kPsThreads) void k_phase_scan(uint32_t *cells, size
   }
 }
 
-template __global__ void k_phase_scan<16>(uint32_t *, size_t, size_t, float *, uint32_t, uint32_t *);
-template __global__ void k_phase_scan<32>(uint32_t *, size_t, size_t, float *, uint32_t, uint32_t *);
 template __global__ void k_phase_scan<64>(uint32_t *, size_t, size_t, float *, uint32_t, uint32_t *);
+
+// ---- round 4: the recurrence as a shift register across a row of lanes -------------------------------------------
+// k_phase_scan's recurrence wave spends 27 of its 43 cycles per step on its five instructions (a lone wave issues one
+// vector instruction per ~5.4 cycles, dependent or not) and the rest on carrying cells between LDS and its registers:
+// lane = channel means every step's input and output is a dword of its own in every lane.  Here lane = TIME: a channel
+// is a row of 16 lanes, lane j of the row holds step 16 i + j of chunk i exactly as one coalesced dword load delivers
+// it, and the accumulator travels along the row through the DPP operand of the add itself:
+//     x = row_shr:1(w) + step          (lane j takes w of lane j - 1; lane 0 has no source and KEEPS its x)
+//     w = wrap(x)                      (mul, rndne, fma, fma as above)
+// sixteen times.  Every lane executes every round; lane 0's x was set to (last chunk's final w) + step[0] by one
+// row_ror:1 add in front, so after round t lanes 0 .. t hold their final values -- a lane whose left neighbour is
+// final recomputes the same value again, the lanes to the right compute on values that are not final yet and are
+// overwritten when their turn comes.  After sixteen rounds w of lane j is the accumulator BEHIND step 16 i + j, i.e.
+// the phase of cell 16 i + j + 1: it is stored one cell to the right, as one dword store (the cell behind the chunk
+// is the next chunk's first step, requested sixteen chunks earlier by the same wave: memory operations of a wave on
+// one address keep their order).  Five vector instructions per step and nothing else: no LDS, no mover waves, no
+// flags, no waits to expire.  Four channels per wave, four waves (one per SIMD) per workgroup.
+// A chunk with a step above 4.85 or a start above pi takes the reference's loops in the same arrangement.
+constexpr int kPrThreads = 256;
+
+template <bool ROR>
+__device__ __forceinline__ void pr_add(float &x, const float w, const float st)
+{
+  // (the two wait states a DPP read of a register needs behind the VALU write of it: the compiler does not look into
+  //  inline assembly)
+  if (ROR)
+  {
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(w), "v"(st));
+  }
+  else
+  {
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(w), "v"(st));
+  }
+}
+
+// The pipeline is ONE piece of assembly: the steps are requested sixteen chunks ahead straight into the registers they
+// are consumed from, with COUNTED waits (memory operations of a wave complete in order on this part: when chunk i is due,
+// the operations behind its request are the requests of the chunks up to i + 15 and the stores of the chunks since) --
+// registers that have a load on its way must not be the compiler's to move, and left to itself it also waits for
+// everything in flight before every chunk (round 1's 60 ns per step).  Scalar base + one constant 32-bit offset per lane:
+// no vector address arithmetic (every vector instruction of a lone wave costs 5.4 cycles).
+//   v40 .. v55  the sixteen slots          v56 cur (the chunk's steps)   v57 w   v58 x   v59 k
+//   s40 chunks done   s41 refused   s[42:43] address   s44 chunks - 1   s45 4.85f   s[46:47] lanes 0 .. 14 of every row
+// A chunk holding a step above 4.85 (or a NaN) is refused: the pipeline stops in front of it with its steps in v56.
+#ifndef HRFD_PR_ABLATE
+#define HRFD_PR_ABLATE 0
+#endif
+#if (HRFD_PR_ABLATE & 1)   // TIMING EXPERIMENT ONLY: no stores
+#define HRFD_PR_STORE ""
+#else
+#define HRFD_PR_STORE "global_store_dword %[voff], v57, s[42:43] offset:4\n"
+#endif
+#if (HRFD_PR_ABLATE & 2)   // TIMING EXPERIMENT ONLY: no requests inside the loop
+#define HRFD_PR_LOAD(slot) ""
+#else
+#define HRFD_PR_LOAD(slot) "global_load_dword " slot ", %[voff], s[42:43]\n"
+#endif
+#define HRFD_PR_WRAP \
+  "v_mul_f32 v59, 0x3e22f984, v58\n" \
+  "v_rndne_f32 v59, v59\n" \
+  "v_fmamk_f32 v57, v59, 0xc0c90fdb, v58\n" \
+  "v_fmac_f32 v57, 0x343bbd2e, v59\n"
+// (s_nop 1: the two wait states a DPP read of a register needs behind the VALU write of it)
+#define HRFD_PR_ROUND \
+  "s_nop 1\n" \
+  "v_add_f32_dpp v58, v57, v56 row_shr:1 row_mask:0xf bank_mask:0xf\n" HRFD_PR_WRAP
+#define HRFD_PR_REQUEST(slot, chunk_sgpr_or_const) \
+  "s_min_u32 s42, " chunk_sgpr_or_const ", s44\n" \
+  "s_lshl_b32 s42, s42, 6\n" \
+  "s_add_u32 s42, %[b0], s42\n" \
+  "s_addc_u32 s43, %[b1], 0\n" \
+  "global_load_dword " slot ", %[voff], s[42:43]\n"
+#define HRFD_PR_REQUEST2(slot, chunk_sgpr_or_const) \
+  "s_min_u32 s42, " chunk_sgpr_or_const ", s44\n" \
+  "s_lshl_b32 s42, s42, 6\n" \
+  "s_add_u32 s42, %[b0], s42\n" \
+  "s_addc_u32 s43, %[b1], 0\n" \
+  HRFD_PR_LOAD(slot)
+#define HRFD_PR_TURN(slot, behind) \
+  "s_cmp_ge_u32 s40, %[n]\n" \
+  "s_cbranch_scc1 9f\n" \
+  "s_waitcnt vmcnt(" behind ")\n" \
+  "v_mov_b32 v56, " slot "\n" \
+  "v_cmp_nle_f32_e64 vcc, |v56|, s45\n" \
+  "s_cbranch_vccz 1f\n" \
+  "s_mov_b32 s41, 1\n" \
+  "s_branch 9f\n" \
+  "1:\n" \
+  "s_add_u32 s42, s40, 16\n" HRFD_PR_REQUEST2(slot, "s42") \
+  "v_add_f32_dpp v58, v57, v56 row_ror:1 row_mask:0xf bank_mask:0xf\n" HRFD_PR_WRAP \
+  HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND \
+  HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND \
+  "s_lshl_b32 s42, s40, 6\n" \
+  "s_add_u32 s42, %[b0], s42\n" \
+  "s_addc_u32 s43, %[b1], 0\n" \
+  "s_add_u32 s40, s40, 1\n" \
+  "s_cmp_eq_u32 s40, %[n]\n" \
+  "s_cselect_b64 exec, s[46:47], -1\n" \
+  HRFD_PR_STORE \
+  "s_mov_b64 exec, -1\n"
+
+// w: the phase of the call's first cell in, the accumulator behind the last chunk done out (every lane of a row: the
+// row's lane 15 is the one that counts).  Returns the chunks done; refused: the next one holds a step the branch-free wrap
+// is not proven for, `held` are its steps.  Every lane of the wave must be active.
+__device__ __forceinline__ uint32_t pr_pipeline(float &w, float &held, bool &refused, const uint32_t voff, const uint32_t *wbase, const uint32_t nchunks)
+{
+  const uint64_t b = (uint64_t)(uintptr_t)wbase;
+  const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)nchunks);
+  uint32_t done, flag;
+  asm volatile(
+      "s_mov_b32 s40, 0\n"
+      "s_mov_b32 s41, 0\n"
+      "s_sub_u32 s44, %[n], 1\n"
+      "s_mov_b32 s45, 0x409b3333\n"
+      "s_mov_b32 s46, 0x7fff7fff\n"
+      "s_mov_b32 s47, 0x7fff7fff\n"
+      "v_mov_b32 v57, %[w]\n"
+      "v_mov_b32 v56, 0\n"
+      "s_nop 4\n"
+      HRFD_PR_REQUEST("v40", "0") HRFD_PR_REQUEST("v41", "1") HRFD_PR_REQUEST("v42", "2") HRFD_PR_REQUEST("v43", "3")
+      HRFD_PR_REQUEST("v44", "4") HRFD_PR_REQUEST("v45", "5") HRFD_PR_REQUEST("v46", "6") HRFD_PR_REQUEST("v47", "7")
+      HRFD_PR_REQUEST("v48", "8") HRFD_PR_REQUEST("v49", "9") HRFD_PR_REQUEST("v50", "10") HRFD_PR_REQUEST("v51", "11")
+      HRFD_PR_REQUEST("v52", "12") HRFD_PR_REQUEST("v53", "13") HRFD_PR_REQUEST("v54", "14") HRFD_PR_REQUEST("v55", "15")
+      // the first sixteen chunks: behind the request of chunk d are 15 - d of the first requests, d later ones and d stores
+      HRFD_PR_TURN("v40", "15") HRFD_PR_TURN("v41", "16") HRFD_PR_TURN("v42", "17") HRFD_PR_TURN("v43", "18")
+      HRFD_PR_TURN("v44", "19") HRFD_PR_TURN("v45", "20") HRFD_PR_TURN("v46", "21") HRFD_PR_TURN("v47", "22")
+      HRFD_PR_TURN("v48", "23") HRFD_PR_TURN("v49", "24") HRFD_PR_TURN("v50", "25") HRFD_PR_TURN("v51", "26")
+      HRFD_PR_TURN("v52", "27") HRFD_PR_TURN("v53", "28") HRFD_PR_TURN("v54", "29") HRFD_PR_TURN("v55", "30")
+      // ... then 15 requests and 16 stores
+      "8:\n"
+      HRFD_PR_TURN("v40", "31") HRFD_PR_TURN("v41", "31") HRFD_PR_TURN("v42", "31") HRFD_PR_TURN("v43", "31")
+      HRFD_PR_TURN("v44", "31") HRFD_PR_TURN("v45", "31") HRFD_PR_TURN("v46", "31") HRFD_PR_TURN("v47", "31")
+      HRFD_PR_TURN("v48", "31") HRFD_PR_TURN("v49", "31") HRFD_PR_TURN("v50", "31") HRFD_PR_TURN("v51", "31")
+      HRFD_PR_TURN("v52", "31") HRFD_PR_TURN("v53", "31") HRFD_PR_TURN("v54", "31") HRFD_PR_TURN("v55", "31")
+      "s_branch 8b\n"
+      "9:\n"
+      "s_waitcnt vmcnt(0)\n"                               // (requests behind the end repeat the last chunk: they land in the slots)
+      "v_mov_b32 %[w], v57\n"
+      "v_mov_b32 %[held], v56\n"
+      "s_mov_b32 %[done], s40\n"
+      "s_mov_b32 %[flag], s41\n"
+      : [w] "+v"(w), [held] "=&v"(held), [done] "=&s"(done), [flag] "=&s"(flag)
+      : [voff] "v"(voff), [b0] "s"(b0), [b1] "s"(b1), [n] "s"(n)
+      : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+        "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+  refused = flag != 0u;
+  return done;
+}
+#undef HRFD_PR_TURN
+#undef HRFD_PR_REQUEST
+#undef HRFD_PR_REQUEST2
+#undef HRFD_PR_ROUND
+#undef HRFD_PR_WRAP
+
+// steps: a multiple of 16, and 4 * row_stride cells must fit a 32-bit byte offset (the host sees to both).
+// The call is a sequence of RUNS: the pipeline as far as it gets, then -- in front of a chunk it refuses, or while the
+// accumulator is above pi -- one chunk with the reference's loops in the same arrangement, then the pipeline again.
+// A run writes exactly its own cells: lanes 0 .. 14 of its last chunk store one cell to the right like everybody, lane 15
+// keeps the accumulator for the run behind, and the run's first cell (whose step had to be read first) is written when the
+// run is through.
+__global__ __launch_bounds__(kPrThreads) void k_phase_rows(uint32_t *cells, size_t steps, size_t row_stride, float *acc_io, uint32_t n_channels)
+{
+  const int j = threadIdx.x & 15;
+  // a row behind the bank repeats the bank's last channel (the same values to the same cells): no lane is ever masked
+  // (rows of ONE wave run in lockstep, so the copies cannot disturb each other; a whole wave behind the bank leaves)
+  const uint32_t cw = blockIdx.x * (uint32_t)(kPrThreads / 16) + 4u * (threadIdx.x >> 6);     // the wave's first channel
+  const uint32_t nchunks = (uint32_t)(steps / 16);
+  if (nchunks == 0u || cw >= n_channels)
+  {
+    return;
+  }
+  const uint32_t c = min(cw + ((threadIdx.x >> 4) & 3u), n_channels - 1u);
+  const uint32_t *wbase = cells + (size_t)cw * row_stride;   // (uniform over the wave: pr_pipeline takes it into SGPRs)
+  const uint32_t voff = (uint32_t)(((size_t)(c - cw) * row_stride + (size_t)j) * 4u);
+  uint32_t *row = cells + (size_t)c * row_stride;
+  float w = acc_io[c];                                    // every lane of the row; from the first chunk on, lane 15 is the one that counts
+  uint32_t i = 0;                                         // chunks done
+  bool wild = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(w) <= 3.1415927f)) != 0ull;
+  // the accumulator in front of a run, in lane 0 (whose cell it belongs in)
+  auto carry_of = [&]() -> float {
+    float cr;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(cr) : "v"(w));
+    return cr;
+  };
+  // chunk i with the reference's loops (cur: its steps, taken before anything of it is stored)
+  auto loops_chunk = [&](const float cur) {
+    const float carry = carry_of();
+    float x;
+    pr_add<true>(x, w, cur);
+#pragma nounroll
+    for (int t = 0; t < 16; t++)
+    {
+      if (t != 0)
+      {
+        pr_add<false>(x, w, cur);
+      }
+      w = ps_wrap_loops(x);
+    }
+    if (j != 15)
+    {
+      row[16u * (size_t)i + (size_t)j + 1] = __builtin_bit_cast(uint32_t, w);
+    }
+    if (j == 0)
+    {
+      row[16u * (size_t)i] = __builtin_bit_cast(uint32_t, carry);
+    }
+    i++;
+    wild = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(w) <= 3.1415927f)) != 0ull;
+  };
+#pragma nounroll
+  while (i < nchunks)
+  {
+    if (wild)
+    {
+      loops_chunk(__builtin_bit_cast(float, row[16u * (size_t)i + (size_t)j]));
+      continue;
+    }
+    const float carry = carry_of();
+    const uint32_t i0 = i;
+    float held = 0.0f;
+    bool refused = false;
+    i += pr_pipeline(w, held, refused, voff, wbase + 16u * (size_t)i0, nchunks - i0);
+    if (i != i0 && j == 0)
+    {
+      row[16u * (size_t)i0] = __builtin_bit_cast(uint32_t, carry);
+    }
+    if (i < nchunks)
+    {
+      loops_chunk(held);                                  // (refused: a step above 4.85)
+    }
+  }
+  if (j == 15)
+  {
+    acc_io[c] = w;
+  }
+}
 
 // the same recurrence for a cell count that is not a multiple of four (no 16-byte pieces): one thread per channel,
 // straight from memory

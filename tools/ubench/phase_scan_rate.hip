@@ -1,9 +1,9 @@
-// k_phase_scan alone on synthetic steps: ms per launch, ns per step, and the result against the reference's loops on
+// The Nco phase recurrence kernels alone on synthetic steps: ms per launch, ns per step, and the result against the reference's loops on
 // the host.  (Round 3 also ran a variant here that moved the cells between memory and the recurrence wave's registers
 // directly, 16 buffer_load_dwordx4 + 16 buffer_store_dwordx4 per 64 steps and no LDS: 16.91 ns per step against 16.79 --
 // what the wave pays beside its chain is the 32 128-bit transfers per chunk themselves, whichever pipeline they use.)
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../../hackrfdiags_amd/csrc -o phase_scan_rate phase_scan_rate.hip
-// Run:   ./phase_scan_rate [channels] [steps] [row_stride] [channels per workgroup: 16 | 32 | 64]
+// Run:   ./phase_scan_rate [channels] [steps] [row_stride] [kernel: 0 = k_phase_rows | 64 = k_phase_scan<64>]
 #include "hrfd_rx_kernels.hip"
 #include "../../include/hrfd.h"
 #include "hrfd_tx_kernels.hip"
@@ -20,10 +20,17 @@ static float host_wrap(float acc)
   return acc;
 }
 
-template <int K>
-static void launch(int which, uint32_t *cells, size_t steps, size_t stride, float *acc, uint32_t C, uint32_t *err)
+// K = 0: k_phase_rows (round 4: lane = time, four channels per wave); K = 64: k_phase_scan<64> (round 2: lane = channel)
+static void launch(int K, uint32_t *cells, size_t steps, size_t stride, float *acc, uint32_t C, uint32_t *err)
 {
-  hipLaunchKernelGGL((k_phase_scan<K, false>), dim3((C + K - 1) / K), dim3(kPsThreads), 0, 0, cells, steps, stride, acc, C, err, (const uint32_t *)nullptr, (uint32_t *)nullptr);
+  if (K == 0)
+  {
+    hipLaunchKernelGGL(k_phase_rows, dim3((C + 15) / 16), dim3(kPrThreads), 0, 0, cells, steps, stride, acc, C);
+  }
+  else
+  {
+    hipLaunchKernelGGL((k_phase_scan<64>), dim3((C + 63) / 64), dim3(kPsThreads), 0, 0, cells, steps, stride, acc, C, err);
+  }
 }
 
 int main(int argc, char **argv)
@@ -31,7 +38,7 @@ int main(int argc, char **argv)
   const uint32_t C = argc > 1 ? atoi(argv[1]) : 1024;
   const size_t steps = argc > 2 ? atol(argv[2]) : 262144;
   const size_t stride = argc > 3 ? atol(argv[3]) : steps;
-  const int K = argc > 4 ? atoi(argv[4]) : 16;
+  const int K = argc > 4 ? atoi(argv[4]) : 0;
   uint32_t *cells, *err;
   float *acc;
   hipMalloc(&cells, (size_t)C * stride * 4);
@@ -76,9 +83,7 @@ int main(int argc, char **argv)
       hipMemset(acc, 0, C * 4);
       hipMemset(err, 0, 64);
       hipEventRecord(e0, 0);
-      if (K == 16) launch<16>(which, cells, steps, stride, acc, C, err);
-      else if (K == 32) launch<32>(which, cells, steps, stride, acc, C, err);
-      else launch<64>(which, cells, steps, stride, acc, C, err);
+      launch(K, cells, steps, stride, acc, C, err);
       hipEventRecord(e1, 0);
       hipDeviceSynchronize();
       float ms = 0;
@@ -108,7 +113,7 @@ int main(int argc, char **argv)
           }
         }
       }
-      printf("%s<%d> %u channels x %zu steps (rows %zu apart): %.3f ms, %.2f ns per step; expired %u%s", "k_phase_scan", K, C, steps, stride,
+      printf("%s (%d) %u channels x %zu steps (rows %zu apart): %.3f ms, %.2f ns per step; expired %u%s", K == 0 ? "k_phase_rows" : "k_phase_scan<64>", K, C, steps, stride,
              ms, ms * 1e6 / steps, he[0], (check && rep == 0) ? "" : "\n");
       if (check && rep == 0)
       {
