@@ -43,12 +43,12 @@ struct hrfd_mod
 };
 
 // the Nco phase recurrence over `steps` cells per channel, rows `row_stride` cells apart: k_phase_rows (four channels per
-// wave, a lone wave per SIMD up to 4096 channels, two up to 8192: the wave's time per step is the same; whole chunks of 16
+// wave, a lone wave per SIMD up to 4096 channels, two up to 8192: the wave's time per step is the same; whole chunks of 64
 // steps, which every call and every time slice is); banks beyond that put more waves on a SIMD than that shape likes and
 // keep round 2's k_phase_scan<64> (64 channels per recurrence wave)
 static void phase_scan(hrfd_mod *h, uint32_t *cells, size_t steps, size_t row_stride, float *d_acc, uint32_t n_channels, hipStream_t s)
 {
-  if (h->scan_kind != 1 && n_channels <= 8192u && (steps & 15) == 0 && row_stride < ((size_t)1 << 28))
+  if (h->scan_kind != 1 && n_channels <= 8192u && (steps & 63) == 0 && row_stride < ((size_t)1 << 28))
   {
     hipLaunchKernelGGL(k_phase_rows, dim3((n_channels + 15) / 16), dim3(kPrThreads), 0, s, cells, steps, row_stride, d_acc, n_channels);
   }

@@ -1055,22 +1055,22 @@ template __global__ void k_phase_scan<64>(uint32_t *, size_t, size_t, float *, u
 
 // ---- round 4: the recurrence as a shift register across a row of lanes -------------------------------------------
 // k_phase_scan's recurrence wave spends 27 of its 43 cycles per step on its five instructions (a lone wave issues one
-// vector instruction per ~5.4 cycles, dependent or not) and the rest on carrying cells between LDS and its registers:
-// lane = channel means every step's input and output is a dword of its own in every lane.  Here lane = TIME: a channel
-// is a row of 16 lanes, lane j of the row holds step 16 i + j of chunk i exactly as one coalesced dword load delivers
-// it, and the accumulator travels along the row through the DPP operand of the add itself:
-//     x = row_shr:1(w) + step          (lane j takes w of lane j - 1; lane 0 has no source and KEEPS its x)
-//     w = wrap(x)                      (mul, rndne, fma, fma as above)
-// sixteen times.  Every lane executes every round; lane 0's x was set to (last chunk's final w) + step[0] by one
-// row_ror:1 add in front, so after round t lanes 0 .. t hold their final values -- a lane whose left neighbour is
-// final recomputes the same value again, the lanes to the right compute on values that are not final yet and are
-// overwritten when their turn comes.  After sixteen rounds w of lane j is the accumulator BEHIND step 16 i + j, i.e.
-// the phase of cell 16 i + j + 1: it is stored one cell to the right, as one dword store (the cell behind the chunk
-// is the next chunk's first step, requested sixteen chunks earlier by the same wave: memory operations of a wave on
-// one address keep their order).  Five vector instructions per step and nothing else: no LDS, no mover waves, no
-// flags, no waits to expire.  Four channels per wave, four waves (one per SIMD) per workgroup.
-// A chunk with a step above 4.85 or a start above pi takes the reference's loops in the same arrangement.
+// vector instruction per ~5.4 cycles) and the rest on carrying cells between LDS and its registers: lane = channel means
+// every step's input and output is a dword of its own in every lane.  Here lane = TIME: a channel is a row of 16 lanes,
+// lane j of the row holds steps 4 j .. 4 j + 3 of a chunk of 64 exactly as one coalesced 16-byte load delivers them, and
+// the accumulator travels along the row through the DPP operand of the add itself:
+//     x0 = row_shr:1(w3) + step0       (lane j takes w3 of lane j - 1; lane 0 has no source and KEEPS its x0)
+//     w0 = wrap(x0);  w1 = wrap(w0 + step1);  w2 = wrap(w1 + step2);  w3 = wrap(w2 + step3)     (mul, rndne, fma, fma each)
+// sixteen times.  Every lane executes every round; lane 0's x0 was set to (last chunk's final w3) + step0 by a row_ror:1
+// add in front, so after round t lanes 0 .. t hold their final values -- a lane whose left neighbour is final recomputes
+// the same four values again (each has a register of its own), the lanes to the right compute on values that are not
+// final yet and are overwritten when their turn comes.  After sixteen rounds w0..w3 of lane j are the accumulators BEHIND
+// steps 4 j .. 4 j + 3, i.e. the phases of cells 4 j + 1 .. 4 j + 4: stored one cell to the right, as one 16-byte store.
+// Five vector instructions per step, a DPP hop (two wait states and a slower operand path) per four, and nothing else: no
+// LDS, no mover waves, no flags, no waits that could expire.  Four channels per wave, four waves (one per SIMD) per
+// workgroup.
 constexpr int kPrThreads = 256;
+constexpr int kPrChunk = 64;                              // steps per chunk and row
 
 template <bool ROR>
 __device__ __forceinline__ void pr_add(float &x, const float w, const float st)
@@ -1087,76 +1087,95 @@ __device__ __forceinline__ void pr_add(float &x, const float w, const float st)
   }
 }
 
-// The pipeline is ONE piece of assembly: the steps are requested sixteen chunks ahead straight into the registers they
+// The pipeline is ONE piece of assembly: the steps are requested eight chunks ahead straight into the registers they
 // are consumed from, with COUNTED waits (memory operations of a wave complete in order on this part: when chunk i is due,
-// the operations behind its request are the requests of the chunks up to i + 15 and the stores of the chunks since) --
+// the operations behind its request are the requests of the chunks up to i + 7 and the stores of the chunks since) --
 // registers that have a load on its way must not be the compiler's to move, and left to itself it also waits for
 // everything in flight before every chunk (round 1's 60 ns per step).  Scalar base + one constant 32-bit offset per lane:
 // no vector address arithmetic (every vector instruction of a lone wave costs 5.4 cycles).
-//   v40 .. v55  the sixteen slots          v56 cur (the chunk's steps)   v57 w   v58 x   v59 k
+//   v[40:71]  eight slots of four        v[72:75] the chunk's steps    v76 .. v79 w0 .. w3    v80 x    v81 k    v82 x0
 //   s40 chunks done   s41 refused   s[42:43] address   s44 chunks - 1   s45 4.85f   s[46:47] lanes 0 .. 14 of every row
-// A chunk holding a step above 4.85 (or a NaN) is refused: the pipeline stops in front of it with its steps in v56.
+//   s48 round counter   s[50:51] scratch   s[52:53] lane 15 of every row
+// A chunk holding a step above 4.85 (or a NaN) is refused: the pipeline stops in front of it with its steps in v[72:75].
 #ifndef HRFD_PR_ABLATE
 #define HRFD_PR_ABLATE 0
 #endif
 #if (HRFD_PR_ABLATE & 1)   // TIMING EXPERIMENT ONLY: no stores
-#define HRFD_PR_STORE ""
+#define HRFD_PR_STORE4 ""
 #else
-#define HRFD_PR_STORE "global_store_dword %[voff], v57, s[42:43] offset:4\n"
+#define HRFD_PR_STORE4 "global_store_dwordx4 %[voff], v[76:79], s[42:43] offset:4\n"
 #endif
 #if (HRFD_PR_ABLATE & 2)   // TIMING EXPERIMENT ONLY: no requests inside the loop
 #define HRFD_PR_LOAD(slot) ""
 #else
-#define HRFD_PR_LOAD(slot) "global_load_dword " slot ", %[voff], s[42:43]\n"
+#define HRFD_PR_LOAD(slot) "global_load_dwordx4 " slot ", %[voff], s[42:43]\n"
 #endif
-#define HRFD_PR_WRAP \
-  "v_mul_f32 v59, 0x3e22f984, v58\n" \
-  "v_rndne_f32 v59, v59\n" \
-  "v_fmamk_f32 v57, v59, 0xc0c90fdb, v58\n" \
-  "v_fmac_f32 v57, 0x343bbd2e, v59\n"
+#define HRFD_PR_WRAP(x, dst) \
+  "v_mul_f32 v81, 0x3e22f984, " x "\n" \
+  "v_rndne_f32 v81, v81\n" \
+  "v_fmamk_f32 " dst ", v81, 0xc0c90fdb, " x "\n" \
+  "v_fmac_f32 " dst ", 0x343bbd2e, v81\n"
+#define HRFD_PR_LANE \
+  HRFD_PR_WRAP("v82", "v76") \
+  "v_add_f32 v80, v76, v73\n" HRFD_PR_WRAP("v80", "v77") \
+  "v_add_f32 v80, v77, v74\n" HRFD_PR_WRAP("v80", "v78") \
+  "v_add_f32 v80, v78, v75\n" HRFD_PR_WRAP("v80", "v79")
 // (s_nop 1: the two wait states a DPP read of a register needs behind the VALU write of it)
 #define HRFD_PR_ROUND \
   "s_nop 1\n" \
-  "v_add_f32_dpp v58, v57, v56 row_shr:1 row_mask:0xf bank_mask:0xf\n" HRFD_PR_WRAP
-#define HRFD_PR_REQUEST(slot, chunk_sgpr_or_const) \
+  "v_add_f32_dpp v82, v79, v72 row_shr:1 row_mask:0xf bank_mask:0xf\n" HRFD_PR_LANE
+#define HRFD_PR_ADDR(chunk_sgpr_or_const) \
   "s_min_u32 s42, " chunk_sgpr_or_const ", s44\n" \
-  "s_lshl_b32 s42, s42, 6\n" \
+  "s_lshl_b32 s42, s42, 8\n" \
   "s_add_u32 s42, %[b0], s42\n" \
-  "s_addc_u32 s43, %[b1], 0\n" \
-  "global_load_dword " slot ", %[voff], s[42:43]\n"
-#define HRFD_PR_REQUEST2(slot, chunk_sgpr_or_const) \
-  "s_min_u32 s42, " chunk_sgpr_or_const ", s44\n" \
-  "s_lshl_b32 s42, s42, 6\n" \
-  "s_add_u32 s42, %[b0], s42\n" \
-  "s_addc_u32 s43, %[b1], 0\n" \
-  HRFD_PR_LOAD(slot)
-#define HRFD_PR_TURN(slot, behind) \
+  "s_addc_u32 s43, %[b1], 0\n"
+#define HRFD_PR_TURN(slot, s0, s1, s2, s3, behind) \
   "s_cmp_ge_u32 s40, %[n]\n" \
   "s_cbranch_scc1 9f\n" \
   "s_waitcnt vmcnt(" behind ")\n" \
-  "v_mov_b32 v56, " slot "\n" \
-  "v_cmp_nle_f32_e64 vcc, |v56|, s45\n" \
+  "v_mov_b32 v72, " s0 "\n" \
+  "v_mov_b32 v73, " s1 "\n" \
+  "v_mov_b32 v74, " s2 "\n" \
+  "v_mov_b32 v75, " s3 "\n" \
+  "v_cmp_nle_f32_e64 vcc, |v72|, s45\n" \
+  "v_cmp_nle_f32_e64 s[50:51], |v73|, s45\n" \
+  "s_or_b64 vcc, vcc, s[50:51]\n" \
+  "v_cmp_nle_f32_e64 s[50:51], |v74|, s45\n" \
+  "s_or_b64 vcc, vcc, s[50:51]\n" \
+  "v_cmp_nle_f32_e64 s[50:51], |v75|, s45\n" \
+  "s_or_b64 vcc, vcc, s[50:51]\n" \
   "s_cbranch_vccz 1f\n" \
   "s_mov_b32 s41, 1\n" \
   "s_branch 9f\n" \
   "1:\n" \
-  "s_add_u32 s42, s40, 16\n" HRFD_PR_REQUEST2(slot, "s42") \
-  "v_add_f32_dpp v58, v57, v56 row_ror:1 row_mask:0xf bank_mask:0xf\n" HRFD_PR_WRAP \
-  HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND \
-  HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND \
-  "s_lshl_b32 s42, s40, 6\n" \
+  "s_add_u32 s42, s40, 8\n" HRFD_PR_ADDR("s42") HRFD_PR_LOAD(slot) \
+  "v_add_f32_dpp v82, v79, v72 row_ror:1 row_mask:0xf bank_mask:0xf\n" HRFD_PR_LANE \
+  "s_mov_b32 s48, 5\n" \
+  "2:\n" \
+  HRFD_PR_ROUND HRFD_PR_ROUND HRFD_PR_ROUND \
+  "s_sub_u32 s48, s48, 1\n" \
+  "s_cmp_lg_u32 s48, 0\n" \
+  "s_cbranch_scc1 2b\n" \
+  "s_lshl_b32 s42, s40, 8\n" \
   "s_add_u32 s42, %[b0], s42\n" \
   "s_addc_u32 s43, %[b1], 0\n" \
   "s_add_u32 s40, s40, 1\n" \
   "s_cmp_eq_u32 s40, %[n]\n" \
-  "s_cselect_b64 exec, s[46:47], -1\n" \
-  HRFD_PR_STORE \
-  "s_mov_b64 exec, -1\n"
+  "s_cbranch_scc1 3f\n" \
+  HRFD_PR_STORE4 \
+  "s_branch 4f\n" \
+  "3:\n" \
+  "s_mov_b64 exec, s[46:47]\n" \
+  HRFD_PR_STORE4 \
+  "s_mov_b64 exec, s[52:53]\n" \
+  "global_store_dwordx3 %[voff], v[76:78], s[42:43] offset:4\n" \
+  "s_mov_b64 exec, -1\n" \
+  "4:\n"
 
-// w: the phase of the call's first cell in, the accumulator behind the last chunk done out (every lane of a row: the
-// row's lane 15 is the one that counts).  Returns the chunks done; refused: the next one holds a step the branch-free wrap
-// is not proven for, `held` are its steps.  Every lane of the wave must be active.
-__device__ __forceinline__ uint32_t pr_pipeline(float &w, float &held, bool &refused, const uint32_t voff, const uint32_t *wbase, const uint32_t nchunks)
+// w: the accumulator in front of the run in (lane 15 of the row is the one that counts: the first add takes it into lane
+// 0), the one behind the last chunk done out (again lane 15).  Returns the chunks done; refused: the next one holds a step
+// the branch-free wrap is not proven for, `held` are its steps.  Every lane of the wave must be active.
+__device__ __forceinline__ uint32_t pr_pipeline(float &w, float (&held)[4], bool &refused, const uint32_t voff, const uint32_t *wbase, const uint32_t nchunks)
 {
   const uint64_t b = (uint64_t)(uintptr_t)wbase;
   const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
@@ -1169,65 +1188,79 @@ __device__ __forceinline__ uint32_t pr_pipeline(float &w, float &held, bool &ref
       "s_mov_b32 s45, 0x409b3333\n"
       "s_mov_b32 s46, 0x7fff7fff\n"
       "s_mov_b32 s47, 0x7fff7fff\n"
-      "v_mov_b32 v57, %[w]\n"
-      "v_mov_b32 v56, 0\n"
+      "s_mov_b32 s52, 0x80008000\n"
+      "s_mov_b32 s53, 0x80008000\n"
+      "v_mov_b32 v79, %[w]\n"
+      "v_mov_b32 v72, 0\n"
+      "v_mov_b32 v73, 0\n"
+      "v_mov_b32 v74, 0\n"
+      "v_mov_b32 v75, 0\n"
       "s_nop 4\n"
-      HRFD_PR_REQUEST("v40", "0") HRFD_PR_REQUEST("v41", "1") HRFD_PR_REQUEST("v42", "2") HRFD_PR_REQUEST("v43", "3")
-      HRFD_PR_REQUEST("v44", "4") HRFD_PR_REQUEST("v45", "5") HRFD_PR_REQUEST("v46", "6") HRFD_PR_REQUEST("v47", "7")
-      HRFD_PR_REQUEST("v48", "8") HRFD_PR_REQUEST("v49", "9") HRFD_PR_REQUEST("v50", "10") HRFD_PR_REQUEST("v51", "11")
-      HRFD_PR_REQUEST("v52", "12") HRFD_PR_REQUEST("v53", "13") HRFD_PR_REQUEST("v54", "14") HRFD_PR_REQUEST("v55", "15")
-      // the first sixteen chunks: behind the request of chunk d are 15 - d of the first requests, d later ones and d stores
-      HRFD_PR_TURN("v40", "15") HRFD_PR_TURN("v41", "16") HRFD_PR_TURN("v42", "17") HRFD_PR_TURN("v43", "18")
-      HRFD_PR_TURN("v44", "19") HRFD_PR_TURN("v45", "20") HRFD_PR_TURN("v46", "21") HRFD_PR_TURN("v47", "22")
-      HRFD_PR_TURN("v48", "23") HRFD_PR_TURN("v49", "24") HRFD_PR_TURN("v50", "25") HRFD_PR_TURN("v51", "26")
-      HRFD_PR_TURN("v52", "27") HRFD_PR_TURN("v53", "28") HRFD_PR_TURN("v54", "29") HRFD_PR_TURN("v55", "30")
-      // ... then 15 requests and 16 stores
+      HRFD_PR_ADDR("0") "global_load_dwordx4 v[40:43], %[voff], s[42:43]\n"
+      HRFD_PR_ADDR("1") "global_load_dwordx4 v[44:47], %[voff], s[42:43]\n"
+      HRFD_PR_ADDR("2") "global_load_dwordx4 v[48:51], %[voff], s[42:43]\n"
+      HRFD_PR_ADDR("3") "global_load_dwordx4 v[52:55], %[voff], s[42:43]\n"
+      HRFD_PR_ADDR("4") "global_load_dwordx4 v[56:59], %[voff], s[42:43]\n"
+      HRFD_PR_ADDR("5") "global_load_dwordx4 v[60:63], %[voff], s[42:43]\n"
+      HRFD_PR_ADDR("6") "global_load_dwordx4 v[64:67], %[voff], s[42:43]\n"
+      HRFD_PR_ADDR("7") "global_load_dwordx4 v[68:71], %[voff], s[42:43]\n"
+      // the first eight chunks: behind the request of chunk d are 7 - d of the first requests, d later ones and d stores
+      HRFD_PR_TURN("v[40:43]", "v40", "v41", "v42", "v43", "7") HRFD_PR_TURN("v[44:47]", "v44", "v45", "v46", "v47", "8")
+      HRFD_PR_TURN("v[48:51]", "v48", "v49", "v50", "v51", "9") HRFD_PR_TURN("v[52:55]", "v52", "v53", "v54", "v55", "10")
+      HRFD_PR_TURN("v[56:59]", "v56", "v57", "v58", "v59", "11") HRFD_PR_TURN("v[60:63]", "v60", "v61", "v62", "v63", "12")
+      HRFD_PR_TURN("v[64:67]", "v64", "v65", "v66", "v67", "13") HRFD_PR_TURN("v[68:71]", "v68", "v69", "v70", "v71", "14")
+      // ... then 7 requests and 8 stores
       "8:\n"
-      HRFD_PR_TURN("v40", "31") HRFD_PR_TURN("v41", "31") HRFD_PR_TURN("v42", "31") HRFD_PR_TURN("v43", "31")
-      HRFD_PR_TURN("v44", "31") HRFD_PR_TURN("v45", "31") HRFD_PR_TURN("v46", "31") HRFD_PR_TURN("v47", "31")
-      HRFD_PR_TURN("v48", "31") HRFD_PR_TURN("v49", "31") HRFD_PR_TURN("v50", "31") HRFD_PR_TURN("v51", "31")
-      HRFD_PR_TURN("v52", "31") HRFD_PR_TURN("v53", "31") HRFD_PR_TURN("v54", "31") HRFD_PR_TURN("v55", "31")
+      HRFD_PR_TURN("v[40:43]", "v40", "v41", "v42", "v43", "15") HRFD_PR_TURN("v[44:47]", "v44", "v45", "v46", "v47", "15")
+      HRFD_PR_TURN("v[48:51]", "v48", "v49", "v50", "v51", "15") HRFD_PR_TURN("v[52:55]", "v52", "v53", "v54", "v55", "15")
+      HRFD_PR_TURN("v[56:59]", "v56", "v57", "v58", "v59", "15") HRFD_PR_TURN("v[60:63]", "v60", "v61", "v62", "v63", "15")
+      HRFD_PR_TURN("v[64:67]", "v64", "v65", "v66", "v67", "15") HRFD_PR_TURN("v[68:71]", "v68", "v69", "v70", "v71", "15")
       "s_branch 8b\n"
       "9:\n"
-      "s_waitcnt vmcnt(0)\n"                               // (requests behind the end repeat the last chunk: they land in the slots)
-      "v_mov_b32 %[w], v57\n"
-      "v_mov_b32 %[held], v56\n"
+      "s_waitcnt vmcnt(0)\n"                                // (requests behind the end repeat the last chunk: they land in the slots)
+      "v_mov_b32 %[w], v79\n"
+      "v_mov_b32 %[h0], v72\n"
+      "v_mov_b32 %[h1], v73\n"
+      "v_mov_b32 %[h2], v74\n"
+      "v_mov_b32 %[h3], v75\n"
       "s_mov_b32 %[done], s40\n"
       "s_mov_b32 %[flag], s41\n"
-      : [w] "+v"(w), [held] "=&v"(held), [done] "=&s"(done), [flag] "=&s"(flag)
+      : [w] "+v"(w), [h0] "=&v"(held[0]), [h1] "=&v"(held[1]), [h2] "=&v"(held[2]), [h3] "=&v"(held[3]), [done] "=&s"(done), [flag] "=&s"(flag)
       : [voff] "v"(voff), [b0] "s"(b0), [b1] "s"(b1), [n] "s"(n)
-      : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
-        "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+      : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s51", "s52", "s53",
+        "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+        "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+        "v80", "v81", "v82");
   refused = flag != 0u;
   return done;
 }
 #undef HRFD_PR_TURN
-#undef HRFD_PR_REQUEST
-#undef HRFD_PR_REQUEST2
+#undef HRFD_PR_ADDR
 #undef HRFD_PR_ROUND
+#undef HRFD_PR_LANE
 #undef HRFD_PR_WRAP
 
-// steps: a multiple of 16, and 4 * row_stride cells must fit a 32-bit byte offset (the host sees to both).
+// steps: a multiple of 64, and 4 * row_stride cells must fit a 32-bit byte offset (the host sees to both).
 // The call is a sequence of RUNS: the pipeline as far as it gets, then -- in front of a chunk it refuses, or while the
 // accumulator is above pi -- one chunk with the reference's loops in the same arrangement, then the pipeline again.
-// A run writes exactly its own cells: lanes 0 .. 14 of its last chunk store one cell to the right like everybody, lane 15
-// keeps the accumulator for the run behind, and the run's first cell (whose step had to be read first) is written when the
-// run is through.
+// A run writes exactly its own cells: lane 15 of its last chunk keeps its last value (the accumulator for the run behind:
+// the cell belongs to that run), and the run's first cell (whose step had to be read first) is written when the run is
+// through.
 __global__ __launch_bounds__(kPrThreads) void k_phase_rows(uint32_t *cells, size_t steps, size_t row_stride, float *acc_io, uint32_t n_channels)
 {
   const int j = threadIdx.x & 15;
   // a row behind the bank repeats the bank's last channel (the same values to the same cells): no lane is ever masked
   // (rows of ONE wave run in lockstep, so the copies cannot disturb each other; a whole wave behind the bank leaves)
   const uint32_t cw = blockIdx.x * (uint32_t)(kPrThreads / 16) + 4u * (threadIdx.x >> 6);     // the wave's first channel
-  const uint32_t nchunks = (uint32_t)(steps / 16);
+  const uint32_t nchunks = (uint32_t)(steps / kPrChunk);
   if (nchunks == 0u || cw >= n_channels)
   {
     return;
   }
   const uint32_t c = min(cw + ((threadIdx.x >> 4) & 3u), n_channels - 1u);
   const uint32_t *wbase = cells + (size_t)cw * row_stride;   // (uniform over the wave: pr_pipeline takes it into SGPRs)
-  const uint32_t voff = (uint32_t)(((size_t)(c - cw) * row_stride + (size_t)j) * 4u);
-  uint32_t *row = cells + (size_t)c * row_stride;
+  const uint32_t voff = (uint32_t)(((size_t)(c - cw) * row_stride + 4u * (size_t)j) * 4u);
+  uint32_t *row = cells + (size_t)c * row_stride + 4u * (size_t)j;   // the lane's four cells of chunk 0
   float w = acc_io[c];                                    // every lane of the row; from the first chunk on, lane 15 is the one that counts
   uint32_t i = 0;                                         // chunks done
   bool wild = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(w) <= 3.1415927f)) != 0ull;
@@ -1238,26 +1271,33 @@ __global__ __launch_bounds__(kPrThreads) void k_phase_rows(uint32_t *cells, size
     return cr;
   };
   // chunk i with the reference's loops (cur: its steps, taken before anything of it is stored)
-  auto loops_chunk = [&](const float cur) {
+  auto loops_chunk = [&](const float (&cur)[4]) {
     const float carry = carry_of();
-    float x;
-    pr_add<true>(x, w, cur);
+    float x0, w0 = 0.0f, w1 = 0.0f, w2 = 0.0f;
+    pr_add<true>(x0, w, cur[0]);
 #pragma nounroll
     for (int t = 0; t < 16; t++)
     {
       if (t != 0)
       {
-        pr_add<false>(x, w, cur);
+        pr_add<false>(x0, w, cur[0]);
       }
-      w = ps_wrap_loops(x);
+      w0 = ps_wrap_loops(x0);
+      w1 = ps_wrap_loops(w0 + cur[1]);
+      w2 = ps_wrap_loops(w1 + cur[2]);
+      w = ps_wrap_loops(w2 + cur[3]);
     }
+    uint32_t *cell = row + (size_t)kPrChunk * i;
+    cell[1] = __builtin_bit_cast(uint32_t, w0);
+    cell[2] = __builtin_bit_cast(uint32_t, w1);
+    cell[3] = __builtin_bit_cast(uint32_t, w2);
     if (j != 15)
     {
-      row[16u * (size_t)i + (size_t)j + 1] = __builtin_bit_cast(uint32_t, w);
+      cell[4] = __builtin_bit_cast(uint32_t, w);
     }
     if (j == 0)
     {
-      row[16u * (size_t)i] = __builtin_bit_cast(uint32_t, carry);
+      cell[0] = __builtin_bit_cast(uint32_t, carry);
     }
     i++;
     wild = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(w) <= 3.1415927f)) != 0ull;
@@ -1267,17 +1307,19 @@ __global__ __launch_bounds__(kPrThreads) void k_phase_rows(uint32_t *cells, size
   {
     if (wild)
     {
-      loops_chunk(__builtin_bit_cast(float, row[16u * (size_t)i + (size_t)j]));
+      const uint4 q = *reinterpret_cast<const uint4 *>(row + (size_t)kPrChunk * i);
+      const float cur[4] = {__builtin_bit_cast(float, q.x), __builtin_bit_cast(float, q.y), __builtin_bit_cast(float, q.z), __builtin_bit_cast(float, q.w)};
+      loops_chunk(cur);
       continue;
     }
     const float carry = carry_of();
     const uint32_t i0 = i;
-    float held = 0.0f;
+    float held[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool refused = false;
-    i += pr_pipeline(w, held, refused, voff, wbase + 16u * (size_t)i0, nchunks - i0);
+    i += pr_pipeline(w, held, refused, voff, wbase + (size_t)kPrChunk * i0, nchunks - i0);
     if (i != i0 && j == 0)
     {
-      row[16u * (size_t)i0] = __builtin_bit_cast(uint32_t, carry);
+      row[(size_t)kPrChunk * i0] = __builtin_bit_cast(uint32_t, carry);
     }
     if (i < nchunks)
     {

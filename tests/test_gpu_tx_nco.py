@@ -241,6 +241,39 @@ def test_fm_modulator_time_slices(oracle, n):
             assert d.max() <= 1 and (d != 0).mean() < 0.02, (call, c)
 
 
+@pytest.mark.parametrize("kind", ["fm", "wbfm"])
+@pytest.mark.parametrize("C", [1, 3, 4, 5, 17, 67])
+def test_phase_recurrence_kernels_agree(oracle, kind, C):
+    """Round 4: the Nco phase recurrence runs on k_phase_rows (lane = time: a channel is a row of 16 lanes, four channels per
+    wave, the accumulator handed along the row by DPP) and no longer on k_phase_scan (lane = channel, cells through LDS).
+    Both must give the same bytes (hook: debug_set_scan(1) is the old kernel), call after call, for banks that fill a wave,
+    leave rows of the last wave empty (they repeat the bank's last channel) or take several workgroups, with one channel
+    at an absurd deviation (WBFM: its chunks are refused by the pipeline and go through the reference's loops, the chunks
+    around them through the pipeline again) -- and the oracle's (WBFM: exactly; FM: the +-1 LSB of the trig path)."""
+    mk = api.MOD_FM if kind == "fm" else api.MOD_WBFM
+    n = 1024 + 512
+    pcm = np.stack([synth.lcg_pcm(300 + c, 2 * n) for c in range(C)])
+    a, b = api.Mod(mk, C), api.Mod(mk, C)
+    b.debug_set_scan(1)
+    os_ = [getattr(oracle, kind + "mod")() for _ in range(C)]
+    if kind == "wbfm" and C >= 3:
+        a.set_param(1.5e6, channel=C - 2)
+        b.set_param(1.5e6, channel=C - 2)
+        os_[C - 2].set_param(1.5e6)
+    for call in range(2):
+        x = pcm[:, call * n:(call + 1) * n]
+        ga, gb = np.atleast_2d(a.process(x)), np.atleast_2d(b.process(x))
+        assert (ga == gb).all(), call
+        for c in range(C):
+            want = os_[c].process(x[c])
+            if kind == "wbfm":
+                assert (ga[c] == want).all(), (call, c)
+            else:
+                d = np.abs(ga[c].astype(np.int16) - want.astype(np.int16))
+                d = np.minimum(d, 256 - d)
+                assert d.max() <= 1 and (d != 0).mean() < 0.02, (call, c)
+
+
 @pytest.mark.parametrize("case", MAN_MOD["am"], ids=lambda c: c["key"])
 def test_golden_am_modulator(engine, case):
     G.check_am_mod(engine, ARR_MOD, case)
