@@ -26,8 +26,16 @@ __device__ __forceinline__ uint32_t mul24(const uint32_t x)
 }
 
 template <int FORM, int WORK>
-__global__ __launch_bounds__(256) void k_issue(uint8_t *out, uint32_t window_chunks, uint32_t seed)
+__global__ __launch_bounds__(256) void k_issue(uint8_t *out, uint32_t window_chunks, uint32_t seed, unsigned long long *clk)
 {
+  // shader clock (s_memtime) against the constant 100 MHz clock (s_memrealtime), one lane of every 1024th workgroup
+  const bool probe = threadIdx.x == 0 && (blockIdx.x & 1023u) == 512u;
+  unsigned long long c0 = 0, r0 = 0;
+  if (probe)
+  {
+    c0 = __builtin_readcyclecounter();
+    r0 = __builtin_amdgcn_s_memrealtime();
+  }
   const uint32_t ch = blockIdx.x % window_chunks;           // 32 KiB chunk inside the window
   uint8_t *base = out + (size_t)ch * 32768;
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
@@ -82,11 +90,20 @@ __global__ __launch_bounds__(256) void k_issue(uint8_t *out, uint32_t window_chu
       *reinterpret_cast<u32x4 *>(base + off) = u32x4{d0, d1, d2, d3};   // (never: keeps the arithmetic alive)
     }
   }
+  if (probe)
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    atomicAdd(&clk[0], __builtin_readcyclecounter() - c0);
+    atomicAdd(&clk[1], __builtin_amdgcn_s_memrealtime() - r0);
+  }
 }
 
 template <int FORM, int WORK>
 static void run(const char *name, uint8_t *win, uint8_t *alloc, size_t alloc_bytes, size_t guard, uint32_t window_chunks)
 {
+  static unsigned long long *clk = nullptr;
+  if (clk == nullptr) hipMalloc(&clk, 16);
+  hipMemset(clk, 0, 16);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -95,7 +112,7 @@ static void run(const char *name, uint8_t *win, uint8_t *alloc, size_t alloc_byt
   for (int rep = 0; rep < 30; rep++)
   {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k_issue<FORM, WORK>), dim3(131072), dim3(256), 0, 0, win, window_chunks, (uint32_t)rep);
+    hipLaunchKernelGGL((k_issue<FORM, WORK>), dim3(131072), dim3(256), 0, 0, win, window_chunks, (uint32_t)rep, clk);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -118,7 +135,10 @@ static void run(const char *name, uint8_t *win, uint8_t *alloc, size_t alloc_byt
           bad += !(q[0] == ch && q[1] == r && q[2] == t && q[3] == 7u);
         }
   }
-  printf("%-72s %.4f ms   wrong cells %zu, guard words touched %zu\n", name, sum / 20, bad, guard_hit);
+  unsigned long long hc[2];
+  hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+  printf("%-72s %.4f ms   shader clock %.0f MHz   wrong cells %zu, guard words touched %zu\n", name, sum / 20, hc[1] ? 100.0 * (double)hc[0] / (double)hc[1] : 0.0, bad,
+         guard_hit);
   fflush(stdout);
 }
 
