@@ -274,6 +274,20 @@ def test_phase_recurrence_kernels_agree(oracle, kind, C):
                 assert d.max() <= 1 and (d != 0).mean() < 0.02, (call, c)
 
 
+@pytest.mark.parametrize("C", [4100, 8200])
+def test_wbfm_modulator_big_banks(oracle, C):
+    """the phase recurrence's two shapes at bank sizes that matter to them: 4100 channels (k_phase_rows with more than one
+    wave on some SIMDs: 257 workgroups of four waves) and 8200 (beyond 8192: round 2's k_phase_scan<64>, 64 channels per
+    recurrence wave).  One block per channel, every 97th channel and the bank's last against the oracle, bit for bit."""
+    n = 512
+    rng = np.random.default_rng(C)
+    pcm = rng.integers(-20000, 20000, size=(C, n), dtype=np.int16)
+    m = api.Mod(api.MOD_WBFM, C)
+    got = m.process(pcm)
+    for c in list(range(0, C, 97)) + [C - 2, C - 1]:
+        assert (got[c] == oracle.wbfmmod().process(pcm[c])).all(), c
+
+
 @pytest.mark.parametrize("case", MAN_MOD["am"], ids=lambda c: c["key"])
 def test_golden_am_modulator(engine, case):
     G.check_am_mod(engine, ARR_MOD, case)
