@@ -8,6 +8,7 @@
 //   form 2  global_store_dwordx4, scalar base + 32-bit offset per lane        (what the compiler makes of k_mod's store)
 //   form 3  buffer_store_dwordx4, offen (32-bit offset per lane)
 //   form 4  buffer_store_dwordx4 with ADD_TID_ENABLE in the resource: NO vector address (lane l writes base + soffset + 16 l)
+//   form 5 / 6  the same bytes as two 8-byte / four 4-byte stores per lane (is the cost per instruction or per byte?)
 // The footprint is 16 MiB (stays in the L2s), 131072 workgroups x 8 rounds x 256 lanes like k_mod's 1024 x 16 launch.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o store_issue store_issue.hip
 #include <hip/hip_runtime.h>
@@ -85,6 +86,25 @@ __global__ __launch_bounds__(256) void k_issue(uint8_t *out, uint32_t window_chu
       const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)r * 256u + wave * 64u) * 16u));
       asm volatile("buffer_store_dwordx4 %0, off, %1, %2 nt" : : "v"(u32x4{d0, d1, d2, d3}), "s"(rs), "s"(soff) : "memory");
     }
+    else if (FORM == 5)
+    {
+      // the same 16 bytes per lane as TWO 8-byte stores, each wave instruction 512 contiguous bytes (k_rx_wbfm_flow's iq dump)
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const uint32_t wbase = ((uint32_t)r * 256u + wave * 64u) * 16u, lane = tid & 63u;
+      const bool hi = lane >= 32u;                          // (host pattern: lane l of the first store is cell l / 2, half l % 2)
+      (void)hi;
+      asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(wbase + lane * 8u), "v"(u32x2{d0, d1}), "s"(base) : "memory");
+      asm volatile("global_store_dwordx2 %0, %1, %2 nt" : : "v"(wbase + 512u + lane * 8u), "v"(u32x2{d2, d3}), "s"(base) : "memory");
+    }
+    else if (FORM == 6)
+    {
+      // ... as FOUR 4-byte stores, 256 contiguous bytes each
+      const uint32_t wbase = ((uint32_t)r * 256u + wave * 64u) * 16u, lane = tid & 63u;
+      asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(wbase + lane * 4u), "v"(d0), "s"(base) : "memory");
+      asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(wbase + 256u + lane * 4u), "v"(d1), "s"(base) : "memory");
+      asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(wbase + 512u + lane * 4u), "v"(d2), "s"(base) : "memory");
+      asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(wbase + 768u + lane * 4u), "v"(d3), "s"(base) : "memory");
+    }
     else if (never != 0u)
     {
       *reinterpret_cast<u32x4 *>(base + off) = u32x4{d0, d1, d2, d3};   // (never: keeps the arithmetic alive)
@@ -124,7 +144,7 @@ static void run(const char *name, uint8_t *win, uint8_t *alloc, size_t alloc_byt
   hipMemcpy(h.data(), alloc, alloc_bytes, hipMemcpyDeviceToHost);
   size_t bad = 0, guard_hit = 0;
   for (size_t i = 0; i < guard / 4; i++) guard_hit += (h[i] != 0xA5A5A5A5u) + (h[h.size() - 1 - i] != 0xA5A5A5A5u);
-  if (FORM != 0)
+  if (FORM != 0 && FORM < 5)
   {
     const uint32_t *w = h.data() + guard / 4;
     for (uint32_t ch = 0; ch < window_chunks; ch++)
@@ -154,8 +174,12 @@ int main()
   run<2, 88>("global_store_dwordx4, scalar base + 32-bit offset per lane", win, alloc, alloc_bytes, guard, window_chunks);
   run<3, 88>("buffer_store_dwordx4 offen", win, alloc, alloc_bytes, guard, window_chunks);
   run<4, 88>("buffer_store_dwordx4, ADD_TID_ENABLE, no vector address", win, alloc, alloc_bytes, guard, window_chunks);
+  run<5, 88>("two global_store_dwordx2 (512 contiguous bytes each)", win, alloc, alloc_bytes, guard, window_chunks);
+  run<6, 88>("four global_store_dword (256 contiguous bytes each)", win, alloc, alloc_bytes, guard, window_chunks);
   run<0, 8>("no store, 8 vector instructions per round", win, alloc, alloc_bytes, guard, window_chunks);
   run<2, 8>("scalar base + 32-bit offset, 8 vector instructions per round", win, alloc, alloc_bytes, guard, window_chunks);
   run<4, 8>("ADD_TID_ENABLE, 8 vector instructions per round", win, alloc, alloc_bytes, guard, window_chunks);
+  run<5, 8>("two dwordx2 stores, 8 vector instructions per round", win, alloc, alloc_bytes, guard, window_chunks);
+  run<6, 8>("four dword stores, 8 vector instructions per round", win, alloc, alloc_bytes, guard, window_chunks);
   return 0;
 }
