@@ -666,6 +666,12 @@ struct Flow
       const u32x2 d = {w[0], w[1]};
       asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" : : "v"(d), "v"(lane_off8), "s"(ddesc), "s"(soff) : "memory");
     };
+    // (a dump store outside the descriptor: no memory traffic, but a vector memory operation like the real ones)
+    auto store_nothing = [&]() {
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 d = {0u, 0u};
+      asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen" : : "v"(d), "v"(lane_off8), "s"(ddesc), "s"(dead) : "memory");
+    };
     // `dep`: stage-1 outputs that between them have read every raw register of the piece being refilled -- the asm
     // names them as inputs, so no read of the old contents can be scheduled behind the load
     auto load_piece = [&](u32x4 (&q)[4], const uint32_t uoff, const int half, const bool live, const uint32_t (&dep)[4][4]) {
@@ -760,7 +766,15 @@ struct Flow
     {
       const uint32_t nodep[4][4] = {};
       load_piece(qa, uoff, 0, u < n_units, nodep);
+      if (DUMP)
+      {
+        store_nothing();                                 // (where a unit's first dump store stands among its loads: the counts below)
+      }
       load_piece(qb, uoff, 1, u < n_units, nodep);
+      if (DUMP)
+      {
+        store_nothing();
+      }
     }
     while (u < n_units)
     {
@@ -768,7 +782,18 @@ struct Flow
       const uint32_t done_seen = lds_ld(&ctl[1]);
       FLOW_MARK(1)
       QuadCarry cy;
-      VM_WAIT(8, "+v"(c16));
+      // (DUMP: the two dump stores of a unit stand among the loads, in order: c16' qa' st0 qb' st1 -- behind c16' are 10
+      //  operations, behind qa' 6, behind qb 7 (st1, c16', qa', st0); without them 8, 4 and 5.  Round 3 waited with the
+      //  plain counts in the dump build as well: the third wait then took the NEXT unit's first loads in, a memory round trip
+      //  per unit -- the iq dump's 1.15-1.2x)
+      if (DUMP)
+      {
+        VM_WAIT(10, "+v"(c16));
+      }
+      else
+      {
+        VM_WAIT(8, "+v"(c16));
+      }
       {
         const bool st0 = first && uoff == 0u;            // "the 16 bytes in front" of a continued stream are the carried ones
         cy.fe = carry_from_16(make_uint4(st0 ? tail_in[0] : c16.x, st0 ? tail_in[1] : c16.y, st0 ? tail_in[2] : c16.z,
@@ -812,7 +837,14 @@ struct Flow
       // (the next unit's loads go out from inside the pieces, as soon as a piece's raw registers are free:
       //  almost two pieces of lead without a register more)
       int un = 0;
-      VM_WAIT(4, "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]));
+      if (DUMP)
+      {
+        VM_WAIT(6, "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]));
+      }
+      else
+      {
+        VM_WAIT(4, "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]));
+      }
       // what happens at the point where a piece's raw registers are free: the next unit's first loads
       auto refill_a = [&](const uint32_t (&y1)[4][4]) {
         lds_landed(un_v);
@@ -881,7 +913,14 @@ struct Flow
       }
       FLOW_MARK(4)
       FLOW_MARK(5)
-      VM_WAIT(5, "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+      if (DUMP)
+      {
+        VM_WAIT(7, "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+      }
+      else
+      {
+        VM_WAIT(5, "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+      }
       auto refill_b = [&](const uint32_t (&y1)[4][4]) { load_piece(qb, uoff_n, 1, un < n_units, y1); };
       if (kWb)
       {
