@@ -62,6 +62,11 @@
 
 namespace hrfd {
 
+#ifdef HRFD_DUMP_PLAIN_WAITS
+constexpr bool kDumpPlainWaits = true;          // TIMING EXPERIMENT ONLY: round 3's counts in the dump builds
+#else
+constexpr bool kDumpPlainWaits = false;
+#endif
 constexpr int kFT = 64;                         // samples per tile
 constexpr int kFStride = 66;                    // dwords per tile slot: 64-bit accesses of 32 lanes fall into 32 different bank pairs
 constexpr int kFRingTiles = HRFD_FLOW_RING;     // tiles of v in the ring
@@ -784,9 +789,9 @@ struct Flow
       QuadCarry cy;
       // (DUMP: the two dump stores of a unit stand among the loads, in order: c16' qa' st0 qb' st1 -- behind c16' are 10
       //  operations, behind qa' 6, behind qb 7 (st1, c16', qa', st0); without them 8, 4 and 5.  Round 3 waited with the
-      //  plain counts in the dump build as well: the third wait then took the NEXT unit's first loads in, a memory round trip
-      //  per unit -- the iq dump's 1.15-1.2x)
-      if (DUMP)
+      //  plain counts in the dump build as well, i.e. for more than it needed; an A/B on one box (tools/dump_ab.sh,
+      //  -DHRFD_DUMP_PLAIN_WAITS) shows no difference: 0.2408 against 0.2394 ms -- what the dump costs is its bytes)
+      if (DUMP && !kDumpPlainWaits)
       {
         VM_WAIT(10, "+v"(c16));
       }
@@ -837,7 +842,7 @@ struct Flow
       // (the next unit's loads go out from inside the pieces, as soon as a piece's raw registers are free:
       //  almost two pieces of lead without a register more)
       int un = 0;
-      if (DUMP)
+      if (DUMP && !kDumpPlainWaits)
       {
         VM_WAIT(6, "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]));
       }
@@ -913,7 +918,7 @@ struct Flow
       }
       FLOW_MARK(4)
       FLOW_MARK(5)
-      if (DUMP)
+      if (DUMP && !kDumpPlainWaits)
       {
         VM_WAIT(7, "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
       }
