@@ -1097,19 +1097,6 @@ __device__ __forceinline__ void pr_add(float &x, const float w, const float st)
 //   s40 chunks done   s41 refused   s[42:43] address   s44 chunks - 1   s45 4.85f   s[46:47] lanes 0 .. 14 of every row
 //   s48 round counter   s[50:51] scratch   s[52:53] lane 15 of every row
 // A chunk holding a step above 4.85 (or a NaN) is refused: the pipeline stops in front of it with its steps in v[72:75].
-#ifndef HRFD_PR_ABLATE
-#define HRFD_PR_ABLATE 0
-#endif
-#if (HRFD_PR_ABLATE & 1)   // TIMING EXPERIMENT ONLY: no stores
-#define HRFD_PR_STORE4 ""
-#else
-#define HRFD_PR_STORE4 "global_store_dwordx4 %[voff], v[76:79], s[42:43] offset:4\n"
-#endif
-#if (HRFD_PR_ABLATE & 2)   // TIMING EXPERIMENT ONLY: no requests inside the loop
-#define HRFD_PR_LOAD(slot) ""
-#else
-#define HRFD_PR_LOAD(slot) "global_load_dwordx4 " slot ", %[voff], s[42:43]\n"
-#endif
 #define HRFD_PR_WRAP(x, dst) \
   "v_mul_f32 v81, 0x3e22f984, " x "\n" \
   "v_rndne_f32 v81, v81\n" \
@@ -1148,7 +1135,7 @@ __device__ __forceinline__ void pr_add(float &x, const float w, const float st)
   "s_mov_b32 s41, 1\n" \
   "s_branch 9f\n" \
   "1:\n" \
-  "s_add_u32 s42, s40, 8\n" HRFD_PR_ADDR("s42") HRFD_PR_LOAD(slot) \
+  "s_add_u32 s42, s40, 8\n" HRFD_PR_ADDR("s42") "global_load_dwordx4 " slot ", %[voff], s[42:43]\n" \
   "v_add_f32_dpp v82, v79, v72 row_ror:1 row_mask:0xf bank_mask:0xf\n" HRFD_PR_LANE \
   "s_mov_b32 s48, 5\n" \
   "2:\n" \
@@ -1162,11 +1149,11 @@ __device__ __forceinline__ void pr_add(float &x, const float w, const float st)
   "s_add_u32 s40, s40, 1\n" \
   "s_cmp_eq_u32 s40, %[n]\n" \
   "s_cbranch_scc1 3f\n" \
-  HRFD_PR_STORE4 \
+  "global_store_dwordx4 %[voff], v[76:79], s[42:43] offset:4\n" \
   "s_branch 4f\n" \
   "3:\n" \
   "s_mov_b64 exec, s[46:47]\n" \
-  HRFD_PR_STORE4 \
+  "global_store_dwordx4 %[voff], v[76:79], s[42:43] offset:4\n" \
   "s_mov_b64 exec, s[52:53]\n" \
   "global_store_dwordx3 %[voff], v[76:78], s[42:43] offset:4\n" \
   "s_mov_b64 exec, -1\n" \
