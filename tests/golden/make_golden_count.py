@@ -7,6 +7,7 @@ oracle/Makefile (build container only):
 
   makethem   signals/{am,dsb,pm,fm}.cc < count.raw | signals/interpolateSignal.cc        -> int8 IQ at 2.048 MS/s
   modulator  {Ssb,Am,Fm,WbFm}Modulator::acceptData over count.raw, 512 samples per call  -> int8 IQ
+             (and the reference's own harness programs ssb.cc / am.cc / fm.cc / wbfm.cc < count.raw: the same bytes)
   loop       that IQ, moved down by 64 kHz (the radio tunes 64 kHz high and IqDataProcessor::upconvertByFsOver4 brings
              the signal back: Radio.cc:1187-1191 -- tests/toolsupport.retune_minus_64k is that channel), 262144 bytes at a
              time through IqDataProcessor::acceptIqData in the matching demodulator mode (LSB / AM / FM / WBFM)
@@ -22,6 +23,7 @@ and last 2 KiB of every IQ stream and the recovered PCM of every loop.  No refer
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 import numpy as np
@@ -65,7 +67,14 @@ def main():
     for name, (make, mode) in mods.items():
         iq = modulate(make(), pcm)
         arrays[f"mod_{name}_head"], arrays[f"mod_{name}_tail"] = iq[:2048], iq[-2048:]
-        manifest["modulator"].append({"kind": name, "iq_bytes": int(iq.size), "iq_sha256": synth.digest(iq)})
+        # the reference's OWN harness program of this modulator ({Am,Fm,WbFm,Ssb}Modulator/{am,fm,wbfm,ssb}.cc, built by
+        # oracle/Makefile from its build script's file list): count.raw on stdin, int8 IQ on stdout -- the same bytes
+        prog = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "prog_" + name)], stdin=open(SRC, "rb"), stdout=subprocess.PIPE, check=True).stdout
+        assert synth.digest(np.frombuffer(prog, dtype=np.int8)) == synth.digest(iq), name
+        manifest["modulator"].append({"kind": name, "iq_bytes": int(iq.size), "iq_sha256": synth.digest(iq),
+                                      "program": {"ssb": "SsbModulator/ssb.cc", "am": "AmModulator/am.cc", "fm": "FmModulator/fm.cc",
+                                                  "wbfm": "WbFmModulator/wbfm.cc"}[name],
+                                      "program_sha256": synth.digest(np.frombuffer(prog, dtype=np.int8))})
         rx = ref.rx()
         rx.set_mode(mode)
         air = T.retune_minus_64k(iq)

@@ -3,7 +3,8 @@
 vectors for the demodulators), through everything on the transmit side and back through the receive side:
 
   makethem   signals/{am,dsb,pm,fm}.cc | interpolateSignal          -> int8 IQ at 2.048 MS/s
-  modulator  {Ssb,Am,Fm,WbFm}Modulator::acceptData, 512 per call    -> int8 IQ
+  modulator  {Ssb,Am,Fm,WbFm}Modulator::acceptData, 512 per call    -> int8 IQ   (= the reference's own harness programs
+             SsbModulator/ssb.cc, AmModulator/am.cc, FmModulator/fm.cc, WbFmModulator/wbfm.cc < count.raw)
   loop       that IQ, 64 kHz down (the radio's tuning offset, Radio.cc:1187-1191), through IqDataProcessor::acceptIqData in
              the matching demodulator mode -> PCM: the closed loop of README.txt:133-136
 
@@ -59,6 +60,8 @@ def test_oracle_makethem(oracle, case):
 def test_oracle_modulators(oracle, case):
     iq = _oracle_modulate(oracle, case["kind"])
     assert iq.size == case["iq_bytes"] and synth.digest(iq) == case["iq_sha256"]
+    # ... which is also what the reference's own harness program of this modulator writes for count.raw on its stdin
+    assert case["program"].endswith(".cc") and case["program_sha256"] == case["iq_sha256"]
 
 
 @pytest.mark.parametrize("case", MAN["loop"], ids=lambda c: c["kind"])
