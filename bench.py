@@ -49,38 +49,7 @@ SETTLE_STEPS = int(os.environ.get("HRFD_BENCH_SETTLE", "100"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def make_fm_batch(channels, blocks, device, first_channel=0):
-    """FM test signal of SURVEY.md 8(d), generated on the GPU: carrier at -64 kHz,
-    +-30 kHz deviation by a (300 + 100*(c mod 32)) Hz tone, amplitude 100, uniform
-    noise in [-3,4].  (Same signal family as hackrfdiags_amd/synth.py; the noise
-    comes from torch's generator here, so the bytes differ from the test vectors.)
-    Thirty-two channels per pass (round 4; one channel per pass before): a 1024-channel batch is ~400 torch dispatches
-    instead of ~12 000 -- a counter pass of rocprofv3 segfaulted inside this function at the larger number."""
-    n = blocks * (BLOCK // 2)
-    out = torch.empty((channels, blocks, BLOCK), dtype=torch.int8, device=device)
-    k = torch.arange(n, dtype=torch.float64, device=device)
-    gen = torch.Generator(device=device)
-    G = 32
-    for g0 in range(0, channels, G):
-        g = min(G, channels - g0)
-        ch = first_channel + g0 + torch.arange(g, device=device)
-        f_c = (300.0 + 100.0 * (ch % 32)).to(torch.float64)[:, None]
-        beta = 30000.0 / f_c
-        phi = (2.0 * np.pi * (-64000.0) / 2048000.0) * k[None, :] - beta * (torch.cos((2.0 * np.pi / 2048000.0) * f_c * k[None, :]) - 1.0)
-        gen.manual_seed(12345 + first_channel + g0)
-        noise = torch.randint(-3, 5, (g, 2, n), device=device, generator=gen, dtype=torch.int32)
-        i = torch.round(100.0 * torch.cos(phi)).to(torch.int32) + noise[:, 0]
-        q = torch.round(100.0 * torch.sin(phi)).to(torch.int32) + noise[:, 1]
-        del phi, noise
-        out[g0:g0 + g] = torch.stack([i, q], dim=2).to(torch.int8).reshape(g, blocks, BLOCK)   # [g, n, 2] interleaved
-        del i, q
-    return out
-
-
-def make_random_batch(channels, blocks, device, first_channel=0):
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1 + first_channel)
-    return torch.randint(-128, 128, (channels, blocks, BLOCK), dtype=torch.int8, device=device, generator=gen)
+from hackrfdiags_amd.synth_torch import make_fm_batch, make_random_batch  # noqa: E402
 
 
 def cgroup_cpu_quota():
@@ -202,7 +171,7 @@ def cpu_baseline_port(seconds, threads, x):
 
 MOD_KINDS = {"ssbmod": ("MOD_SSB", "SSB"), "ammod": ("MOD_AM", "AM"), "fmmod": ("MOD_FM", "FM"), "wbfmmod": ("MOD_WBFM", "WBFM")}
 MOD_KERNELS = {"ssbmod": "hrfd::k_mod<1>",
-               "wbfmmod": "hrfd::k_mod<101> (x32 + Nco step), k_phase_scan, k_wb_rails, hrfd::k_mod<102> (x8)"}
+               "wbfmmod": "hrfd::k_mod<101> (x32 + Nco step), k_phase_rows (the serial Nco recurrence, nine time slices), k_wb_rails, hrfd::k_mod<102> (x8)"}
 
 
 def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle, rank, world, extras=True):
@@ -685,7 +654,7 @@ def rx_workload_text(workload, C, B, world, signal, scatter, quiet_fraction=0.0,
             head = f"{world * C} WBFM channels sharded over {world} GPUs, {C} per GPU (BASELINE config 4), "
         elif world > 1:
             head = (f"{C} concurrent WBFM channels per GPU at 2.048 MS/s = {world * C} channels over {world} GPUs "
-                    f"(BASELINE config 4's shape: it asks for 4096 over 8), ")
+                    f"(WEAK scaling of BASELINE config 2's per-GPU load: the same {C} channels per GPU at every N; config 4 is in `config4`), ")
         elif C == 256:
             head = f"{C} concurrent WBFM channels per GPU at 2.048 MS/s (BASELINE config 2), "
         else:
@@ -704,9 +673,52 @@ def rx_workload_text(workload, C, B, world, signal, scatter, quiet_fraction=0.0,
     return head + tail
 
 
+def verify_against_oracle(iq, pcm, modes, launches, B, n, threshold, seed=0):
+    """`--verify` (on by default for the receive workloads): AFTER the timed region, `n` channels of the bench's own batch
+    -- channel 0, the last one and seeded-random ones from the whole range -- go through the sequential CPU oracle
+    (tests/reflib.Oracle: the checker, never the thing measured), from a fresh state through every launch the handle has
+    seen (settle + warm-up + timed steps over the same resident batch, the streams continuing), and the PCM the LAST timed
+    launch left in the output buffer must be the oracle's, sample for sample.  One Python thread per channel (ctypes
+    releases the GIL inside the oracle)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from tests import reflib
+    orc = reflib.Oracle()
+    C = iq.shape[0]
+    rng = np.random.default_rng(seed)
+    sel = {0, C - 1}
+    while len(sel) < min(n, C):
+        sel.add(int(rng.integers(0, C)))
+    sel = sorted(sel)
+    t0 = time.perf_counter()
+    tsel = torch.tensor(sel, device=iq.device)
+    x = iq[tsel][:, :B * BLOCK].reshape(len(sel), B, BLOCK).cpu().numpy()
+    got = pcm[tsel].cpu().numpy()
+
+    def work(i):
+        o = orc.rx()
+        o.set_mode(reflib.WBFM if modes is None else modes[sel[i]])
+        if threshold is not None:
+            o.set_threshold(int(threshold))
+        bad = 0
+        for launch in range(launches):
+            for b in range(B):
+                p = o.process(x[i, b])[0]
+                if launch == launches - 1:
+                    bad += int(len(p) != 512 or not (got[i, b] == p).all())
+        return bad
+
+    with ThreadPoolExecutor(max_workers=min(16, len(sel))) as ex:
+        bad = list(ex.map(work, range(len(sel))))
+    res = {"oracle_channels_checked": len(sel), "channels": sel, "launches_replayed_by_the_oracle": launches,
+           "pcm_blocks_compared": len(sel) * B, "pcm_blocks_mismatching": int(sum(bad)), "tolerance_lsb": 0,
+           "seconds": round(time.perf_counter() - t0, 1)}
+    assert sum(bad) == 0, f"bench --verify: PCM of channels {[c for c, k in zip(sel, bad) if k]} differs from the oracle"
+    return res
+
+
 def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmup, settle, rank, world,
                scatter=False, quiet_fraction=0.0, threshold=None, iqdump=False, idle_s=0.0, serial_modes=False, stride_pad=0,
-               blk=BLOCK):
+               blk=BLOCK, verify=0):
     """K timed steps of the receive path over one resident batch [C][B][262144]; returns the figures of a bench line.
     The dominant kernels' time comes from HIP events the library records on its launch stream(s) around the
     demodulator kernels of every launch (hrfd_rx_debug_enable_timing)."""
@@ -749,15 +761,15 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
     if scatter and rank == 0:
         # the north star's "per-channel scatter": every rank's IQ starts on rank 0, in ONE source buffer built once
         iq_root = torch.cat([gen(C, B, device, first_channel=r * C) for r in range(world)], dim=0).contiguous()
-    # Kernel time: HIP events the library records on the launch stream around the demodulator kernels of every
-    # `every`-th launch of the timed region.  (Every launch was bracketed until round 4: an event record is a queue packet
-    # of ~3 us, two per launch put a 6-7 us gap between kernels that otherwise follow each other without one --
-    # measured: 0.2237 ms per step with, 0.2166 without, kernel mean 0.2181.  The gap is the instrument's, not the path's.)
-    every = 4 if steps >= 16 else 1
-    n_timed = (steps + every - 1) // every
-    rx.debug_enable_timing(max(n_timed, 1))
-    rx.debug_timing_every(every)
-
+    # Kernel time (round 5): ONE pair of HIP events on the launch stream around ALL `steps` launches of the timed region --
+    # their distance / steps is the mean launch duration over every launch of the region (the kernels of consecutive
+    # steps follow each other on the stream without a gap).  Until round 4 the library bracketed every launch (rounds
+    # 1-3: an event record is a queue packet of ~3 us, two per launch put 6-7 us between kernels that otherwise follow
+    # each other with none) or every fourth one (round 4: 5 samples of 20 steps, and the gaps of the sampled ones still
+    # inside the step time).  Single launches are still sampled -- min / median -- but BEHIND the timed region
+    # (`n_samp` extra launches, hrfd_rx_debug_enable_timing): no event packet stands inside the region.
+    n_samp = 8
+    rx.debug_enable_timing(0)
     def step():
         if scatter:
             with torch.cuda.stream(stream):
@@ -771,16 +783,17 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
     for _ in range(settle + warmup):
         step()
     rx.sync()
-    rx.debug_enable_timing(max(n_timed, 1))             # restart the slot counter
-    rx.debug_timing_every(every)
 
+    ev_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev_region[0].record(stream)
     for _ in range(steps):
         step()
+    ev_region[1].record(stream)
     stream.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -788,23 +801,40 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device)
 
     rx.sync()
+    region_ms = ev_region[0].elapsed_time(ev_region[1]) / steps
+    rx.debug_enable_timing(n_samp)
+    rx.debug_timing_every(1)
+    for _ in range(n_samp):
+        step()
+    stream.synchronize()
+    rx.sync()
     counters = rx.debug_counters()
-    kernel_ms = [rx.debug_kernel_ms(i) for i in range(n_timed)]
+    kernel_ms = [rx.debug_kernel_ms(i) for i in range(n_samp)]
     produced = int(n_pcm.sum().item())
     # a closed gate produces no PCM (the tracker lets one "tail" block through after a signal: none here, the quiet
     # channels are quiet from the start)
     expect = (C - n_quiet) * B * (blk // 512)
     samples_per_step = C * B * (blk // 2)
     algo_bytes = C * B * (blk + blk // 256 + 4) + (C * B * (blk // 8) if iqdump else 0)   # 2.0078 B / IQ sample
-    mean_ms = float(np.mean(kernel_ms))
+    # the launch duration the roofline is priced with: all `steps` launches of the timed region (with the scatter on the
+    # stream the region holds the copies too: then the sampled kernels alone)
+    mean_ms = float(np.mean(kernel_ms)) if scatter else region_ms
     achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
     out = {
         "value": world * samples_per_step * steps / elapsed / 1e6,            # MSamples/s, whole job
         "ms_per_step": 1e3 * elapsed / steps, "mean_ms": mean_ms, "achieved": achieved,
         "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_median": float(np.median(kernel_ms)),
-        "algo_bytes": algo_bytes, "counters": counters, "quiet_channels": n_quiet, "launches_timed": n_timed,
+        "kernel_ms_sampled_mean": float(np.mean(kernel_ms)), "launches_sampled": n_samp,
+        "algo_bytes": algo_bytes, "counters": counters, "quiet_channels": n_quiet, "launches_timed": steps,
         "pcm_produced": produced, "pcm_expected": expect,
     }
+    if verify and not (iqdump or n_quiet or stride_pad or blk != BLOCK or scatter):
+        modes = None
+        if workload == "mixed":
+            modes = [[api.AM, api.FM, api.WBFM, api.LSB][(4 * c) // C] for c in range(C)]
+        elif workload in ("am", "fm", "ssb"):
+            modes = [{"am": api.AM, "fm": api.FM, "ssb": api.LSB}[workload]] * C
+        out["verification"] = verify_against_oracle(iq, pcm, modes, settle + warmup + steps + n_samp, B, verify, threshold, seed=C + steps)
     rx.close()
     del iq, pcm, n_pcm, iq256, iq_root
     torch.cuda.empty_cache()                             # the next workload of the line starts from a clean allocator
@@ -856,8 +886,12 @@ def also_lines(api, shard, device, args):
                                                     kw.get("iqdump", False))})
         return r
 
-    rx("wbfm_1024x16", workload="wbfm", C=1024, B=16, signal="fmtone")
-    rx("mixed_256x16", workload="mixed", C=256, B=16, signal="fmtone")
+    r = rx("wbfm_1024x16", workload="wbfm", C=1024, B=16, signal="fmtone", verify=args.verify)
+    out["wbfm_1024x16"]["verification"] = r.get("verification")
+    r = rx("mixed_256x16", workload="mixed", C=256, B=16, signal="fmtone", verify=args.verify)
+    out["mixed_256x16"]["verification"] = r.get("verification")
+    # config 4's whole bank on ONE GPU (16 GiB of IQ per launch): the N = 1 point of its strong-scaling curve
+    rx("wbfm_4096x16", workload="wbfm", C=4096, B=16, signal="fmtone", steps=10, warmup=3, settle=10)
     rx("wbfm_256x16_random", workload="wbfm", C=256, B=16, signal="random")
     # what a caller sees that launches into an idle GPU (the reference's cadence is one block per 64 ms): the driver's
     # own warm-up, no settling launches, after a second of idleness
@@ -885,6 +919,83 @@ def also_lines(api, shard, device, args):
     return out
 
 
+def rccl_block(shard, dist, device, rank, world):
+    """Proof that `world` ranks ran on `world` DEVICES over RCCL: every rank's device identity (PCI bus id, uuid)
+    all-gathered, the backend and its version, and one all-reduce of device tensors through it."""
+    ident = [None] * world
+    dist.all_gather_object(ident, {"rank": rank, **shard.device_identity(device.index)})
+    t = torch.tensor([rank + 1], dtype=torch.int64, device=device)
+    dist.all_reduce(t)
+    keys = {(d.get("host"), d.get("pci_bus_id") or d.get("uuid") or d.get("local_device")) for d in ident}
+    backend = dist.get_backend()
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:                               # noqa: BLE001
+            ver = repr(e)
+    return {"backend": backend + (" (= RCCL on ROCm)" if backend == "nccl" else " (REHEARSAL: host-staged, ranks may share a GPU)"),
+            "rccl_version": ver, "world_size": world, "devices": ident, "distinct_devices": len(keys),
+            "one_device_per_rank": len(keys) == world,
+            "all_reduce_of_device_tensors_ok": int(t.item()) == world * (world + 1) // 2}
+
+
+def measure_scatter(shard, device, dist, C, B, steps, rank, world):
+    """The scatter alone: all IQ of the job on rank 0, ONE group of point-to-point sends per step (shard.scatter_iq =
+    ncclGroupStart .. ncclGroupEnd under RCCL) into every rank's resident input tensor; K steps between barriers,
+    MAX over ranks.  Returns ms per step."""
+    mine = torch.zeros((C, B, BLOCK), dtype=torch.int8, device=device)
+    root = torch.zeros((world * C, B, BLOCK), dtype=torch.int8, device=device) if rank == 0 else None
+    for _ in range(2):
+        shard.scatter_iq(root, mine, world * C)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        shard.scatter_iq(root, mine, world * C)
+    torch.cuda.synchronize()
+    dist.barrier()
+    ms = 1e3 * shard.max_over_ranks(time.perf_counter() - t0, device) / steps
+    del mine, root
+    torch.cuda.empty_cache()
+    return ms
+
+
+def multi_gpu_legs(api, shard, device, dist, args, r_excl, C, B, settle, rank, world):
+    """N > 1, in the SAME invocation as the headline ("MS/s and roofline % at G = 1, 2, 4, 8 with scatter
+    included and excluded"): the headline's shape again with the per-channel scatter from rank 0 inside the timed
+    region, the scatter alone, config 4 (4096 channels over the N GPUs, strong scaling) both ways, and the `rccl` block."""
+    common = dict(workload=args.workload, B=B, signal=args.signal, steps=args.steps, warmup=args.warmup, settle=settle,
+                  rank=rank, world=world)
+    out = {"rccl": rccl_block(shard, dist, device, rank, world)}
+
+    def legs(Cg, r_ex):
+        r_in = measure_rx(api, shard, device, dist, C=Cg, scatter=True, **common)
+        sc_ms = measure_scatter(shard, device, dist, Cg, B, max(4, min(args.steps, 20)), rank, world)
+        per_link = Cg * B * BLOCK                            # bytes that leave rank 0 on EACH of its world - 1 links per step
+        return {"channels_per_gpu": Cg, "channels_total": world * Cg,
+                "excluded_ms": round(r_ex["ms_per_step"], 4), "included_ms": round(r_in["ms_per_step"], 4),
+                "value_excluded_MSamples_per_s": round(r_ex["value"], 1), "value_included_MSamples_per_s": round(r_in["value"], 1),
+                "roofline_frac_excluded": round(r_ex["achieved"] / HBM_PEAK_GBS, 4),
+                "scatter_alone_ms": round(sc_ms, 4), "bytes_per_link_per_step": per_link, "links_out_of_rank0": world - 1,
+                "GBps_per_link": round(per_link / (sc_ms * 1e-3) / 1e9, 1),
+                "uncommitted_launches": r_ex["counters"][5] + r_in["counters"][5]}
+
+    if args.scatter:
+        # the headline itself included the scatter: measure the leg without it here
+        r_plain = measure_rx(api, shard, device, dist, C=C, scatter=False, **common)
+        out["scatter"] = legs(C, r_plain)
+    else:
+        out["scatter"] = legs(C, r_excl)
+    if not args.no_config4 and args.workload == "wbfm" and 4096 % world == 0:
+        C4 = 4096 // world
+        r4 = measure_rx(api, shard, device, dist, C=C4, scatter=False, **common)
+        out["config4"] = {"workload": f"BASELINE config 4: 4096 WBFM channels over {world} GPU(s), {C4} per GPU x {B} blocks "
+                                      "(STRONG scaling: the N = 1 point is `also.wbfm_4096x16` of the one-GPU line)",
+                          "scaling": "strong", "kernel_ms_mean": round(r4["mean_ms"], 4), **legs(C4, r4)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -892,15 +1003,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=100,
                     help="untimed steps; the clock governor needs ~25 ms of this load to settle (DESIGN.md 5)")
     ap.add_argument("--channels", type=int, default=0,
-                    help="channels per GPU; default: 256 on one GPU (BASELINE config 2), 512 per GPU on several "
-                         "(config 4: 4096 channels over 8 GPUs), 1024 for the modulator workloads (config 5)")
+                    help="channels per GPU; default: 256 for EVERY N (BASELINE config 2's load per GPU: `value` at "
+                         "N = 1, 2, 4, 8 is one weak-scaling curve; config 4 -- 4096 channels over the N GPUs -- is measured "
+                         "in the same run and reported as `config4`), 1024 for the modulator workloads (config 5)")
     ap.add_argument("--blocks", type=int, default=16, help="262144-byte blocks per channel per step")
     ap.add_argument("--signal", choices=["fmtone", "random"], default="fmtone")
     ap.add_argument("--workload", choices=["wbfm", "mixed", "am", "fm", "ssb", "ssbmod", "ammod", "fmmod", "wbfmmod", "ingest", "fanout"], default="wbfm",
                     help="wbfm = BASELINE config 2 (the headline); mixed = config 3 (AM+FM+WBFM+SSB bank, "
                          "per-mode dispatch); ssbmod = config 5 (SSB modulator, 8-stage x256 interpolator)")
     ap.add_argument("--scatter", action="store_true",
-                    help="N > 1 only: all IQ starts on rank 0 and is scattered over RCCL inside the timed region")
+                    help="N > 1 only: the HEADLINE's timed region includes the scatter of all IQ from rank 0 over RCCL "
+                         "(without this flag both legs are still measured and reported as `scatter`: `value` excludes it)")
+    ap.add_argument("--verify", type=int, default=16,
+                    help="receive workloads: after the timed region, this many channels of the bench's own batch go through the "
+                         "sequential CPU oracle and must match bit for bit (0: off)")
+    ap.add_argument("--no-config4", action="store_true", help="N > 1: leave out the config 4 legs (4096 channels over the N GPUs)")
     ap.add_argument("--quiet-fraction", type=float, default=0.0,
                     help="this fraction of the channels carries no signal (with --threshold: their squelch gates close)")
     ap.add_argument("--threshold", type=int, default=None, help="squelch threshold in dBFS (setSignalDetectThreshold)")
@@ -919,7 +1036,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.channels <= 0:
-        args.channels = 1024 if args.workload in MOD_KINDS else 4096 if args.workload == "fanout" else (256 if world == 1 else 512)
+        args.channels = 1024 if args.workload in MOD_KINDS else 4096 if args.workload == "fanout" else 256
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -935,9 +1052,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if rehearse:
-            if args.scatter:
-                raise SystemExit("--scatter needs RCCL: gloo cannot send device tensors (rehearsal mode)")
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo")         # (device shards are staged through the host: shard.scatter_iq)
         else:
             dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
 
@@ -961,7 +1076,8 @@ def main():
     r = measure_rx(api, shard, device, dist, workload=args.workload, C=C, B=B, signal=args.signal, steps=args.steps,
                    warmup=args.warmup, settle=settle, rank=rank, world=world, scatter=args.scatter,
                    quiet_fraction=args.quiet_fraction, threshold=args.threshold, iqdump=args.iqdump,
-                   serial_modes=args.serial_modes, stride_pad=args.stride_pad)
+                   serial_modes=args.serial_modes, stride_pad=args.stride_pad, verify=args.verify if rank == 0 else 0)
+    multi = multi_gpu_legs(api, shard, device, dist, args, r, C, B, settle, rank, world) if world > 1 else None
     counters = r["counters"]
     assert r["pcm_produced"] == r["pcm_expected"], f"PCM samples produced {r['pcm_produced']} != {r['pcm_expected']}"
     wname = rx_workload_name(args.workload, C, B, args.signal, args.quiet_fraction, args.iqdump)
@@ -1019,17 +1135,23 @@ def main():
                            "the block kernels k_rx_fir / k_rx_post / k_rx_finish): first kernel's start to last kernel's end, "
                            "HIP events on the launch stream"),
                 "kernel_ms_mean": round(r["mean_ms"], 4),
+                "kernel_launches_timed": r["launches_timed"],
+                "kernel_timing": "one HIP event pair on the launch stream around all launches of the timed region / steps; "
+                                 "min, median, sampled_mean: single launches bracketed BEHIND the region",
                 "kernel_ms_min": round(r["kernel_ms_min"], 4),
                 "kernel_ms_median": round(r["kernel_ms_median"], 4),
-                "kernel_launches_timed": r["launches_timed"],
+                "kernel_ms_sampled_mean": round(r["kernel_ms_sampled_mean"], 4),
+                "kernel_launches_sampled": r["launches_sampled"],
                 "algorithmic_bytes_per_launch": r["algo_bytes"],
             },
             "verification": {"uncommitted_launches": counters[5], "tiles_repaired_in_place": counters[4],
-                             "launches": counters[6]},
+                             "launches": counters[6], **r.get("verification", {"oracle_channels_checked": 0})},
             "kernel_code_tag": kernel_code_tag(),
             "kernel_source_tag": kernel_source_tag(),
             "runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "under_profiler": under_profiler()},
         }
+        if multi is not None:
+            line.update(multi)
         if counters[5] != 0:
             # a launch that did not commit means later launches started from a stale state and the batch path was
             # not what ran: the number is not a measurement of it

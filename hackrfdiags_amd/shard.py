@@ -32,6 +32,30 @@ def _run(ops):
             req.wait()
 
 
+def device_identity(index: int) -> dict:
+    """What tells one GPU of a node from another, for the bench line's `rccl` block (the proof that N ranks ran on N
+    devices): PCI bus id from the HIP runtime the process already holds, uuid and name from torch's properties."""
+    import ctypes
+    import socket
+    out = {"host": socket.gethostname(), "local_device": int(index)}
+    try:
+        props = torch.cuda.get_device_properties(index)
+        out["name"] = props.name
+        if hasattr(props, "uuid"):
+            out["uuid"] = str(props.uuid)
+    except Exception as e:                                   # noqa: BLE001 (identity is best effort, the bus id below is the key)
+        out["props_error"] = repr(e)
+    try:
+        from . import _lib
+        rt = _lib._load_hip_runtime()
+        buf = ctypes.create_string_buffer(64)
+        if rt.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+            out["pci_bus_id"] = buf.value.decode()
+    except Exception as e:                                   # noqa: BLE001
+        out["pci_error"] = repr(e)
+    return out
+
+
 def scatter_iq(iq_all: Optional[torch.Tensor], mine: torch.Tensor, n_channels: int, src: int = 0) -> torch.Tensor:
     """Rank `src` holds int8 [n_channels, blocks, block_bytes] (contiguous); every rank receives its shard INTO
     `mine` ([hi - lo, blocks, block_bytes], contiguous, persistent: no allocation, no second copy per step).
@@ -39,6 +63,9 @@ def scatter_iq(iq_all: Optional[torch.Tensor], mine: torch.Tensor, n_channels: i
     rank, world = dist.get_rank(), dist.get_world_size()
     lo, hi = channel_range(rank, world, n_channels)
     assert mine.shape[0] == hi - lo and mine.is_contiguous()
+    # gloo carries host tensors only: device shards are staged through the host (REHEARSALS of bench.py --gpus N on a
+    # one-GPU box, tests; under nccl = RCCL the device tensors go as they are, over xGMI)
+    staged = mine.is_cuda and dist.get_backend() == "gloo"
     if rank == src:
         assert iq_all is not None and iq_all.is_contiguous()
         ops = []
@@ -47,10 +74,15 @@ def scatter_iq(iq_all: Optional[torch.Tensor], mine: torch.Tensor, n_channels: i
             if r == src:
                 mine.copy_(iq_all[a:b])
             elif b > a:
-                ops.append(dist.P2POp(dist.isend, iq_all[a:b], r))      # a slice of leading rows is contiguous
+                ops.append(dist.P2POp(dist.isend, iq_all[a:b].cpu() if staged else iq_all[a:b], r))   # a slice of leading rows is contiguous
         _run(ops)
     elif hi > lo:
-        _run([dist.P2POp(dist.irecv, mine, src)])
+        if staged:
+            host = torch.empty(mine.shape, dtype=mine.dtype)
+            _run([dist.P2POp(dist.irecv, host, src)])
+            mine.copy_(host)
+        else:
+            _run([dist.P2POp(dist.irecv, mine, src)])
     return mine
 
 

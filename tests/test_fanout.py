@@ -64,44 +64,89 @@ def test_fanout_on_one_device_equals_one_handle_and_the_oracle(oracle, n_shards,
                     assert gn[c, b - half * B] == len(p) and (got[c, b - half * B, :len(p)] == p).all(), (half, c, b)
 
 
+def _fanout_bank(oracle, C, B, devices, launches, n_check, period_too):
+    """C WBFM channels x B blocks per batch through hrfd_fanout_* over `devices` (shard g on devices[g]), the IQ of the
+    whole bank on device 0, EVERY channel an input of its own: `n_check` channels of the whole range against the
+    sequential oracle, ALL channels against one handle over the whole bank on device 0 (the same device code, another
+    partition: a shard that reads or writes another shard's rows shows), nothing replayed.  `period_too`: one more
+    batch on a fresh fan-out with inputs of period 7 -- every channel against the channel fed the same input."""
+    import torch
+    from tests.fullsize import PERIOD, distinct_batch, assert_all_distinct, oracle_rx_stream, pick_channels
+    dev = torch.device("cuda:0")
+    nsh = len(devices)
+    assert sum(api.fanout_channel_range(C, nsh, g)[1] for g in range(nsh)) == C
+    x = distinct_batch(C, launches * B, dev)
+    assert_all_distinct(x)
+    sel = pick_channels(C, n_check)
+    tsel = torch.tensor(sel, device=dev)
+    fo = api.Fanout(C, devices)
+    fo.set_mode(api.WBFM)
+    one = api.Rx(C)
+    one.set_mode(api.WBFM)
+    out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+    npcm = torch.zeros((C, B), dtype=torch.int32, device=dev)
+    got = []
+    s = torch.cuda.Stream()
+    for k in range(launches):
+        with torch.cuda.stream(s):
+            xs = x[:, k * B:(k + 1) * B].contiguous()
+        fo.scatter(0, xs.data_ptr(), BLK, B, src_stream=s.cuda_stream)
+        fo.process(0)
+        assert fo.collect(0, out.data_ptr(), npcm.data_ptr()) == 0, "a channel was replayed"
+        torch.cuda.synchronize()
+        assert int(npcm.sum().item()) == C * B * 512
+        got.append(out[tsel].cpu().numpy())
+        out1 = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        one.process_device(xs.data_ptr(), B * BLK, BLK, B, out1.data_ptr())
+        assert one.sync() == 0
+        assert torch.equal(out1, out), k                  # every channel, on the device
+        del xs, out1
+    xsel = x[tsel].cpu().numpy()
+    del x
+    one.close()
+    torch.cuda.empty_cache()
+    for i, c in enumerate(sel):
+        for b, (p, _, _) in enumerate(oracle_rx_stream(oracle, WBFM, xsel[i])):
+            assert (got[b // B][i, b % B] == p).all(), (c, b)
+    fo.close()
+    if period_too:
+        base = np.stack([synth.make_input("fmtone" if k % 2 else "lcg", 800 + k, B).reshape(B, BLK) for k in range(PERIOD)])
+        fo = api.Fanout(C, devices)
+        fo.set_mode(api.WBFM)
+        idx = torch.arange(C, device=dev) % PERIOD
+        with torch.cuda.stream(s):
+            xs = torch.from_numpy(base).to(dev)[idx]
+        fo.scatter(0, xs.data_ptr(), BLK, B, src_stream=s.cuda_stream)
+        fo.process(0)
+        assert fo.collect(0, out.data_ptr(), npcm.data_ptr()) == 0
+        torch.cuda.synchronize()
+        del xs
+        assert bool((out[PERIOD:] == out[idx[PERIOD:]]).all())          # channel c = channel c mod 7, on the device
+        head = out[:PERIOD].cpu().numpy()
+        for k in range(PERIOD):
+            for b, (p, _, _) in enumerate(oracle_rx_stream(oracle, WBFM, base[k])):
+                assert (head[k, b] == p).all(), (k, b)
+        fo.close()
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.gpu
 def test_config4_full_size_through_the_fanout_on_one_device(oracle):
     """BASELINE config 4 as far as one GPU allows: 4096 WBFM channels x 16 blocks (16 GiB of IQ on the source device)
     through hrfd_fanout_* with EIGHT shards of 512 channels -- all eight on device 0 here; on an 8-GPU node the same
-    calls put one shard on each GPU and the scatter's copies go over xGMI (unmeasured until such a node exists).
-    Two batches (every stream continues).  A spread of channels against the sequential oracle; every one of the 4096
-    against the channel that was fed the same input; nothing replayed."""
-    import torch
-    C, B, NSH = 4096, 16, 8
-    NBASE = 8
-    dev = torch.device("cuda:0")
-    base = np.stack([synth.make_input("fmtone" if k % 2 else "lcg", 800 + k, 2 * B).reshape(2 * B, BLK) for k in range(NBASE)])
-    assert [api.fanout_channel_range(C, NSH, g) for g in range(NSH)] == [(512 * g, 512) for g in range(NSH)]
-    fo = api.Fanout(C, [0] * NSH)
-    fo.set_mode(api.WBFM)
-    idx = (torch.arange(C, device=dev) % NBASE)
-    out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
-    npcm = torch.zeros((C, B), dtype=torch.int32, device=dev)
-    s = torch.cuda.Stream()
-    for half in range(2):
-        with torch.cuda.stream(s):
-            bdev = torch.from_numpy(base[:, half * B:(half + 1) * B].copy()).to(dev)      # [NBASE, B, BLK]
-            x = bdev[idx]                                                                  # [4096, 16, 262144]: 16 GiB
-        fo.scatter(0, x.data_ptr(), BLK, B, src_stream=s.cuda_stream)
-        fo.process(0)
-        assert fo.collect(0, out.data_ptr(), npcm.data_ptr()) == 0, "a channel was replayed"
-        torch.cuda.synchronize()
-        del x
-        assert int(npcm.sum().item()) == C * B * 512
-        # every channel equals the first channel with its input, on the device (64 MiB of PCM)
-        assert bool((out.view(C // NBASE, NBASE, B, 512) == out[:NBASE].unsqueeze(0)).all())
-        got = out[:NBASE].cpu().numpy()
-        for k in range(NBASE):
-            o = oracle.rx()
-            o.set_mode(WBFM)
-            for b in range((half + 1) * B):
-                p = o.process(base[k, b])[0]
-                if b >= half * B:
-                    assert (got[k, b - half * B] == p).all(), (half, k, b)
-    fo.close()
-    torch.cuda.empty_cache()
+    calls put one shard on each GPU and the scatter's copies go over xGMI (test_fanout_over_the_devices_of_a_node,
+    below, switches itself on there).  Two batches (every stream continues), every channel an input of its own."""
+    assert [api.fanout_channel_range(4096, 8, g) for g in range(8)] == [(512 * g, 512) for g in range(8)]
+    _fanout_bank(oracle, 4096, 16, [0] * 8, launches=2, n_check=64, period_too=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_dev", [2, 3, 4, 8])
+def test_fanout_over_the_devices_of_a_node(oracle, n_dev):
+    """The same bank with one shard per DEVICE: hipDeviceEnablePeerAccess, per-device table replication and the
+    hipMemcpyPeerAsync scatter / gather of hrfd_fanout.hip over xGMI.  Needs n_dev devices: skipped on the one-GPU
+    boxes this repository has been developed on (never run so far), switched on by itself on a node."""
+    if api.device_count() < n_dev:
+        pytest.skip(f"needs {n_dev} devices, this box has {api.device_count()}")
+    _fanout_bank(oracle, 512 * n_dev, 16, list(range(n_dev)), launches=2, n_check=64, period_too=True)

@@ -5,121 +5,94 @@
   config 3                    64 AM + 64 FM + 64 WBFM + 64 SSB x 16 blocks, one launch of k_rx_flow_bank
   config 5                    1024 SSB modulators
 
-Each against the sequential CPU oracle on a spread of channels, plus size-independent properties over
-ALL channels: channels fed identical input give identical output, every launch committed (nothing was
-replayed), and the batch kernel (k_rx_wbfm_flow) and the block kernel (k_rx_wbfm) agree; a soak over
-60 launches of random input with gates closing at random."""
+Every channel is fed an input of ITS OWN (round 5; tests/fullsize.py says why: until round 4 the inputs had period 8,
+the number of XCDs, and a channel mapped onto c +- 8k would have gone unseen): 64 channels drawn from the whole range
+-- 0, C - 1, every residue mod 8 -- against the sequential CPU oracle, plus size-independent properties over ALL
+channels: the batch kernel (k_rx_wbfm_flow) and the block kernel (k_rx_wbfm) agree on every channel's distinct input,
+channels fed identical input (period 7, coprime to 8) give identical output, every launch committed (nothing was
+replayed); soaks over hundreds of launches of random input with gates closing at random."""
 import os
-import zlib
 
 import numpy as np
 import pytest
 
 from hackrfdiags_amd import api, synth
+from tests.fullsize import PERIOD, check_rx_bank_distinct, check_rx_bank_period, distinct_batch, oracle_rx_stream, pick_channels
 from tests.reflib import AM, FM, LSB, WBFM
 
 pytestmark = pytest.mark.gpu
 BLK = synth.BLOCK_BYTES
-NBASE = 8
-
-
-def _oracle_pcm(oracle, mode, x):
-    o = oracle.rx()
-    o.set_mode(mode)
-    outs = [o.process(x[b]) for b in range(x.shape[0])]
-    return np.stack([w[0] for w in outs]), [w[1] for w in outs]
 
 
 @pytest.mark.parametrize("C", [512, 1024])
 def test_wbfm_512_and_1024_channels(oracle, C):
     """C x 16 blocks of 262144 B per launch (2 and 4 GiB of IQ): the persistent grid is 2 and 4 workgroups
-    per CU deep here.  Two launches (the second continues every stream)."""
-    import torch
-    B = 16
-    dev = torch.device("cuda:0")
-    base = [synth.make_input("fmtone" if k % 2 else "lcg", 500 + k, 2 * B).reshape(2 * B, BLK) for k in range(NBASE)]
-    x = torch.empty((C, B, BLK), dtype=torch.int8, device=dev)
-    want = [_oracle_pcm(oracle, WBFM, base[k]) for k in range(NBASE)]
-    rx = api.Rx(C)
-    rx.set_mode(api.WBFM)
-    ref_other = api.Rx(C)
-    ref_other.set_mode(api.WBFM)
-    ref_other.debug_set_stream(0)                        # k_rx_wbfm: runs of blocks, phases in sequence
-    for half in range(2):
-        for c in range(C):
-            x[c] = torch.from_numpy(base[c % NBASE][half * B:(half + 1) * B]).to(dev)
-        out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
-        mag = torch.zeros((C, B), dtype=torch.int32, device=dev)
-        npcm = torch.zeros((C, B), dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        rx.process_device(x.data_ptr(), B * BLK, BLK, B, out.data_ptr(), d_n_pcm=npcm.data_ptr(), d_magnitude=mag.data_ptr())
-        assert rx.sync() == 0
-        got, gmag = out.cpu().numpy(), mag.cpu().numpy()
-        assert int(npcm.sum().item()) == C * B * 512
-        for k in range(NBASE):
-            assert (got[k] == want[k][0][half * B:(half + 1) * B]).all(), (half, k)
-            assert gmag[k].tolist() == want[k][1][half * B:(half + 1) * B], (half, k)
-            for c in range(k, C, NBASE):                  # every channel with this input
-                assert (got[c] == got[k]).all() and (gmag[c] == gmag[k]).all(), (half, c, k)
-        out2 = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
-        torch.cuda.synchronize()
-        ref_other.process_device(x.data_ptr(), B * BLK, BLK, B, out2.data_ptr())
-        assert ref_other.sync() == 0
-        assert zlib.crc32(out2.cpu().numpy().tobytes()) == zlib.crc32(got.tobytes())
-    assert rx.debug_counters()[5] == 0 and ref_other.debug_counters()[5] == 0, "a launch was replayed"
+    per CU deep here.  Two launches (the second continues every stream).  EVERY channel has an input of its own
+    (tests/fullsize.py); 64 channels drawn from the whole range (0, C - 1, every residue mod 8) against the sequential
+    oracle, and the block kernel k_rx_wbfm (runs of blocks, phases in sequence) must agree on ALL channels."""
+    check_rx_bank_distinct(oracle, api, C, 16, lambda c: WBFM, twin=lambda rx2: rx2.debug_set_stream(0))
+
+
+def test_wbfm_1024_channels_all_channels_period_7(oracle):
+    """the all-channel property at 1024 channels with a period coprime to the 8 XCDs: equal input => equal output"""
+    check_rx_bank_period(oracle, api, 1024, 16, lambda c: WBFM, seed=500)
+
+
+MIXED = [AM, FM, WBFM, LSB]
 
 
 def test_mixed_bank_full_size(oracle):
-    """config 3: 64 AM + 64 FM + 64 WBFM + 64 SSB channels x 16 blocks, two launches"""
-    import torch
-    C, B = 256, 16
-    modes = [AM, FM, WBFM, LSB]
-    amodes = [api.AM, api.FM, api.WBFM, api.LSB]
-    dev = torch.device("cuda:0")
-    base = [synth.make_input(("fmtone", "lcg")[k], 600 + k, 2 * B).reshape(2 * B, BLK) for k in range(2)]
-    rx = api.Rx(C)
-    for c in range(C):
-        rx.set_mode(amodes[(4 * c) // C], channel=c)
-    want = {(q, k): _oracle_pcm(oracle, modes[q], base[k]) for q in range(4) for k in range(2)}
-    x = torch.empty((C, B, BLK), dtype=torch.int8, device=dev)
-    for half in range(2):
-        for c in range(C):
-            x[c] = torch.from_numpy(base[c % 2][half * B:(half + 1) * B]).to(dev)
-        out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
-        torch.cuda.synchronize()
-        rx.process_device(x.data_ptr(), B * BLK, BLK, B, out.data_ptr())
-        assert rx.sync() == 0
-        got = out.cpu().numpy()
-        for q in range(4):
-            c0 = q * (C // 4)
-            for k in range(2):
-                assert (got[c0 + k] == want[(q, k)][0][half * B:(half + 1) * B]).all(), (half, q, k)
-                for c in range(c0 + k, c0 + C // 4, 2):
-                    assert (got[c] == got[c0 + k]).all(), (half, q, c)
-    assert rx.debug_counters()[5] == 0
+    """config 3: 64 AM + 64 FM + 64 WBFM + 64 SSB channels x 16 blocks, two launches, every channel an input of its
+    own; 64 channels of the whole bank (all four quarters) against the oracle in their modes; then the all-channel
+    property with period 7"""
+    C = 256
+    check_rx_bank_distinct(oracle, api, C, 16, lambda c: MIXED[(4 * c) // C])
+    check_rx_bank_period(oracle, api, C, 16, lambda c: MIXED[(4 * c) // C], seed=600)
 
 
 def test_ssb_modulator_1024_channels(oracle):
-    """config 5: 1024 SSB modulators, 16 blocks of 512 PCM samples each, two calls"""
+    """config 5: 1024 SSB modulators, 16 blocks of 512 PCM samples each, two calls.  Every channel has PCM of its own
+    (LCG seed 7 + c) and a sideband that does not follow the channel number mod 8; 64 channels of the whole
+    range against the oracle's modulator.  Then the all-channel property with period 7: equal (input, sideband) =>
+    equal bytes."""
     C, B = 1024, 16
-    base = [synth.lcg_pcm(7 + k, 2 * B * 512) for k in range(NBASE)]
-    pcm = np.stack([base[c % NBASE] for c in range(C)])
+    n = 2 * B * 512
+    lsb_of = lambda c: (c % 3) != 0                       # noqa: E731
+    # --- distinct inputs
+    pcm = np.stack([synth.lcg_pcm(7 + c, n) for c in range(C)])
+    assert len({pcm[c, :64].tobytes() for c in range(C)}) == C
     m = api.Mod(api.MOD_SSB, C)
     for c in range(C):
-        m.set_sideband(c % 16 < 8, channel=c)            # channels k and k + 8 differ in sideband only
-    os_ = {}
-    for k in range(2 * NBASE):
-        o = oracle.ssbmod(k < NBASE)
-        os_[k] = o
+        m.set_sideband(lsb_of(c), channel=c)
+    sel = pick_channels(C)
+    orc = {c: oracle.ssbmod(lsb_of(c)) for c in sel}
     for half in range(2):
-        seg = pcm[:, half * B * 512:(half + 1) * B * 512]
-        got = m.process(seg)
-        for k in range(2 * NBASE):
-            want = np.concatenate([os_[k].process(base[k % NBASE][half * B * 512 + s:half * B * 512 + s + 512]) for s in range(0, B * 512, 512)])
-            assert (got[k] == want).all(), (half, k)
-            for c in range(k, C, 16):
-                assert (got[c] == got[k]).all(), (half, c, k)
-
+        got = m.process(pcm[:, half * B * 512:(half + 1) * B * 512])
+        for c in sel:
+            want = np.concatenate([orc[c].process(pcm[c, half * B * 512 + s:half * B * 512 + s + 512]) for s in range(0, B * 512, 512)])
+            assert (got[c] == want).all(), (half, c)
+        del got
+    del m
+    # --- period 7, every channel
+    base = [synth.lcg_pcm(7007 + k, n) for k in range(PERIOD)]
+    pcm = np.stack([base[c % PERIOD] for c in range(C)])
+    side = lambda c: (c // PERIOD) % 2 == 0               # noqa: E731
+    m = api.Mod(api.MOD_SSB, C)
+    for c in range(C):
+        m.set_sideband(side(c), channel=c)
+    firsts = {}
+    for c in range(C):
+        firsts.setdefault((c % PERIOD, side(c)), c)
+    orc = {key: oracle.ssbmod(key[1]) for key in firsts}
+    for half in range(2):
+        got = m.process(pcm[:, half * B * 512:(half + 1) * B * 512])
+        for key, c0 in firsts.items():
+            want = np.concatenate([orc[key].process(base[key[0]][half * B * 512 + s:half * B * 512 + s + 512]) for s in range(0, B * 512, 512)])
+            assert (got[c0] == want).all(), (half, key)
+        for c in range(C):
+            c0 = firsts[(c % PERIOD, side(c))]
+            assert c == c0 or (got[c] == got[c0]).all(), (half, c, c0)
+        del got
 
 
 def test_soak_flow_shapes_agree_launch_after_launch():
@@ -197,40 +170,57 @@ def test_soak_wbfm_flow_against_the_block_kernel():
 def test_realtime_cadence_1024_channels_one_block_per_batch(oracle, kind):
     """The north star's target in the reference's own cadence (bench.py `also.realtime_1024x1`): 1024 channels, ONE
     262144-byte block per channel per batch (hackRf/hackrf.c:100-101, DataConsumer.cc:219-262), from pinned host memory
-    through hrfd_ingest_*, PCM back on the host, batch after batch with the streams continuing.  Four batches; PCM,
-    magnitude and gate of a spread of channels against the sequential oracle, and every channel against the channel
-    that was fed the same input."""
+    through hrfd_ingest_*, PCM back on the host, batch after batch with the streams continuing.  Four batches, every
+    channel an input of its own: PCM, magnitude and gate of 64 channels of the whole range against the sequential
+    oracle.  Then four more batches on a fresh bank with inputs of period 7: every channel against the channel of its
+    mode that was fed the same input."""
+    import torch
     C, NB = 1024, 4
-    modes = [AM, FM, WBFM, LSB]
-    amodes = [api.AM, api.FM, api.WBFM, api.LSB]
-    base = [synth.make_input("fmtone" if k % 2 else "lcg", 900 + k, NB).reshape(NB, BLK) for k in range(NBASE)]
-    rx = api.Rx(C)
-    if kind == "mixed":
-        for c in range(C):
-            rx.set_mode(amodes[(4 * c) // C], channel=c)
-    else:
-        rx.set_mode(api.WBFM)
-    ing = api.Ingest(rx, BLK, 1, 2)
-    got = []
+    mode_of = (lambda c: MIXED[(4 * c) // C]) if kind == "mixed" else (lambda c: WBFM)
+
+    def bank():
+        rx = api.Rx(C)
+        if kind == "mixed":
+            for c in range(C):
+                rx.set_mode(mode_of(c), channel=c)
+        else:
+            rx.set_mode(api.WBFM)
+        return rx, api.Ingest(rx, BLK, 1, 2)
+
+    def run(ing, x):
+        got = []
+        for t in range(NB):
+            slot = ing.acquire()
+            slot[:, 0] = x[:, t]
+            ing.submit(0)
+            got.append(ing.collect())
+        assert ing.replayed() == 0
+        ing.close()
+        return got
+
+    # --- distinct inputs
+    x = distinct_batch(C, NB, torch.device("cuda:0")).cpu().numpy()
+    torch.cuda.empty_cache()
+    rx, ing = bank()
+    got = run(ing, x)
+    for c in pick_channels(C):
+        for t, (p, m, a) in enumerate(oracle_rx_stream(oracle, mode_of(c), x[c])):
+            pcm, n_pcm, mag, allowed = got[t]
+            assert n_pcm[c, 0] == 512 and bool(allowed[c, 0]) == a and int(mag[c, 0]) == m, (c, t)
+            assert (pcm[c, 0] == p).all(), (c, t)
+    del x
+    # --- period 7, every channel
+    base = np.stack([synth.make_input("fmtone" if k % 2 else "lcg", 900 + k, NB).reshape(NB, BLK) for k in range(PERIOD)])
+    rx, ing = bank()
+    got = run(ing, base[np.arange(C) % PERIOD])
+    firsts = {}
+    for c in range(C):
+        firsts.setdefault((mode_of(c), c % PERIOD), c)
+    for (mode, r), c0 in firsts.items():
+        for t, (p, m, a) in enumerate(oracle_rx_stream(oracle, mode, base[r])):
+            assert (got[t][0][c0, 0] == p).all() and int(got[t][2][c0, 0]) == m, (mode, r, t)
     for t in range(NB):
-        slot = ing.acquire()
-        for k in range(NBASE):
-            slot[k::NBASE, 0] = base[k][t]
-        ing.submit(0)
-        got.append(ing.collect())
-    assert ing.replayed() == 0
-    ing.close()
-    quarters = range(4) if kind == "mixed" else [2]
-    for q in quarters:
-        lo, hi = (q * C // 4, (q + 1) * C // 4) if kind == "mixed" else (0, C)
-        for k in range(NBASE):
-            o = oracle.rx()
-            o.set_mode(modes[q])
-            first = lo + ((k - lo) % NBASE)              # the first channel of this quarter with base input k
-            for t in range(NB):
-                p, m, a, _ = o.process(base[k][t])
-                pcm, n_pcm, mag, allowed = got[t]
-                assert n_pcm[first, 0] == 512 and bool(allowed[first, 0]) == a and int(mag[first, 0]) == m, (q, k, t)
-                assert (pcm[first, 0] == p).all(), (q, k, t)
-                same = np.arange(first, hi, NBASE)
-                assert (pcm[same, 0] == pcm[first, 0]).all() and (mag[same, 0] == mag[first, 0]).all(), (q, k, t)
+        pcm, n_pcm, mag, allowed = got[t]
+        for c in range(C):
+            c0 = firsts[(mode_of(c), c % PERIOD)]
+            assert c == c0 or ((pcm[c, 0] == pcm[c0, 0]).all() and mag[c, 0] == mag[c0, 0]), (t, c, c0)

@@ -747,35 +747,14 @@ def test_fm_atan2_kernels_agree(oracle, kind):
 
 
 def test_full_size_bench_batch_matches_oracle(oracle):
-    """BASELINE config 2 at full size -- 256 WBFM channels x 16 blocks in one launch (1 GiB of IQ,
-    runs of 8 blocks per workgroup) followed by a second launch that continues the streams --
-    every PCM sample of a spread of channels against the sequential oracle, and two
-    size-independent properties over ALL channels: channels fed identical input give identical
-    PCM, and the launch committed (no unit failed its speculation)."""
-    import torch
-    C, B = 256, 16
-    base = [synth.make_input("fmtone" if k % 2 else "lcg", 200 + k, 2 * B).reshape(2 * B, BLK) for k in range(8)]
-    dev = torch.device("cuda:0")
-    x = torch.empty((C, 2 * B, BLK), dtype=torch.int8, device=dev)
-    for c in range(C):
-        x[c] = torch.from_numpy(base[c % 8]).to(dev)
-    pcm = torch.zeros((C, 2 * B, 512), dtype=torch.int16, device=dev)
-    rx = api.Rx(C)
-    rx.set_mode(api.WBFM)
-    for half in range(2):
-        xs = x[:, half * B:(half + 1) * B].contiguous()
-        out = torch.zeros((C, B, 512), dtype=torch.int16, device=dev)
-        torch.cuda.synchronize()                         # torch fills on its own stream, the handle runs on another
-        rx.process_device(xs.data_ptr(), B * BLK, BLK, B, out.data_ptr())
-        assert rx.sync() == 0
-        pcm[:, half * B:(half + 1) * B] = out
-    got = pcm.cpu().numpy()
-    for k in range(8):
-        want = np.stack([w[0] for w in _oracle_stream(oracle, WBFM, base[k], 2 * B)])
-        assert (got[k] == want).all(), k
-        for c in range(k, C, 8):                          # every channel with this input
-            assert (got[c] == got[k]).all(), (c, k)
-    assert rx.debug_counters()[5] == 0
+    """BASELINE config 2 at full size -- 256 WBFM channels x 16 blocks in one launch (1 GiB of IQ) followed by a
+    second launch that continues the streams, EVERY channel fed an input of its own (the bench's own generators,
+    tests/fullsize.py): every PCM sample, magnitude and gate of 64 channels drawn from the whole range (0, 255, every
+    residue mod 8) against the sequential oracle, the block kernel agreeing on all 256, nothing replayed.  Then the
+    all-channel property with inputs of period 7 (coprime to the 8 XCDs): equal input => equal PCM."""
+    from tests.fullsize import check_rx_bank_distinct, check_rx_bank_period
+    check_rx_bank_distinct(oracle, api, 256, 16, lambda c: WBFM, twin=lambda rx2: rx2.debug_set_stream(0))
+    check_rx_bank_period(oracle, api, 256, 16, lambda c: WBFM, seed=200)
 
 
 def test_odd_shapes_mixed_modes_and_runs(oracle):

@@ -148,3 +148,69 @@ def test_ranks_run_libhrfd_on_their_shards(world, n_channels):
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(world))
     assert all(results[r] for r in range(world)), results
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The nccl (= RCCL) twin: one rank per DEVICE, device tensors end to end, the grouped scatter / gather over xGMI --
+# the path bench.py --gpus N takes on a node.  Needs `world` devices: skipped on the one-GPU boxes this repository
+# has been developed on (never run so far); it switches itself on the day a node is there.
+# ---------------------------------------------------------------------------------------------------------------
+def _nccl_worker(rank, world, port, n_channels, blocks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from hackrfdiags_amd import api
+    BLK = synth.BLOCK_BYTES
+    lo, hi = shard.channel_range(rank, world, n_channels)
+    ref = _inputs(n_channels, 2 * blocks) if rank == 0 else None
+    mine = torch.zeros((hi - lo, blocks, BLK), dtype=torch.int8, device=dev)
+    pcm = torch.zeros((hi - lo, blocks, 512), dtype=torch.int16, device=dev)
+    allpcm = torch.zeros((n_channels, blocks, 512), dtype=torch.int16, device=dev) if rank == 0 else None
+    rx = api.Rx(hi - lo, device=rank)
+    rx.set_mode(api.WBFM)
+    # proof that `world` ranks sit on `world` different devices
+    ident = [None] * world
+    dist.all_gather_object(ident, str(torch.cuda.get_device_properties(dev).uuid) if hasattr(torch.cuda.get_device_properties(dev), "uuid")
+                           else f"{rank}:{torch.cuda.get_device_properties(dev).name}")
+    ok = len(set(ident)) == world
+    got = []
+    for step in range(2):
+        iq_all = torch.from_numpy(ref[:, step * blocks:(step + 1) * blocks].copy()).to(dev).contiguous() if rank == 0 else None
+        shard.scatter_iq(iq_all, mine, n_channels)
+        torch.cuda.synchronize()
+        rx.process_device(mine.data_ptr(), blocks * BLK, BLK, blocks, pcm.data_ptr())
+        ok = ok and rx.sync() == 0
+        shard.gather_pcm(pcm, allpcm, n_channels)
+        torch.cuda.synchronize()
+        if rank == 0:
+            got.append(allpcm.cpu().numpy().copy())
+    if rank == 0:
+        ok = ok and bool((np.concatenate(got, axis=1) == _oracle_pcm(ref)).all())
+    t = shard.max_over_ranks(0.25 * (rank + 1), dev)
+    ok = ok and abs(t - 0.25 * world) < 1e-9
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, ok))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_channels", [(2, 6), (4, 9), (8, 16)])
+def test_ranks_run_libhrfd_on_their_own_devices_over_rccl(world, n_channels):
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} devices, this box has {torch.cuda.device_count()}")
+    from tests.reflib import build_oracle
+    build_oracle()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + world * 7 + n_channels
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, n_channels, 3, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=10) for _ in range(world))
+    assert all(results[r] for r in range(world)), results
