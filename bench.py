@@ -768,7 +768,7 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
     # each other with none) or every fourth one (round 4: 5 samples of 20 steps, and the gaps of the sampled ones still
     # inside the step time).  Single launches are still sampled -- min / median -- but BEHIND the timed region
     # (`n_samp` extra launches, hrfd_rx_debug_enable_timing): no event packet stands inside the region.
-    n_samp = 8
+    n_samp = min(8, steps)
     rx.debug_enable_timing(0)
     def step():
         if scatter:

@@ -106,7 +106,8 @@ class Rx:
         """The arithmetic atan2 of the WBFM kernels over all (q, i): float32 [256][256]; tab: the
         first-octant-table variant of k_rx_wbfm_flow instead of the polynomial one."""
         out = np.zeros((256, 256), dtype=np.float32)
-        fn = self.L.hrfd_rx_debug_atan_eval_tab if tab else self.L.hrfd_rx_debug_atan_eval
+        fn = (self.L.hrfd_rx_debug_atan_eval_quad if tab == "quad" else
+              self.L.hrfd_rx_debug_atan_eval_tab if tab else self.L.hrfd_rx_debug_atan_eval)
         check(fn(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "hrfd_rx_debug_atan_eval")
         return out
 

@@ -84,6 +84,54 @@ static void build_atan2(float *out)
   }
 }
 
+// First-quadrant table of the re-split flow kernel (theta_quad, hrfd_rx_kernels.hip): TQ[|q| * 129 + |i|] =
+// (float)atan2((double)|q|, (double)|i|) -- the reference's own entry for i, q >= 0 -- with, in its two free top bits,
+// the signed correction (ulps) that makes bits(pi_f - t) + fix the reference's entry for i < 0.  Derived from the
+// reference table `lut` itself and PROVEN here, entry by entry: the corrections fit two bits, the table is odd in q
+// (row q = -128 included), every word is below 2.0.  Returns false when any of that fails on this libm (the library
+// then keeps the kernels that do not use this table).
+static bool build_atan_quadrant(const float *lut, uint32_t *out)
+{
+  auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+  const float pi_f = 3.14159274f;
+  bool ok = true;
+  for (int i = 0; i < kQuadDwords; i++)
+  {
+    out[i] = 0u;
+  }
+  for (int aq = 0; aq <= 128; aq++)
+  {
+    for (int ai = 0; ai <= 128; ai++)
+    {
+      const float t = (float)atan2((double)aq, (double)ai);
+      const uint32_t tb = bits(t);
+      ok = ok && tb < 0x40000000u;
+      if (aq <= 127 && ai <= 127)
+      {
+        ok = ok && tb == bits(lut[(aq + 128) * 256 + (ai + 128)]);          // i, q >= 0: the reference's entry itself
+      }
+      if (aq >= 1 && ai <= 127)
+      {
+        ok = ok && (tb ^ 0x80000000u) == bits(lut[(128 - aq) * 256 + (ai + 128)]);   // q < 0, i >= 0: the exact negation
+      }
+      int32_t fix = 0;
+      if (ai >= 1)
+      {
+        // i = -ai: the entry of q = +aq where it exists, else (q = -128) the negated one
+        const uint32_t target = (aq <= 127) ? bits(lut[(aq + 128) * 256 + (128 - ai)]) : (bits(lut[0 * 256 + (128 - ai)]) ^ 0x80000000u);
+        fix = (int32_t)(target - bits(pi_f - t));
+        ok = ok && fix >= -2 && fix <= 1;
+        if (aq >= 1 && aq <= 127)
+        {
+          ok = ok && (target ^ 0x80000000u) == bits(lut[(128 - aq) * 256 + (128 - ai)]);   // q < 0, i < 0: odd in q as well
+        }
+      }
+      out[aq * kQuadRow + ai] = tb | ((uint32_t)(fix & 3) << 30);
+    }
+  }
+  return ok;
+}
+
 static void build_dbfs(int32_t *out)
 {
   for (int i = 1; i <= 256; i++)
@@ -157,6 +205,8 @@ struct hrfd_rx
   uint8_t *d_atcorr2 = nullptr;        // first-octant table atan2 (theta_tab): correction bytes, T0
   float *d_att0 = nullptr;
   bool tab_ok = false;                 // its corrections fit: k_rx_wbfm_flow may run
+  uint32_t *d_atquad = nullptr;        // first-quadrant table with embedded corrections (theta_quad: the re-split WBFM flow kernel)
+  bool quad_ok = false;
   bool arith_ok = false;               // corrections fit: k_rx_wbfm computes theta instead of gathering it
   int atan_mode = -1;                  // test hook: -1 auto, 0 force the table gather, 1 require arithmetic
   int32_t *d_dbfs = nullptr;
@@ -219,7 +269,7 @@ static int rx_free(hrfd_rx *h)
   }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_atcorr2, h->d_att0, h->d_dbfs, h->d_counters,
+  void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_atcorr2, h->d_att0, h->d_atquad, h->d_dbfs, h->d_counters,
                   h->d_lists, h->d_sub_lists, h->d_chan, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
                   h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq, h->d_dbg};
   for (void *p : ptrs)
@@ -295,6 +345,7 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   ok = ok && alloc((void **)&h->d_atinv, sizeof(float) * kInvEntries);
   ok = ok && alloc((void **)&h->d_atcorr2, kCorrBytes);
   ok = ok && alloc((void **)&h->d_att0, sizeof(float) * kCorrBytes);
+  ok = ok && alloc((void **)&h->d_atquad, sizeof(uint32_t) * kQuadDwords);
   ok = ok && alloc((void **)&h->d_dbfs, sizeof(int32_t) * 257);
   ok = ok && alloc((void **)&h->d_counters, sizeof(uint32_t) * (kNumDevCounters + kCntSticky));
   ok = ok && alloc((void **)&h->d_lists, sizeof(uint32_t) * 10 * n_channels);
@@ -370,6 +421,11 @@ extern "C" int hrfd_rx_create(uint32_t n_channels, int device, hrfd_rx **out)
   }
   if (e == hipSuccess) e = hipMemcpy(&bad2, h->d_counters + kCntScratch, sizeof(bad2), hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemset(h->d_counters + kCntScratch, 0, sizeof(uint32_t));
+  {
+    std::vector<uint32_t> tq(kQuadDwords);
+    h->quad_ok = build_atan_quadrant(lut.data(), tq.data());
+    if (e == hipSuccess) e = hipMemcpy(h->d_atquad, tq.data(), sizeof(uint32_t) * kQuadDwords, hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess)
   {
     rc = fail(HRFD_ENODEV, "hrfd_rx_create: initial upload failed: %s", hipGetErrorString(e));
@@ -722,6 +778,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.at_inv = h->d_atinv;
   P.at_corr2 = h->d_atcorr2;
   P.at_t0 = h->d_att0;
+  P.at_quad = h->d_atquad;
   P.dbfs = h->d_dbfs;
   P.chk_pub = h->d_chk_pub;
   P.chk_spec = h->d_chk_spec;

@@ -40,6 +40,30 @@ extern "C" int hrfd_rx_debug_atan_eval_tab(hrfd_rx *h, float *out65536)
 {
   return atan_eval(h, out65536, true);
 }
+// ... and the first-quadrant table of the re-split flow kernel (theta_quad)
+extern "C" int hrfd_rx_debug_atan_eval_quad(hrfd_rx *h, float *out65536)
+{
+  if (h == nullptr || out65536 == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_atan_eval_quad: NULL");
+  }
+  if (!h->quad_ok)
+  {
+    return fail(HRFD_ESTATE, "hrfd_rx_debug_atan_eval_quad: the first-quadrant table did not verify against the reference table on this host");
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  float *d = nullptr;
+  HIP_TRY(hipMalloc((void **)&d, sizeof(float) * 65536));
+  hipLaunchKernelGGL(k_atan_eval_quad, dim3(256), dim3(256), 0, 0, h->d_atquad, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(out65536, d, sizeof(float) * 65536, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess)
+  {
+    return fail(HRFD_ENODEV, "hrfd_rx_debug_atan_eval_quad: %s", hipGetErrorString(e));
+  }
+  return HRFD_OK;
+}
 static int atan_eval(hrfd_rx *h, float *out65536, bool tab)
 {
   if (h == nullptr || out65536 == nullptr)
@@ -217,9 +241,9 @@ extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
 extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
 {
   HRFD_HOOK_GATE("hrfd_rx_debug_expire");
-  if (h == nullptr || where < 0 || (where > 7 && where < 1000) || where > 8063)
+  if (h == nullptr || where < 0 || (where > 11 && where < 1000) || where > 10063)
   {
-    return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 6");
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 11, or 1000 point + generation");
   }
   h->expire_once = where;
   return HRFD_OK;

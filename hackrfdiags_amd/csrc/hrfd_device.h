@@ -45,6 +45,9 @@ constexpr int kMaxNV = kMaxN256 + kMaxHal;    // floats of the v/y stream in LDS
 constexpr int kTriEntries = 129 * 130 / 2;    // (a, b) with 0 <= b <= a <= 128
 constexpr int kCorrBytes = 8448;              // kTriEntries padded to 16-byte copies
 constexpr int kInvEntries = 132;              // 1/a for a = 0..128 (entry 0 is 0), padded
+constexpr int kQuadRow = 129;                 // first-quadrant table (theta_quad): TQ[|q| * 129 + |i|], 0 <= |i|, |q| <= 128
+constexpr int kQuadEntries = 129 * 129;
+constexpr int kQuadDwords = 16644;            // padded to 16-byte copies
 
 // carried history sizes of the integer stages ("carried state")
 constexpr int kWbS = 4, kWbU = 8, kWbV = 38;  // WBFM: last N-M inputs of D(8,4), D(12,4), D(40,2)
@@ -162,6 +165,7 @@ struct RxParams
   const float *at_inv;
   const uint8_t *at_corr2;     // first-octant table atan2 (theta_tab, k_rx_wbfm_flow): correction bytes [kCorrBytes]
   const float *at_t0;          //   and T0 [kCorrBytes floats]
+  const uint32_t *at_quad;     // first-quadrant table with embedded corrections (theta_quad) [kQuadDwords]
   const int32_t *dbfs;         // [257]
   float *chk_pub;              // [C][n_blocks] y at (n256 - kHist + 59) of this block
   float *chk_spec;             // [C][n_blocks] y at (-kHist + 59) as speculated by this block

@@ -44,6 +44,20 @@
 #ifndef HRFD_FLOW_SVC_PRIO
 #define HRFD_FLOW_SVC_PRIO 3
 #endif
+// Round 5, the RE-SPLIT of the WBFM chain: the ring holds the mixed 256 kS/s samples as 16-bit (q, i)
+// pairs instead of the float v (a third of the LDS per sample), theta / wrap / numerator move from the stream waves to
+// the service waves, which keep a tile's v in REGISTERS through the partial sum, the warm-up passes and the tile
+// itself, and the freed LDS holds a first-QUADRANT atan2 table (theta_quad) and a ring of 512 tiles.
+// -DHRFD_FLOW_SPLIT=0 builds the round-4 kernel (the A/B of profiles/r5_flow_split_ab.txt).
+#ifndef HRFD_FLOW_SPLIT
+#define HRFD_FLOW_SPLIT 1
+#endif
+#ifndef HRFD_FLOW_SVC_WB
+#define HRFD_FLOW_SVC_WB 6          /* service waves of the re-split WBFM kernel (they do a third of the work now) */
+#endif
+#ifndef HRFD_FLOW_RING2
+#define HRFD_FLOW_RING2 512         /* its ring, in tiles of 64 samples (a power of two) */
+#endif
 // diagnostic build: -DHRFD_FLOW_PROBE accumulates, per stream wave, the cycles between the marks of its unit loop
 // (slots 24..31 of its workgroup's stamp row are summed over the waves; read with tools/gpu_flow_times.py)
 #ifdef HRFD_FLOW_PROBE
@@ -75,6 +89,11 @@ constexpr int kFUDw = 1024;                     // U ring: 2048 int16 = two gene
 constexpr int kFVDw = 256;                      // V ring: 512 int16 = two generations
 constexpr int kFEdges = 64;                     // per-unit records kept (>= kFRingTiles / kFUnitTiles + slack)
 constexpr int kFPRing = 512;                    // per-tile partial sums kept (eight generations)
+constexpr int kFRing2 = HRFD_FLOW_RING2;        // re-split WBFM: tiles of (q, i) pairs in the ring ...
+constexpr int kFStride2 = 36;                   // ... 32 dwords each, rows 36 apart: 16 lanes' ds_read_b128 fall into 64 different banks
+constexpr int kFEdges2 = 128;                   // ... and unit records (>= kFRing2 / kFUnitTiles + slack)
+static_assert((kFRing2 & (kFRing2 - 1)) == 0 && kFRing2 >= 128, "ring of the re-split kernel: a power of two");
+static_assert(kFRing2 / kFUnitTiles + 16 <= kFEdges2, "unit records must outlive the ring");
 static_assert(kFRingTiles == 256 || kFRingTiles == 320 || kFRingTiles == 384, "ring_slot knows these sizes");
 static_assert(kFRingTiles / kFUnitTiles + 16 <= kFEdges, "unit records must outlive the ring");
 
@@ -265,6 +284,68 @@ __device__ __forceinline__ void flow_tile_u(const uint32_t *tp, float y, FlowTil
   o.y = y;
 }
 
+// The same on a tile whose v the lane holds in REGISTERS (re-split kernel): a warm-up pass over the lane's own tile ...
+__device__ __forceinline__ float flow_warm_reg(const float (&v)[kFT], float y)
+{
+  const float a1 = DEEMPH_A1;
+#pragma unroll
+  for (int j = 0; j < kFT; j++)
+  {
+    const float r = a1 * y;
+    y = v[j] - r;
+  }
+  return y;
+}
+
+// ... and the tile proper (flow_tile_u on registers)
+template <bool FIX>
+__device__ __forceinline__ void flow_tile_reg(const float (&v)[kFT], float y, FlowTile &o)
+{
+  const float a1 = DEEMPH_A1;
+  uint32_t pa = 0, pb = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+  {
+    float r = a1 * y;
+    const float y0 = v[4 * i] - r;
+    r = a1 * y0;
+    const float y1 = v[4 * i + 1] - r;
+    r = a1 * y1;
+    const float y2 = v[4 * i + 2] - r;
+    r = a1 * y2;
+    y = v[4 * i + 3] - r;
+    const uint32_t sa = pack_s16<FIX>(y0, y1), sb = pack_s16<FIX>(y2, y);
+    if (i == 0)
+    {
+      o.sfirst0 = sa;
+      o.sfirst1 = sb;
+      o.ud[0] = 0u;
+    }
+    else
+    {
+      int acc = 1 << 14;
+      acc = dot2(pa, kRevWbD1.p[0], acc);
+      acc = dot2(pb, kRevWbD1.p[1], acc);
+      acc = dot2(sa, kRevWbD1.p[2], acc);
+      acc = dot2(sb, kRevWbD1.p[3], acc);
+      const uint32_t u16 = (uint32_t)q15_out(acc) & 0xffffu;
+      if (i & 1)
+      {
+        o.ud[i >> 1] = (i == 1) ? (u16 << 16) : (o.ud[i >> 1] | (u16 << 16));
+      }
+      else
+      {
+        o.ud[i >> 1] = u16;
+      }
+    }
+    pa = sa;
+    pb = sb;
+  }
+  o.slast0 = pa;
+  o.slast1 = pb;
+  o.y = y;
+}
+
 constexpr int kFinWords = 168;
 
 // GATED: the exact second pass over channels whose squelch gate closed inside the batch.  The batch launch (GATED ==
@@ -289,12 +370,17 @@ constexpr int kFinWords = 168;
 template <int MODE>
 struct FlowLds
 {
-  static constexpr bool kAtan = (MODE != 14);            // theta_tab: WBFM and FM
+  static constexpr bool kSplit = (MODE == 3) && (HRFD_FLOW_SPLIT != 0);   // the re-split WBFM chain (round 5)
+  static constexpr bool kAtan = (MODE != 14) && !kSplit;   // theta_tab: FM, and the round-4 WBFM build
   static constexpr int kRails = (MODE == 14) ? 2 : 1;    // AM / SSB keep both rails through all three decimators
   static constexpr int kVDw = (MODE == 14) ? 2 * kFVDw : kFVDw;   // V ring per rail (AM / SSB: four generations, fir service c)
   static constexpr int k8k = (MODE == 14) ? 512 : 4;     // AM / SSB: int16 per rail of the 8 kS/s rings (four generations)
-  static constexpr int oRing = 0;
-  static constexpr int oAtcorr = oRing + kFRingTiles * kFStride;
+  static constexpr int kRingTiles = kSplit ? kFRing2 : kFRingTiles;
+  static constexpr int kStride = kSplit ? kFStride2 : kFStride;
+  static constexpr int kEdges = kSplit ? kFEdges2 : kFEdges;
+  static constexpr int oTq = 0;                          // re-split: the first-quadrant table FIRST (its index is the LDS address)
+  static constexpr int oRing = kSplit ? kQuadDwords : 0;
+  static constexpr int oAtcorr = oRing + kRingTiles * kStride;
   static constexpr int oAtt0 = oAtcorr + (kAtan ? kCorrBytes / 4 : 4);
   static constexpr int oUring = oAtt0 + (kAtan ? kCorrBytes : 4);
   static constexpr int oVring = oUring + kRails * kFUDw;
@@ -304,22 +390,27 @@ struct FlowLds
   static constexpr int oRcar = oYs + ((MODE == 14) ? 128 : 4);
   static constexpr int oThfin = oRcar + 4;
   static constexpr int oEdges = oThfin + 4;
-  static constexpr int oUflag = oEdges + 4 * kFEdges;
-  static constexpr int oParr = oUflag + kFEdges;
+  static constexpr int oUflag = oEdges + (kSplit ? 4 : 4 * kEdges);   // (the re-split kernel has no unit edges)
+  static constexpr int oParr = oUflag + kEdges;
   static constexpr int oPflag = oParr + kFPRing;
   static constexpr int oCtl = oPflag + 8;
-  static constexpr int oMagl = oCtl + 24;
+  static constexpr int oMagl = oCtl + 32;
   static constexpr int oDbfs = oMagl + 16 * 64;
   static constexpr int oBlkout = oDbfs + 32;
   static constexpr int oWfin = oBlkout + 64;
   static constexpr int oFinl = oWfin + 4;
   static constexpr int oBlist = oFinl + kFinWords;
   static constexpr int oGctl = oBlist + 16;
-  static constexpr int kTotal = oGctl + 4;
+  static constexpr int oLastdw = oGctl + 4;               // re-split: per generation, the last ring word of its last tile (two samples)
+  static constexpr int oWcar = oLastdw + 8;               // ... per warm-up pass and generation: y of its last lane at the end of the pass
+  static constexpr int oWflag = oWcar + 4 * 8;            // ... and the flags of those
+  static constexpr int kTotal = oWflag + 4 * 8;
   static_assert(kTotal * 4 <= 163840, "LDS");
-  static_assert((oAtcorr % 4) == 0 && (oAtt0 % 4) == 0 && (oUring % 4) == 0 && (oVring % 4) == 0 && (oXs % 4) == 0 && (oYs % 4) == 0 &&
+  static_assert((oRing % 4) == 0 && (oAtcorr % 4) == 0 && (oAtt0 % 4) == 0 && (oUring % 4) == 0 && (oVring % 4) == 0 && (oXs % 4) == 0 && (oYs % 4) == 0 &&
                 (kFinWords % 4) == 0, "16-byte alignment of what is accessed as 128-bit words");
 };
+constexpr int kCtlRel = 24;                     // ctl[]: re-split, generations whose ring rows have been read (released to the stream waves)
+constexpr int kCtlTab = 25;                     // ... service waves that have copied their share of the table
 
 // The flow kernel as an object: what the sections below share -- the workgroup's LDS arrays, the channel, the run's
 // geometry, the carried state, the failure code -- are its members, set once by setup(); the sections are member
@@ -337,6 +428,7 @@ struct Flow
   static_assert(MODE == 3 || MODE == 2 || MODE == 14, "WBFM, FM, AM / SSB");
   typedef FlowLds<MODE> Lds;
   static constexpr bool kWb = (MODE == 3);
+  static constexpr bool kSplit = Lds::kSplit;            // WBFM, re-split (round 5): (q, i) pairs in the ring, theta in the service waves
   static constexpr bool kAtan = Lds::kAtan;
   static constexpr int kRails = Lds::kRails;
   static constexpr int kVDw = Lds::kVDw;
@@ -360,6 +452,8 @@ struct Flow
   uint32_t *blkout, *wfin, *finl;
   uint8_t *blist;
   uint32_t *gctl;
+  uint32_t *tquad, *lastdw, *wflag;
+  float *wcar;
   // the workgroup's place: channel, run, lane
   uint32_t ci, run, c;
   int n256, tid, lane, wave;
@@ -410,6 +504,10 @@ struct Flow
                                              // section, 160 tracking, 161 poison, 162..165 the pending fe_tail
     blist = reinterpret_cast<uint8_t *>(lds + Lds::oBlist);   // GATED: the blocks of the stream, in order (the allowed ones)
     gctl = lds + Lds::oGctl;                  // GATED: 0 number of allowed blocks, 1 `present` of the call's last block; AM / SSB: 2 generations through their 8 kS/s part
+    tquad = lds + Lds::oTq;                   // re-split: the first-quadrant atan2 table (theta_quad), copied by the service waves
+    lastdw = lds + Lds::oLastdw;              // ... [8] per generation: the last ring word of its last tile
+    wcar = reinterpret_cast<float *>(lds + Lds::oWcar);   // ... [4][8] per warm-up pass and generation: its last lane's y behind the pass
+    wflag = lds + Lds::oWflag;                // ... [4][8] generation + 1 when that value is there
 
     if (!map_unit(blockIdx.x, P.n_list, P.n_runs, ci, run))
     {
@@ -497,11 +595,11 @@ struct Flow
     {
       reinterpret_cast<uint4 *>(atcorr)[tid] = reinterpret_cast<const uint4 *>(P.at_corr2)[tid];
     }
-    else if (tid >= 640 && tid < 640 + kFEdges)
+    else if (tid >= 640 && tid < 640 + Lds::kEdges)
     {
       uflag[tid - 640] = 0u;
     }
-    else if (tid >= 768 && tid < 792)
+    else if (tid >= 768 && tid < 800)
     {
       ctl[tid - 768] = 0u;
     }
@@ -528,6 +626,10 @@ struct Flow
     {
       finl[160] = st->tracking;
       finl[161] = P.fin.chan_poison[c];
+    }
+    else if (kSplit && tid >= 980 && tid < 1012)
+    {
+      wflag[tid - 980] = 0u;
     }
     else if (tid >= 908 && tid < 912 && (GATED || b_end == P.n_blocks))
     {
@@ -721,8 +823,9 @@ struct Flow
       tail_in[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t *>(st->fe_tail)[i]);
     }
     // lane constant: where this lane's four samples of a piece go (tile lane / 16 of the piece, 4 (lane % 16) inside)
-    const int lane_dw = kWb ? kFStride * (lane >> 4) + ((4 * lane) & 63)    // one dword per sample
-                            : kFStride * (lane >> 4) + ((2 * lane) & 31);   // FIR modes: one dword per PAIR, I rail at 0, Q rail at 32
+    const int lane_dw = kSplit ? kFStride2 * (lane >> 4) + ((2 * lane) & 31)   // re-split: one dword per PAIR of samples, bytes i0 q0 i1 q1
+                        : kWb  ? kFStride * (lane >> 4) + ((4 * lane) & 63)    // one dword per sample
+                               : kFStride * (lane >> 4) + ((2 * lane) & 31);   // FIR modes: one dword per PAIR, I rail at 0, Q rail at 32
     int bu0 = hal >> 9, blk = 0;                         // first unit and index (in the run) of the block a unit belongs to
     unsigned long long probe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
     (void)probe; (void)tprev;
@@ -784,7 +887,7 @@ struct Flow
     while (u < n_units)
     {
       FLOW_MARK(0)
-      const uint32_t done_seen = lds_ld(&ctl[1]);
+      const uint32_t done_seen = lds_ld(&ctl[kSplit ? kCtlRel : 1]);
       FLOW_MARK(1)
       QuadCarry cy;
       // (DUMP: the two dump stores of a unit stand among the loads, in order: c16' qa' st0 qb' st1 -- behind c16' are 10
@@ -810,11 +913,14 @@ struct Flow
       cy.p = (first && u == 0) ? p_in : 0u;
       FLOW_MARK(2)
       // ring space: the tiles this unit overwrites must not be anybody's warm-up any more
-      if (!(HRFD_ABLATE & (1024 | 2048)) && 8 * u + 8 + wt > 64 * (int)done_seen + kFRingTiles)   // (1024: TIMING EXPERIMENT ONLY, stream waves alone)
+      // (re-split: a generation's rows are free as soon as its service wave has READ them -- kCtlRel -- and nobody reads
+      //  a row twice: no slack for warm-ups)
+      const int ring_slack = kSplit ? 0 : wt;
+      if (!(HRFD_ABLATE & (1024 | 2048)) && 8 * u + 8 + ring_slack > 64 * (int)done_seen + Lds::kRingTiles)   // (1024: TIMING EXPERIMENT ONLY, stream waves alone)
       {
         const unsigned long long t0 = __builtin_readcyclecounter();
         FlowSpin sp;
-        while (8 * u + 8 + wt > 64 * (int)lds_ld(&ctl[1]) + kFRingTiles && !sp.expired(P, ctl, fail_code, 1))
+        while (8 * u + 8 + ring_slack > 64 * (int)lds_ld(&ctl[kSplit ? kCtlRel : 1]) + Lds::kRingTiles && !sp.expired(P, ctl, fail_code, 1))
         {
           __builtin_amdgcn_s_sleep(8);
         }
@@ -827,8 +933,8 @@ struct Flow
       finish_block();                                    // of the previous unit
       FLOW_MARK(3)
       // (uniform, and said so: left to itself the compiler computes the row offset per lane with a quarter-rate v_mul_lo_u32)
-      const int slot0 = __builtin_amdgcn_readfirstlane(ring_slot(8 * u));   // NT is a multiple of 8: a unit never wraps
-      uint32_t *dst = ring + slot0 * kFStride + lane_dw;
+      const int slot0 = __builtin_amdgcn_readfirstlane(kSplit ? ((8 * u) & (kFRing2 - 1)) : ring_slot(8 * u));   // NT is a multiple of 8: a unit never wraps
+      uint32_t *dst = ring + slot0 * Lds::kStride + lane_dw;
       uint32_t v[4], mag4, magsum;
       uint32_t iqb[2] = {0u, 0u};
       float theta[4];
@@ -884,7 +990,26 @@ struct Flow
         reinterpret_cast<uint2 *>(d + 32)[0] = make_uint2(q01, q23);
         mag4 = magnitude(mx[0]) + magnitude(mx[1]) + magnitude(mx[2]) + magnitude(mx[3]);
       };
-      if (kWb)
+      // re-split WBFM: the lane's four mixed samples as two ring words (bytes i0 q0 i1 q1, offset binary), one 8-byte store
+      auto store_pairs = [&](const uint32_t (&mx)[4], uint32_t *d) {
+        const uint32_t w0 = __builtin_amdgcn_perm(mx[1], mx[0], 0x06040200u), w1 = __builtin_amdgcn_perm(mx[3], mx[2], 0x06040200u);
+        reinterpret_cast<uint2 *>(d)[0] = make_uint2(w0, w1);
+        mag4 = magnitude(mx[0]) + magnitude(mx[1]) + magnitude(mx[2]) + magnitude(mx[3]);
+        if (DUMP)
+        {
+          iqb[0] = w0 ^ 0x80808080u;
+          iqb[1] = w1 ^ 0x80808080u;
+        }
+      };
+      if (kSplit)
+      {
+        const uint4 ra[4] = {make_uint4(qa[0].x, qa[0].y, qa[0].z, qa[0].w), make_uint4(qa[1].x, qa[1].y, qa[1].z, qa[1].w),
+                             make_uint4(qa[2].x, qa[2].y, qa[2].z, qa[2].w), make_uint4(qa[3].x, qa[3].y, qa[3].z, qa[3].w)};
+        uint32_t mx[4];
+        quad_front(ra, cy.fe, mx, refill_a);
+        store_pairs(mx, dst);
+      }
+      else if (kWb)
       {
         const uint4 ra[4] = {make_uint4(qa[0].x, qa[0].y, qa[0].z, qa[0].w), make_uint4(qa[1].x, qa[1].y, qa[1].z, qa[1].w),
                              make_uint4(qa[2].x, qa[2].y, qa[2].z, qa[2].w), make_uint4(qa[3].x, qa[3].y, qa[3].z, qa[3].w)};
@@ -911,7 +1036,7 @@ struct Flow
       }
       magsum = mag4;
       uint32_t e0 = 0u, e1 = 0u, e2 = 0u, e3 = 0u;
-      if (kWb)
+      if (kWb && !kSplit)
       {
         e0 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[0]), 0);
         e1 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[1]), 0);
@@ -927,7 +1052,15 @@ struct Flow
         VM_WAIT(5, "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
       }
       auto refill_b = [&](const uint32_t (&y1)[4][4]) { load_piece(qb, uoff_n, 1, un < n_units, y1); };
-      if (kWb)
+      if (kSplit)
+      {
+        const uint4 rb[4] = {make_uint4(qb[0].x, qb[0].y, qb[0].z, qb[0].w), make_uint4(qb[1].x, qb[1].y, qb[1].z, qb[1].w),
+                             make_uint4(qb[2].x, qb[2].y, qb[2].z, qb[2].w), make_uint4(qb[3].x, qb[3].y, qb[3].z, qb[3].w)};
+        uint32_t mx[4];
+        quad_front(rb, cy.fe, mx, refill_b);
+        store_pairs(mx, dst + 4 * kFStride2);
+      }
+      else if (kWb)
       {
         const uint4 rb[4] = {make_uint4(qb[0].x, qb[0].y, qb[0].z, qb[0].w), make_uint4(qb[1].x, qb[1].y, qb[1].z, qb[1].w),
                              make_uint4(qb[2].x, qb[2].y, qb[2].z, qb[2].w), make_uint4(qb[3].x, qb[3].y, qb[3].z, qb[3].w)};
@@ -953,13 +1086,13 @@ struct Flow
         store_dump(iqb, u, 1);
       }
       magsum += mag4;
-      if (kWb)
+      if (kWb && !kSplit)
       {
         e2 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[2]), 63);
         e3 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[3]), 63);
       }
       FLOW_MARK(6)
-      if (kWb && lane < 4)
+      if (kWb && !kSplit && lane < 4)
       {
         edges[u & (kFEdges - 1)][lane] = (lane == 0) ? e0 : (lane == 1) ? e1 : (lane == 2) ? e2 : e3;
       }
@@ -981,7 +1114,7 @@ struct Flow
       pend_nth = 0u;
       if (lane == 0)
       {
-        lds_st(&uflag[u & (kFEdges - 1)], (uint32_t)u + 1u);
+        lds_st(&uflag[u & (Lds::kEdges - 1)], (uint32_t)u + 1u);
         if (counted)
         {
           lds_add_async(pend_nth, &ctl[8 + slot], 1u);
@@ -1926,6 +2059,514 @@ struct Flow
     }
   }
 
+  // --------------------------------------------------------------- service waves, WBFM, re-split (round 5)
+  __device__ __forceinline__ void service_waves_wbfm2()
+  {
+    // =================================================================== service waves: (q, i) pairs -> PCM
+    // A generation is 64 tiles, one per lane, as in service_waves_wbfm -- but the lane makes its tile's v ITSELF, from the
+    // ring's (q, i) pairs (theta_quad, wrap, gain, the FIR half of the de-emphasis filter: WbFmDemodulator.cc:404-430,
+    // IirFilter.cc:161-176), and keeps the 64 floats in REGISTERS through everything that reads them:
+    //   the geometric partial sum; `wt` WARM-UP PASSES over the lane's OWN tile -- pass k starts from the value the LEFT
+    //   lane's pass k - 1 ended with (one DPP hop; lane 0 takes the last lane of the generation in front from wcar[]),
+    //   pass 0 from the seed at the end of the tile in front: after wt hops lane l starts its tile from exactly the value
+    //   the round-4 kernel computed by running tiles l - wt .. l - 1 itself out of the ring -- the same operations on the
+    //   same operands, so the same bits, the same verification and the same (rare) repairs -- and then the tile proper.
+    // The ring's rows are read ONCE, in generation order, and handed back to the stream waves at once (kCtlRel).
+    // (the per-generation records -- lastdw, wcar / wflag, parr, pflag -- have eight slots: at most SVC generations are
+    //  in flight, consecutive ones, because a generation completes only behind the one in front: verification order)
+    static_assert(SVC <= 7, "per-generation records of the re-split service waves");
+    __builtin_amdgcn_s_setprio(HRFD_FLOW_SVC_PRIO);
+    const float a1 = DEEMPH_A1;
+    const int fa_t = first ? 0 : (wt + M);               // first tile that can be started properly
+    const uint32_t pcm_off = (uint32_t)(hal >> 5);       // PCM samples that the history in front would yield
+    uint32_t *pcm32 = reinterpret_cast<uint32_t *>(P.pcm + ((size_t)c * P.out_blocks + P.out_b0 + b_first) * (size_t)(n256 >> 5));
+    uint32_t repairs = 0;
+    unsigned long long sprobe[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_readcyclecounter();
+    (void)sprobe; (void)sprev;
+    // the carried state of a stream that continues the previous call (requested before the table: one round trip)
+    const float y_in = st->wb_y, theta_in = st->wb_theta, p_in = st->wb_p;
+    // The table comes into LDS through the service waves while the stream waves already run (they do not need it):
+    // 66 KB per workgroup that the round-4 kernel loaded in front of everything.
+    {
+      const uint4 *src = reinterpret_cast<const uint4 *>(P.at_quad);
+      uint4 *dstq = reinterpret_cast<uint4 *>(tquad);
+      for (int i = tid; i < kQuadDwords / 4; i += 64 * SVC)
+      {
+        dstq[i] = src[i];
+      }
+      if (lane == 0)
+      {
+        atomicAdd(&ctl[kCtlTab], 1u);                    // (LDS runs a wave's operations in order: behind its copies)
+      }
+      FlowSpin sp;
+      while (lds_ld(&ctl[kCtlTab]) != (uint32_t)SVC && !sp.expired(P, ctl, fail_code, 9))
+      {
+        __builtin_amdgcn_s_sleep(2);
+      }
+      lds_order();
+    }
+    FLOW_TIME_SET(43)
+    auto grab_gen = [&]() -> int {
+      uint32_t v = 0;
+      if (lane == 0)
+      {
+        v = atomicAdd(&ctl[4], 1u);
+      }
+      return __builtin_amdgcn_readfirstlane((int)v);
+    };
+    float th_last = 0.0f, p_last = 0.0f;                 // theta and b0*x of the lane's last sample (the carried state at the end)
+    for (int g = grab_gen(); g < n_gens && fail_code == 0u && !(HRFD_ABLATE & 1024); g = grab_gen())
+    {
+      SVC_MARK(0)
+      const int t0 = 64 * g;
+      const int ntl = min(64, n_tiles - t0);             // tiles of this generation (a multiple of 8)
+      const int t = t0 + lane;
+      const bool have = lane < ntl;
+      // 1. the generation's units are in the ring ...
+      {
+        const int ulo = 8 * g, uhi = 8 * g + (ntl >> 3);
+        const int uu = ulo + lane;
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+        FlowSpin sp;
+        for (;;)
+        {
+          const bool ok = (uu >= uhi) || lds_ld(&uflag[uu & (kFEdges2 - 1)]) == (uint32_t)uu + 1u;
+          if (__all(ok) || sp.expired(P, ctl, fail_code, 3))
+          {
+            break;
+          }
+          __builtin_amdgcn_s_sleep(6);
+        }
+        // ... and the generation in front has read its rows (they are read in order: lastdw[] of it is there)
+        while (lds_ld(&ctl[kCtlRel]) != (uint32_t)g && !sp.expired(P, ctl, fail_code, 10))
+        {
+          __builtin_amdgcn_s_sleep(2);
+        }
+        waited += __builtin_readcyclecounter() - tw0;
+        lds_order();
+      }
+      if (fail_code != 0u)
+      {
+        break;                                           // the workgroup is aborting (FlowSpin): the channel will be replayed
+      }
+      SVC_MARK(1)
+      // 2. the tile's 64 samples (32 ring words) and the two in front of it -> v[64] in registers
+      float v[kFT];
+      {
+        const uint32_t *tp = ring + (t & (kFRing2 - 1)) * kFStride2;
+        const uint32_t *pp_ = (lane == 0) ? &lastdw[(g - 1) & 7] : ring + ((t - 1) & (kFRing2 - 1)) * kFStride2 + 31;
+        uint4 row[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+        {
+          row[j] = reinterpret_cast<const uint4 *>(tp)[j];
+        }
+        uint32_t prevw = *pp_;                           // (generation 0, lane 0: whatever is there -- replaced below or history)
+        // the rows go back to the stream waves: LDS has executed this wave's reads when it executes the flag's store
+        const uint32_t lastw = (uint32_t)__builtin_amdgcn_readlane((int)row[7].w, ntl - 1);
+        if (lane == 0)
+        {
+          lds_st(&lastdw[g & 7], lastw);
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0)
+        {
+          lds_st(&ctl[kCtlRel], (uint32_t)g + 1u);
+        }
+        flow_hold_up(P, 9, g);
+        float thp, pp;
+        {
+          const uint32_t x = prevw ^ 0x80808080u, a = abs4_s8(x);
+          const float tm2 = theta_quad<0>(x, a, tquad), tm1 = theta_quad<1>(x, a, tquad);
+          thp = tm1;
+          pp = numerator_p<true>(tm1, tm2, kgain);
+          if (t == 0)
+          {
+            // the stream's first sample: theta and b0*x in front of it are the carried ones when the stream continues the
+            // previous call; a run that re-derives its history starts it from zeros (on silent input that IS the truth:
+            // a transient there would never die away bit for bit and fail the cross-run check)
+            thp = first ? theta_in : 0.0f;
+            pp = first ? p_in : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+        {
+          const uint32_t w4[4] = {row[j].x, row[j].y, row[j].z, row[j].w};
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            const uint32_t x = w4[k] ^ 0x80808080u, a = abs4_s8(x);
+            const float th0 = theta_quad<0>(x, a, tquad), th1 = theta_quad<1>(x, a, tquad);
+            const float p0 = numerator_p<true>(th0, thp, kgain);
+            const float p1 = numerator_p<true>(th1, th0, kgain);
+            v[8 * j + 2 * k] = p0 + pp;
+            v[8 * j + 2 * k + 1] = p1 + p0;
+            thp = th1;
+            pp = p1;
+          }
+        }
+        th_last = thp;
+        p_last = pp;
+      }
+      SVC_MARK(2)
+      // 3. geometric partial sum of v over the own tile: P = sum_k c^k v[63 - k], c = -a1 (approximate on purpose)
+      if (have && M > 0)
+      {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const float cc = -a1, c2 = cc * cc;
+        const f32x2 c22 = {c2, c2};
+        f32x2 pab = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < kFT / 2; j++)
+        {
+          const f32x2 vv = {v[2 * j], v[2 * j + 1]};
+          pab = __builtin_elementwise_fma(pab, c22, vv);
+        }
+        float p = __builtin_fmaf(pab.x, cc, pab.y);
+        if (first && t == 0)
+        {
+          p += deemph_pow(kFT) * y_in;                   // the stream's past, as seen from the end of tile 0
+        }
+        parr[t & (kFPRing - 1)] = p;
+      }
+      lds_order();
+      if (lane == 0)
+      {
+        lds_st(&pflag[g & 7], (uint32_t)g + 1u);
+      }
+      flow_hold_up(P, 4, g);
+      SVC_MARK(3)
+      if (g > 0 && M > 0)
+      {
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+        FlowSpin sp;
+        while (lds_ld(&pflag[(g - 1) & 7]) != (uint32_t)g && !sp.expired(P, ctl, fail_code, 4))
+        {
+          __builtin_amdgcn_s_sleep(4);
+        }
+        waited += __builtin_readcyclecounter() - tw0;
+        lds_order();
+        if (fail_code != 0u)
+        {
+          break;
+        }
+      }
+      SVC_MARK(4)
+      // 4. seed, warm-up passes, tile
+      const bool active = have && t >= fa_t;
+      const bool exact0 = first && t == 0;               // the stream starts here: every pass starts from the carried y
+      FlowTile o;
+      o.y = 0.0f;
+      o.sfirst0 = o.sfirst1 = o.slast0 = o.slast1 = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+      {
+        o.ud[i] = 0u;
+      }
+      float y_spec = 0.0f;
+      {
+        // y at the end of tile t - 1: sum_m (c^64)^(m-1) P[t - m], oldest first
+        float y = 0.0f;
+        if (M > 0)
+        {
+          float acc = 0.0f;
+          for (int m = M; m >= 1; m--)
+          {
+            const int idx = t - m;
+            const float pv = (idx >= 0) ? parr[idx & (kFPRing - 1)] : 0.0f;
+            acc = __builtin_fmaf(acc, P.flow_seed_ct, pv);
+          }
+          y = acc;
+        }
+        y = exact0 ? y_in : y;
+        for (int k = 0; k < wt; k++)
+        {
+          const float ye = flow_warm_reg(v, y);          // the lane's tile, from the start this pass was given
+          // the last lane's value for lane 0 of the next generation, that generation's for ours
+          if (ntl == 64 && lane == 63)
+          {
+            wcar[8 * k + (g & 7)] = ye;
+          }
+          asm volatile("" ::: "memory");
+          if (ntl == 64 && lane == 63)
+          {
+            lds_st(&wflag[8 * k + (g & 7)], (uint32_t)g + 1u);
+          }
+          flow_hold_up(P, 10, g);
+          float carry = 0.0f;
+          if (g > 0)
+          {
+            const unsigned long long tw0 = __builtin_readcyclecounter();
+            FlowSpin sp;
+            while (lds_ld(&wflag[8 * k + ((g - 1) & 7)]) != (uint32_t)g && !sp.expired(P, ctl, fail_code, 11))
+            {
+              __builtin_amdgcn_s_sleep(2);
+            }
+            waited += __builtin_readcyclecounter() - tw0;
+            lds_order();
+            carry = wcar[8 * k + ((g - 1) & 7)];
+          }
+          y = u2f(shr1(f2u(ye), f2u(carry)));
+          y = exact0 ? y_in : y;
+        }
+        y_spec = y;
+        if (active && fail_code == 0u)
+        {
+          if (small_y)
+          {
+            flow_tile_reg<false>(v, y, o);
+          }
+          else
+          {
+            flow_tile_reg<true>(v, y, o);
+          }
+        }
+      }
+      if (fail_code != 0u)
+      {
+        break;
+      }
+      SVC_MARK(5)
+      // 5. generations are verified in order ...
+      {
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+        FlowSpin sp;
+        while (lds_ld(&ctl[1]) != (uint32_t)g && !sp.expired(P, ctl, fail_code, 5))
+        {
+          __builtin_amdgcn_s_sleep(2);
+        }
+        waited += __builtin_readcyclecounter() - tw0;
+        lds_order();
+      }
+      if (fail_code != 0u)
+      {
+        break;
+      }
+      SVC_MARK(6)
+      const uint32_t left_y = wfin[0], left_s0 = wfin[1], left_s1 = wfin[2];
+      // 6. every lane but the first runnable one checks its speculated start against its left neighbour's end;
+      //    a tile that has not merged is re-run from the true value, ascending (rare; v is still in the lane's registers)
+      {
+        const float y_left = u2f(shr1(f2u(o.y), left_y));
+        const bool bad = active && t > fa_t && !same_trajectory(y_left, y_spec);
+        unsigned long long bm = __ballot(bad);
+        while (bm != 0ull)
+        {
+          const int l = __ffsll((long long)bm) - 1;      // wave-uniform
+          bm &= ~(1ull << l);
+          repairs++;
+          const float y_true = u2f(shr1(f2u(o.y), left_y));
+          if (lane == l)
+          {
+            if (small_y)
+            {
+              flow_tile_reg<false>(v, y_true, o);
+            }
+            else
+            {
+              flow_tile_reg<true>(v, y_true, o);
+            }
+          }
+          // the right neighbour's speculation must now match the corrected final y
+          const float y_new_left = u2f(shr1(f2u(o.y), left_y));
+          const bool bad2 = (lane == l + 1) && active && !same_trajectory(y_new_left, y_spec);
+          bm |= __ballot(bad2);
+        }
+      }
+      // ... and hand their last lane's end to the next one at once
+      const uint32_t fy = (uint32_t)__builtin_amdgcn_readlane((int)f2u(o.y), ntl - 1);
+      const uint32_t fs0 = (uint32_t)__builtin_amdgcn_readlane((int)o.slast0, ntl - 1);
+      const uint32_t fs1 = (uint32_t)__builtin_amdgcn_readlane((int)o.slast1, ntl - 1);
+      if (lane == 0)
+      {
+        wfin[0] = fy;
+        wfin[1] = fs0;
+        wfin[2] = fs1;
+      }
+      asm volatile("" ::: "memory");
+      if (lane == 0)
+      {
+        lds_st(&ctl[1], (uint32_t)g + 1u);
+      }
+      flow_hold_up(P, 5, g);
+      // the integer stages follow in a chain of their own
+      {
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+        FlowSpin sp;
+        while (lds_ld(&ctl[2]) != (uint32_t)g && !sp.expired(P, ctl, fail_code, 6))
+        {
+          __builtin_amdgcn_s_sleep(2);
+        }
+        waited += __builtin_readcyclecounter() - tw0;
+        lds_order();
+      }
+      if (fail_code != 0u)
+      {
+        break;
+      }
+      // 7. U[0] of every tile: S[-4 .. -1] are the LEFT lane's last four samples (its final ones)
+      {
+        const uint32_t ls0 = shr1(o.slast0, left_s0), ls1 = shr1(o.slast1, left_s1);
+        int acc = 1 << 14;
+        acc = dot2(ls0, kRevWbD1.p[0], acc);
+        acc = dot2(ls1, kRevWbD1.p[1], acc);
+        acc = dot2(o.sfirst0, kRevWbD1.p[2], acc);
+        acc = dot2(o.sfirst1, kRevWbD1.p[3], acc);
+        o.ud[0] = (o.ud[0] & 0xffff0000u) | ((uint32_t)q15_out(acc) & 0xffffu);
+      }
+      if (have)
+      {
+        uint4 *up = reinterpret_cast<uint4 *>(uring + ((8 * t) & (kFUDw - 1)));
+        up[0] = make_uint4(o.ud[0], o.ud[1], o.ud[2], o.ud[3]);
+        up[1] = make_uint4(o.ud[4], o.ud[5], o.ud[6], o.ud[7]);
+      }
+      SVC_MARK(7)
+      // 8. V[k] = D(12,4)(U), two per lane and pass (WbFmDemodulator.cc:478-486)
+      for (int i = lane; i < 2 * ntl; i += 64)
+      {
+        const int k = 256 * g + 2 * i;                   // even
+        const uint4 ua = *reinterpret_cast<const uint4 *>(uring + ((2 * k - 4) & (kFUDw - 1)));
+        const uint4 ub = *reinterpret_cast<const uint4 *>(uring + ((2 * k) & (kFUDw - 1)));
+        const uint32_t uu[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};   // U[4k-8 .. 4k+7]
+        int acc0 = 1 << 14, acc1 = 1 << 14;
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+        {
+          acc0 = dot2(uu[j], kRevD12.p[j], acc0);
+          acc1 = dot2(uu[j + 2], kRevD12.p[j], acc1);
+        }
+        vring[(k >> 1) & (kFVDw - 1)] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+      }
+      // 9. PCM[p] = D(40,2)(V), two per lane (WbFmDemodulator.cc:488-496)
+      if (have)
+      {
+        const int pp = 128 * g + 2 * lane;               // even; V[2pp-38 .. 2pp+3] = dwords pp-19 .. pp+1
+        int acc0 = 1 << 14, acc1 = 1 << 14;
+        uint32_t prev = vring[(pp - 19) & (kFVDw - 1)];
+#pragma unroll
+        for (int j = 0; j < 20; j++)
+        {
+          const uint32_t next = vring[(pp - 18 + j) & (kFVDw - 1)];
+          acc0 = dot2(prev, kRevD40.p[j], acc0);
+          acc1 = dot2(next, kRevD40.p[j], acc1);
+          prev = next;
+        }
+        if (GATED)
+        {
+          // the stream is a list of blocks: PCM pair pp / 2 of the stream is pair (pp mod npcm) / 2 of block blist[pp / npcm]
+          const uint32_t npcm = (uint32_t)n256 >> 5;
+          const uint32_t k = (uint32_t)pp / npcm;
+          pcm32[((uint32_t)blist[k & 63u] * npcm + ((uint32_t)pp - k * npcm)) >> 1] =
+              ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+        }
+        else if ((uint32_t)pp >= pcm_off)
+        {
+          pcm32[((uint32_t)pp - pcm_off) >> 1] = ((uint32_t)q15_out(acc0) & 0xffffu) | ((uint32_t)q15_out(acc1) << 16);
+        }
+      }
+      SVC_MARK(8)
+      // 10. cross-block check values: y at block-relative position -705 = the end of the tile [-768, -704)
+      //     (GATED: one exact stream from the committed state, nothing to check)
+      if (have && !GATED)
+      {
+        const int x = 64 * t + 768 - hal;                // = (number of blocks completed) * n256 when this is such a tile
+        if (x >= 0)
+        {
+          const int q = x / n256;
+          if (q * n256 == x)
+          {
+            const uint32_t b = b_first + (uint32_t)q;    // the block this value stands in front of
+            if (q == 0)
+            {
+              P.chk_spec[(size_t)c * P.n_blocks + b] = o.y;   // speculated by this run (b_first > 0)
+            }
+            else
+            {
+              P.chk_pub[(size_t)c * P.n_blocks + b - 1] = o.y;
+              if (b < b_end)
+              {
+                P.chk_spec[(size_t)c * P.n_blocks + b] = o.y;
+                if (local)
+                {
+                  lds_st(&finl[b & 63u], f2u(o.y));
+                }
+              }
+            }
+          }
+        }
+      }
+      // 11. hand over to the next generation
+      {
+        if (g + 1 == n_gens && (GATED || b_end == P.n_blocks))
+        {
+          // the carried state for the next call (pending: committed when the launch verified clean)
+          const uint32_t thl = (uint32_t)__builtin_amdgcn_readlane((int)f2u(th_last), ntl - 1);
+          const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)f2u(p_last), ntl - 1);
+          if (lane == 0)
+          {
+            so->wb_y = u2f(fy);
+            so->wb_theta = u2f(thl);
+            so->wb_p = u2f(pl);
+            reinterpret_cast<uint32_t *>(so->wb_s)[0] = fs0;
+            reinterpret_cast<uint32_t *>(so->wb_s)[1] = fs1;
+          }
+          if (lane < 4)
+          {
+            reinterpret_cast<uint32_t *>(so->wb_u)[lane] = uring[(8 * n_tiles - 4 + lane) & (kFUDw - 1)];
+          }
+          if (lane < 19)
+          {
+            reinterpret_cast<uint32_t *>(so->wb_v)[lane] = vring[(2 * n_tiles - 19 + lane) & (kFVDw - 1)];
+          }
+          if (local)
+          {
+            // the same section in ChanState's order, dwords from wb_theta on: theta, p, y, pad, s (2), u (4), v (20)
+            if (lane == 0)
+            {
+              lds_st(&finl[128], thl);
+              lds_st(&finl[129], pl);
+              lds_st(&finl[130], fy);
+              lds_st(&finl[131], 0u);
+              lds_st(&finl[132], fs0);
+              lds_st(&finl[133], fs1);
+            }
+            if (lane < 4)
+            {
+              lds_st(&finl[134 + lane], uring[(8 * n_tiles - 4 + lane) & (kFUDw - 1)]);
+            }
+            if (lane < 20)
+            {
+              lds_st(&finl[138 + lane], lane < 19 ? vring[(2 * n_tiles - 19 + lane) & (kFVDw - 1)] : 0u);
+            }
+          }
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0)
+        {
+          lds_st(&ctl[2], (uint32_t)g + 1u);
+        }
+      }
+      flow_hold_up(P, 6, g);
+      SVC_MARK(9)
+    }
+    FLOW_TIME_MAX(45)
+#ifdef HRFD_FLOW_PROBE
+    if (P.dbg != nullptr && lane == 0)
+    {
+      for (int i = 0; i < 10; i++)
+      {
+        atomicAdd(&P.dbg[(size_t)blockIdx.x * kDbgSlots + 32 + i], sprobe[i]);
+      }
+    }
+#endif
+    if (repairs != 0u && lane == 0)
+    {
+      atomicAdd(&P.counters[kCntRepair], repairs);
+      atomicAdd(&P.sticky[kCntTotRepair], repairs);
+    }
+  }
+
   // ------------------------------------------------------------------------------------------------ finish
   __device__ __forceinline__ void finish()
   {
@@ -2109,9 +2750,11 @@ struct Flow
   }
 };
 
-template <int SVC, bool GATED, bool DUMP, int MODE>
+template <int SVC_, bool GATED, bool DUMP, int MODE>
 __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds)
 {
+  // (the re-split WBFM chain gives its service waves a third of the work: more of them)
+  constexpr int SVC = FlowLds<MODE>::kSplit ? HRFD_FLOW_SVC_WB : SVC_;
   Flow<SVC, GATED, DUMP, MODE> F(P, lds);
   if (!F.setup())
   {
@@ -2124,6 +2767,10 @@ __device__ __forceinline__ void flow_body(const RxParams &P, uint32_t *const lds
   else if constexpr (MODE != 3)
   {
     F.service_waves_fir();
+  }
+  else if constexpr (FlowLds<MODE>::kSplit)
+  {
+    F.service_waves_wbfm2();
   }
   else
   {

@@ -383,6 +383,38 @@ __device__ __forceinline__ float theta_tab(uint32_t mixed, const uint8_t *corr, 
   return u2f(__builtin_amdgcn_bitop3_b32(bits, mixed << 8, 0x80000000u, 0xF2));
 }
 
+// ---- atan2 from a first-QUADRANT table (round 5: the re-split flow kernel) -------------------------------------
+// TQ[|q| * 129 + |i|], 0 <= |i|, |q| <= 128: for i >= 0, q >= 0 the word IS the reference's entry
+// (WbFmDemodulator.cc:137-148: (float)atan2((double)q, (double)i), host libm).  Every entry is below 2.0, so bits 31
+// and 30 of its float are zero: they carry the signed 2-bit correction (in ulps, -2 .. 1) that makes
+// bits(pi_f - t) + fix the reference's entry for i < 0 (built and PROVEN to fit by the host at hrfd_rx_create from the
+// very table it replaces: build_atan_quadrant in hrfd_api.hip).  q < 0 negates (the reference table is odd in q:
+// checked there too).  One LDS word per sample, no octant logic: |i|, |q| come four bytes at a time.
+// x = the ring word of two samples as SIGNED bytes (i0, q0, i1, q1) -> |.| of the four bytes (|-128| = 128)
+__device__ __forceinline__ uint32_t abs4_s8(uint32_t x)
+{
+  const uint32_t s = (x >> 7) & 0x01010101u;            // 1 in the bytes that are negative
+  const uint32_t m = (s << 8) - s;                       // 0xff there
+  return (x ^ m) + s;                                    // ~b + 1 <= 128: no carry leaves a byte
+}
+
+// theta of sample k (0 or 1) of the word: x signed bytes, a = abs4_s8(x), tq = the table in LDS
+template <int K>
+__device__ __forceinline__ float theta_quad(uint32_t x, uint32_t a, const uint32_t *tq)
+{
+  const uint32_t coef = (K == 0) ? 0x00008101u : 0x81010000u;       // |i| + 129 |q| of sample K
+  const uint32_t idx = __builtin_amdgcn_udot4(a, coef, 0u, false);
+  const uint32_t w = tq[idx];
+  const uint32_t t = w & 0x3fffffffu;
+  const int32_t fix = (int32_t)w >> 30;
+  const uint32_t pv = f2u(kPiF - u2f(t)) + (uint32_t)fix;
+  const bool ineg = (x & (K == 0 ? 0x00000080u : 0x00800000u)) != 0u;
+  const uint32_t mag = ineg ? pv : t;
+  // sign of q: bit 15 (sample 0) / bit 31 (sample 1) of x
+  const uint32_t sg = (K == 0) ? (x << 16) : x;
+  return u2f(__builtin_amdgcn_bitop3_b32(mag, sg, 0x80000000u, 0xF8));   // mag | (sg & 0x80000000): index = 4a + 2b + c
+}
+
 // deltaTheta wrap (WbFmDemodulator.cc:417-425).  The reference compares the
 // float against the double M_PI: (double)d > M_PI  <=>  d >= 0x1.921fb6p+1f,
 // and subtracts 2*M_PI in double before rounding back to float.  |d| <= 2*pi,
@@ -1125,6 +1157,20 @@ __global__ void k_atan_eval(const uint8_t *corr, const float *inv, float *out)
   {
     const uint32_t mixed = ((t >> 8) << 16) | (t & 0xffu);
     out[t] = TAB ? theta_tab(mixed, corr, inv) : theta_arith(mixed, corr, inv);
+  }
+}
+
+// test hook (hrfd_rx_debug_atan_eval_quad): theta_quad over the whole (q, i) domain, table layout
+__global__ void k_atan_eval_quad(const uint32_t *tq, float *out)
+{
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;       // (q_idx << 8) | i_idx
+  if (t < 65536u)
+  {
+    // the ring's word: bytes (i, q) of sample 0 in the low half, of sample 1 in the high half; signed = offset binary ^ 0x80
+    const uint32_t w = (t | (t << 16)) ^ 0x80808080u;
+    const uint32_t a = abs4_s8(w);
+    const float t0 = theta_quad<0>(w, a, tq), t1 = theta_quad<1>(w, a, tq);
+    out[t] = (f2u(t0) == f2u(t1)) ? t0 : __builtin_nanf("");
   }
 }
 

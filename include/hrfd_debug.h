@@ -31,6 +31,7 @@ int hrfd_rx_debug_timing_every(hrfd_rx *h, int n);
 /* the device's atan2 (arithmetic form / first-octant-table form) for all 65536 (q, i): must equal hrfd_atan2_table() */
 int hrfd_rx_debug_atan_eval(hrfd_rx *h, float *out65536);
 int hrfd_rx_debug_atan_eval_tab(hrfd_rx *h, float *out65536);
+int hrfd_rx_debug_atan_eval_quad(hrfd_rx *h, float *out65536);   /* first-quadrant table (the re-split WBFM flow kernel) */
 /* per-workgroup cycle stamps of k_rx_wbfm (probe builds); the cross-block check values of the latest launch */
 int hrfd_rx_debug_stamps(hrfd_rx *h, uint32_t cap_groups, unsigned long long *host_out);
 int hrfd_rx_debug_chk(hrfd_rx *h, float *pub, float *spec, uint32_t n);

@@ -442,9 +442,9 @@ def test_closed_gates_are_redone_on_the_device(oracle, mode, run_len):
 
 
 @pytest.mark.parametrize("mode,point", [(AM, 1), (AM, 2), (LSB, 1), (LSB, 2), (LSB, 3), (FM, 1), (WBFM, 4), (WBFM, 5), (WBFM, 6),
-                                        (WBFM, 7), (AM, 7), (FM, 7), (WBFM, 8)],
+                                        (WBFM, 7), (AM, 7), (FM, 7), (WBFM, 8), (WBFM, 9), (WBFM, 10)],
                          ids=["am_b", "am_c", "lsb_b", "lsb_c", "lsb_rails", "fm_b", "wbfm_sums", "wbfm_verify", "wbfm_integer",
-                              "wbfm_stream", "am_stream", "fm_stream", "wbfm_arrival"])
+                              "wbfm_stream", "am_stream", "fm_stream", "wbfm_arrival", "wbfm_rows_released", "wbfm_pass_carry"])
 @pytest.mark.parametrize("gen", [0, 1, 6, 20])
 def test_a_held_up_service_wave_is_not_overtaken(oracle, mode, point, gen):
     """The service waves of the flow kernel hand generations over to each other at a few points and otherwise run side by
@@ -639,12 +639,13 @@ def test_inner_demod_many_channels(oracle):
 
 
 # ---------------------------------------------------------------- arithmetic atan2
-@pytest.mark.parametrize("tab", [False, True], ids=["polynomial", "first_octant_table"])
+@pytest.mark.parametrize("tab", [False, True, "quad"], ids=["polynomial", "first_octant_table", "first_quadrant_table"])
 def test_arithmetic_atan2_equals_table_everywhere(tab):
     """The WBFM kernels compute theta instead of gathering it from the reference's 256 x 256
     table -- k_rx_wbfm: polynomial + 2-bit correction from LDS; k_rx_wbfm_flow:
-    first-octant float table (8385 entries) + octant arithmetic + 2-bit correction.  Every one of
-    the 65536 (q, i) entries must be the table's float, bit for bit."""
+    first-octant float table (8385 entries) + octant arithmetic + 2-bit correction; the re-split WBFM flow kernel
+    (round 5): first-QUADRANT table (16641 words, the correction of the i < 0 half in their two free top bits).
+    Every one of the 65536 (q, i) entries must be the table's float, bit for bit."""
     rx = api.Rx(1)
     rx.debug_set_atan(1)                         # raises if the corrections did not fit
     got = rx.debug_atan_eval(tab)
