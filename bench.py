@@ -1125,8 +1125,10 @@ def main():
                 "measured_stream_read_GBps": round(read_gbs, 1),
                 "frac_of_measured_read": round(achieved / read_gbs, 4),
                 "measured_stream_write_GBps": round(write_gbs, 1),
-                "kernel": ("hrfd::k_rx_wbfm_flow<4, GATED=false, DUMP=%s, WBFM> (one persistent workgroup per CU, LDS ring, "
-                           "first-octant-table atan2)%s" % ("true" if args.iqdump else "false",
+                "kernel": ("hrfd::k_rx_wbfm_flow<4, GATED=false, DUMP=%s, WBFM> (re-split, round 5: one persistent workgroup per CU, "
+                           "10 stream waves put (q, i) pairs into a 512-tile LDS ring, 6 service waves do theta (first-quadrant "
+                           "table in LDS), wrap, de-emphasis recurrence with the tile's v in registers, integer stages)%s"
+                           % ("true" if args.iqdump else "false",
                                                             ", the gated pass behind it" if args.quiet_fraction > 0 else "")
                            if args.workload == "wbfm" else
                            "hrfd::k_rx_flow_bank<4> (a bank of several modes as one launch, the mode read per workgroup)"

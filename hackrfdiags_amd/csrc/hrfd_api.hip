@@ -838,7 +838,10 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   P.dbg = nullptr;
   const uint32_t n_wb = list_count[HRFD_MODE_WBFM], n_as = list_count[7], n_fm = list_count[HRFD_MODE_FM];
   const bool batch = n_blocks > 1 && !opt.serial && !opt.src256 && opt.subset == nullptr;
-  const bool flow_shape = batch && h->use_stream == 2 && h->tab_ok && h->atan_mode != 0 && (n256 % 512u) == 0 && n256 >= 2048u;
+  // (the flow shapes need their tables: the first-octant one with its corrections -- FM, and the round-4 WBFM build --
+  //  and the first-quadrant one of the re-split WBFM chain; both are proven against the reference table at create)
+  const bool flow_shape = batch && h->use_stream == 2 && h->tab_ok && (HRFD_FLOW_SPLIT == 0 || h->quad_ok) && h->atan_mode != 0 &&
+                          (n256 % 512u) == 0 && n256 >= 2048u;
   const bool flow = flow_shape && n_wb != 0;              // the WBFM channels run on the flow kernel
   const bool fir_shape = flow_shape && h->fir_flow != 0 && n_blocks <= 64u;
   const int kinds = (n_wb != 0) + (n_as != 0) + (n_fm != 0);

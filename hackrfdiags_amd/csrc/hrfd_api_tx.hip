@@ -98,6 +98,20 @@ static int mod_free(hrfd_mod *h)
   return HRFD_OK;
 }
 
+// Which build of glibc's sinf / cosf does this host run?  x86-64 glibc dispatches between a plain and an -mfma build of
+// the same source; they differ on 34 floats with |x| < 120 (all above 17: tools/proofs/sincosf_glibc.c).  1: the fused
+// build (what an FMA-capable CPU gets), 0: the plain one.  The device restates that one (glibc_sinf / glibc_cosf).
+static int libm_variant()
+{
+  auto f = [](uint32_t u) { float x; memcpy(&x, &u, 4); return x; };
+  auto b = [](float x) { uint32_t u; memcpy(&u, &x, 4); return u; };
+  volatile float x1 = f(0x418a3adbu), x2 = f(0x4255b0a9u);
+  const uint32_t c = b(cosf(x1)), s = b(sinf(x2));
+  if (c == 0xb7b4f770u && s == 0xbc7d08a9u) return 1;
+  if (c == 0xb7b4f76fu && s == 0xbc7d08a8u) return 0;
+  return 1;                                              // another libm: the tables' hash check says so (hrfd_nco_table_hash)
+}
+
 extern "C" int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out)
 {
   if (out == nullptr || n_channels == 0 ||
@@ -405,6 +419,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     B.wbtail_out = h->d_wbtail[h->cur ^ 1];
     B.n = n_per_channel;
     B.n_channels = h->n_channels;
+    B.libm_fma = libm_variant();
     // The passes run in TIME SLICES of whole blocks (512 PCM samples), on three streams: the x32 cascade with the Nco
     // steps (k_mod<WB_HEAD>) on the caller's, the phase recurrence -- serial per channel, the same 17 ns per step for
     // 64 channels as for 4096, two thirds of the call -- on one of the handle's, the table lookup and the x8 cascade
@@ -540,6 +555,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     B.phase = h->d_phase;
     B.n = n_per_channel;
     B.n_channels = h->n_channels;
+    B.libm_fma = libm_variant();
     const uint32_t gs = (uint32_t)((samples + 255) / 256);
     if (h->kind == HRFD_MOD_AM)
     {
@@ -626,6 +642,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     B.acc = h->d_acc;
     B.n = n_per_channel;
     B.n_channels = h->n_channels;
+    B.libm_fma = libm_variant();
     const uint32_t gs = (uint32_t)((samples + 255) / 256);
     if (h->kind == HRFD_MOD_SIG_AM)
     {
@@ -862,6 +879,7 @@ extern "C" int hrfd_nco_run(hrfd_nco *h, int fast, uint32_t count, float *i_out,
   N.n_channels = h->n_channels;
   N.count = count;
   N.fast = fast;
+  N.libm_fma = libm_variant();
   hipLaunchKernelGGL(k_nco, dim3((h->n_channels + 63) / 64), dim3(64), 0, h->stream, N);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(i_out, h->d_i, bytes, hipMemcpyDeviceToHost, h->stream));

@@ -2088,11 +2088,26 @@ struct Flow
     // The table comes into LDS through the service waves while the stream waves already run (they do not need it):
     // 66 KB per workgroup that the round-4 kernel loaded in front of everything.
     {
+      // (every load is requested before the first is stored: ONE memory round trip -- a copy loop costs one per turn,
+      //  11 of them at 1.5 us each while the other CUs saturate the memory system: measured, 19 us)
       const uint4 *src = reinterpret_cast<const uint4 *>(P.at_quad);
       uint4 *dstq = reinterpret_cast<uint4 *>(tquad);
-      for (int i = tid; i < kQuadDwords / 4; i += 64 * SVC)
+      constexpr int kTurns = (kQuadDwords / 4 + 64 * SVC - 1) / (64 * SVC);
+      uint4 tq[kTurns];
+#pragma unroll
+      for (int k = 0; k < kTurns; k++)
       {
-        dstq[i] = src[i];
+        const int i = tid + 64 * SVC * k;
+        tq[k] = (i < kQuadDwords / 4) ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int k = 0; k < kTurns; k++)
+      {
+        const int i = tid + 64 * SVC * k;
+        if (i < kQuadDwords / 4)
+        {
+          dstq[i] = tq[k];
+        }
       }
       if (lane == 0)
       {

@@ -394,7 +394,9 @@ __device__ __forceinline__ float theta_tab(uint32_t mixed, const uint8_t *corr, 
 __device__ __forceinline__ uint32_t abs4_s8(uint32_t x)
 {
   const uint32_t s = (x >> 7) & 0x01010101u;            // 1 in the bytes that are negative
-  const uint32_t m = (s << 8) - s;                       // 0xff there
+  uint32_t s8 = s << 8;
+  asm("" : "+v"(s8));                                    // (left to itself the compiler makes s * 255 of the next line: v_mul_lo_u32, quarter rate)
+  const uint32_t m = s8 - s;                             // 0xff there
   return (x ^ m) + s;                                    // ~b + 1 <= 128: no carry leaves a byte
 }
 

@@ -573,6 +573,100 @@ namespace hrfd {
 // ---- AM / FM modulator basebands ---------------------------------------
 // AmModulator::modulateSignal (AmModulator.cc:574-612): I = Q = (int16)(((pcm/32768)*m + 1)/2*128*250),
 // float operations in that order.  One thread per sample; rails [C][2n] int16 (I,Q pairs).
+// ---- glibc 2.35 sinf / cosf, restated (round 5) --------------------------------------------------------------
+// The reference calls cos(float) / sin(float) under <math.h> + `using namespace std`: C++ overload resolution makes
+// that cosf / sinf (Nco.cc:186-199, signals/pm.cc:41-53, fm.cc:44-77).  glibc's are the ARM
+// optimized-routines algorithm (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, s_sincosf_data.c): reduction by
+// pi/2 in double (n = round(x * 2/pi) by an integer trick, x - n * pi/2), then one of two double polynomials, rounded
+// to float once -- deterministic, so it can be the device's arithmetic as well: tools/proofs/sincosf_glibc.c checks
+// this restatement against the host's libm on EVERY float with |x| < 120 (2.2e9 values): 0 mismatches with the
+// fused multiply-adds of the -mfma build that x86-64 glibc dispatches to on an FMA-capable CPU, 34 (all at |x| > 17)
+// without them.  FMA: which of the two the host's libm is -- probed by the host (libm_variant, hrfd_api_tx.hip).
+// Outside the restated range (|x| >= 120, NaN) the double-precision cos / sin rounded to float stand in (never reached:
+// every caller wraps its phase into (-2 pi, 2 pi)).
+struct SinCosTab
+{
+  double c0, c1, c2, c3, c4, s1, s2, s3;
+};
+__device__ __forceinline__ SinCosTab sincos_tab(const bool flip)
+{
+  // __sincosf_table[0] and [1] (the second has the cosine polynomial negated)
+  const double sg = flip ? -1.0 : 1.0;
+  SinCosTab t;
+  t.c0 = sg * 0x1p0;
+  t.c1 = sg * -0x1.ffffffd0c621cp-2;
+  t.c2 = sg * 0x1.55553e1068f19p-5;
+  t.c3 = sg * -0x1.6c087e89a359dp-10;
+  t.c4 = sg * 0x1.99343027bf8c3p-16;
+  t.s1 = -0x1.555545995a603p-3;
+  t.s2 = 0x1.1107605230bc4p-7;
+  t.s3 = -0x1.994eb3774cf24p-13;
+  return t;
+}
+template <bool FMA>
+__device__ __forceinline__ double sc_ma(double a, double b, double c)
+{
+  if (FMA)
+  {
+    return __builtin_fma(a, b, c);
+  }
+  const double p = a * b;                                // (-ffp-contract=off: two roundings)
+  return p + c;
+}
+// sinf_poly (sincosf.h): n even -> the sine polynomial of x, odd -> the cosine polynomial
+template <bool FMA>
+__device__ __forceinline__ float sc_poly(double x, double x2, const SinCosTab &p, int n)
+{
+  if ((n & 1) == 0)
+  {
+    const double x3 = x * x2;
+    const double s1 = sc_ma<FMA>(x2, p.s3, p.s2);
+    const double x7 = x3 * x2;
+    const double s = sc_ma<FMA>(x3, p.s1, x);
+    return (float)sc_ma<FMA>(x7, s1, s);
+  }
+  const double x4 = x2 * x2;
+  const double c2 = sc_ma<FMA>(x2, p.c4, p.c3);
+  const double c1 = sc_ma<FMA>(x2, p.c1, p.c0);
+  const double x6 = x4 * x2;
+  const double c = sc_ma<FMA>(x4, p.c2, c1);
+  return (float)sc_ma<FMA>(x6, c2, c);
+}
+// COS = false: sinf(y); true: cosf(y)
+template <bool FMA, bool COS>
+__device__ __forceinline__ float glibc_sincosf_v(float y)
+{
+  const uint32_t top = (__builtin_bit_cast(uint32_t, y) >> 20) & 0x7ffu;    // abstop12
+  double x = (double)y;
+  if (top >= 0x42fu)                                     // |y| >= 120 (abstop12(120.0f)), infinity, NaN: outside the restated range
+  {
+    return COS ? (float)cos(x) : (float)sin(x);
+  }
+  if (top < 0x3f4u)                                      // |y| < pi / 4 (abstop12(0x1.921FB6p-1f))
+  {
+    if (top < 0x398u)                                    // |y| < 2^-12
+    {
+      return COS ? 1.0f : y;
+    }
+    return sc_poly<FMA>(x, x * x, sincos_tab(false), COS ? 1 : 0);
+  }
+  // reduce_fast: n = round(x * 2/pi) through r = x * (2/pi * 2^24), (int32)r + 2^23 >> 24
+  const double r = x * 0x1.45F306DC9C883p+23;
+  const int n = ((int)r + 0x800000) >> 24;
+  const double hpi = 0x1.921FB54442D18p0;
+  x = FMA ? __builtin_fma(-(double)n, hpi, x) : x - (double)n * hpi;
+  const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign[] = {1, -1, -1, 1}
+  return sc_poly<FMA>(x * s, x * x, sincos_tab((n & 2) != 0), COS ? (n ^ 1) : n);
+}
+__device__ __forceinline__ float glibc_sinf(float y, int fma_variant)
+{
+  return fma_variant ? glibc_sincosf_v<true, false>(y) : glibc_sincosf_v<false, false>(y);
+}
+__device__ __forceinline__ float glibc_cosf(float y, int fma_variant)
+{
+  return fma_variant ? glibc_sincosf_v<true, true>(y) : glibc_sincosf_v<false, true>(y);
+}
+
 struct BaseParams
 {
   const int16_t *pcm;       // [C][n]
@@ -586,6 +680,7 @@ struct BaseParams
   uint32_t *wbtail_out;     // WBFM: [C][2] the call's last two rail pairs (next call's history)
   uint32_t n, n_channels;
   uint32_t lo, len;         // k_wb_rails: input samples [lo, lo + len) of every channel (len 0: all): a time slice
+  int libm_fma;             // which build of glibc's sinf / cosf the host has (glibc_sinf, above)
 };
 
 __global__ void k_am_rails(const BaseParams B)
@@ -637,8 +732,8 @@ __global__ void k_sig_rails(const BaseParams B)
   {
     s = s / 60000.0f;
     s = (float)((double)s * 3.14159265358979323846);
-    const float ci = (float)cos((double)s) * 16000.0f;
-    const float sq = (float)sin((double)s) * 16000.0f;
+    const float ci = glibc_cosf(s, B.libm_fma) * 16000.0f;      // pm.cc:41-53: cos(float) is cosf
+    const float sq = glibc_sinf(s, B.libm_fma) * 16000.0f;
     vi = (int)ci;
     vq = (int)sq;
   }
@@ -673,8 +768,8 @@ __global__ void k_sig_fm(const BaseParams B)
     {
       theta = (float)((double)theta + two_pi);
     }
-    const float ci = (float)cos((double)theta) * 16000.0f;
-    const float sq = (float)sin((double)theta) * 16000.0f;
+    const float ci = glibc_cosf(theta, B.libm_fma) * 16000.0f;
+    const float sq = glibc_sinf(theta, B.libm_fma) * 16000.0f;
     out[k] = ((uint32_t)(int)ci & 0xffffu) | ((uint32_t)(int)sq << 16);
   }
   B.acc[c] = theta;
@@ -1339,9 +1434,9 @@ __global__ void k_phase_scan_plain(uint32_t *cells, size_t steps, size_t row_str
   acc_io[c] = acc;
 }
 
-// Pass 3, one thread per sample: Nco::run (Nco.cc:186-199) calls libm cosf/sinf; here the
-// double-precision cos/sin rounded to float (within 1 ulp of glibc's, so the int16 rails and the
-// int8 output are within 1 LSB: the float-trig tolerance of BASELINE.json), times 16000, (int16_t).
+// Pass 3, one thread per sample: Nco::run (Nco.cc:186-199) calls libm cosf/sinf -- glibc's algorithm restated on the
+// device (glibc_cosf / glibc_sinf, above: bit for bit since round 5; rounds 1-4 rounded a double cos / sin and were
+// within 1 LSB) --, times 16000, (int16_t).
 __global__ void k_fm_rails(const BaseParams B)
 {
   // (B.len != 0: the samples [lo, lo + len) of every channel -- a time slice of the call)
@@ -1357,7 +1452,7 @@ __global__ void k_fm_rails(const BaseParams B)
     t = c * B.n + B.lo + (t - c * len);
   }
   const float phase = B.phase[t];
-  float iv = (float)cos((double)phase), qv = (float)sin((double)phase);
+  float iv = glibc_cosf(phase, B.libm_fma), qv = glibc_sinf(phase, B.libm_fma);
   iv = iv * 16000.0f;
   qv = qv * 16000.0f;
   const int i16 = (int)(short)(int)iv, q16 = (int)(short)(int)qv;
@@ -1443,6 +1538,7 @@ struct NcoParams
   float *i_out, *q_out;     // [C][count]
   uint32_t n_channels, count;
   int fast;
+  int libm_fma;             // which build of glibc's sinf / cosf the host has (glibc_sinf)
 };
 
 __global__ void k_nco(const NcoParams N)
@@ -1482,10 +1578,9 @@ __global__ void k_nco(const NcoParams N)
     }
     else
     {
-      // Nco::run (:186-199) calls libm cosf/sinf; here: double-precision cos/sin
-      // rounded to float (agrees with glibc to within 1 ulp)
-      iv = (float)cos((double)phase);
-      qv = (float)sin((double)phase);
+      // Nco::run (:186-199) calls libm cosf/sinf: glibc's algorithm, restated (glibc_cosf: bit for bit)
+      iv = glibc_cosf(phase, N.libm_fma);
+      qv = glibc_sinf(phase, N.libm_fma);
     }
     N.i_out[(size_t)c * N.count + k] = iv;
     N.q_out[(size_t)c * N.count + k] = qv;

@@ -73,11 +73,11 @@ def test_shim_ssb_modulator_reproduces_oracle(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,arg,param,tol", [("ammod", "500", 0.5, 0), ("fmmod", "1200", 1200.0, 1),
+@pytest.mark.parametrize("kind,arg,param,tol", [("ammod", "500", 0.5, 0), ("fmmod", "1200", 1200.0, 0),
                                                 ("wbfmmod", "30000", 30000.0, 0)])
 def test_shim_am_fm_modulators_reproduce_oracle(oracle, kind, arg, param, tol):
     """AmModulator / FmModulator / WbFmModulator shim classes (reference names and setters) against
-    the oracle: AM and WBFM bit-exact, FM within the +-1 LSB of the trig path"""
+    the oracle: bit-exact, all three (FM since round 5: glibc's cosf / sinf restated on the device)"""
     _build_demo()
     pcm = synth.lcg_pcm(9, 2 * 512)
     out = subprocess.run([DEMO, arg, kind, "0"], input=pcm.tobytes(), stdout=subprocess.PIPE,
@@ -97,9 +97,8 @@ def test_shim_baseband_data_processor_dispatch(oracle, mode):
     """SURVEY 8a row T5: BasebandDataProcessor::getIqData -> modulateBasebandData (BasebandDataProcessor.cc:381,
     630-697) through the shim class: one 512-sample block off the PCM ring (drop / repeat pacing, zeros while the
     stream is idle) through the modulator of the mode; mode None fills the transfer buffer with 64.  Expected: the
-    oracle's ring model driven with the same schedule feeding the oracle's modulator.  Bit-exact, except FM (mode 2):
-    FmModulator goes through libm cosf/sinf in the reference and through double cos/sin on the device, so its int8 IQ
-    is within +-1 LSB (the trig-path tolerance of BASELINE.json's north star)."""
+    oracle's ring model driven with the same schedule feeding the oracle's modulator.  Bit-exact in every mode (FM, mode 2,
+    since round 5: FmModulator goes through libm cosf/sinf in the reference, glibc's algorithm restated on the device)."""
     _build_demo()
     ops = "r" + "w" * 16 + "s" + "r" * 3 + "wr" * 6 + "rrrr" + "w" * 9 + "rr" + "p" + "r"
     n_w = ops.count("w")
@@ -121,11 +120,7 @@ def test_shim_baseband_data_processor_dispatch(oracle, mode):
             ring.set_running(o == "s")
     want = np.stack(want)
     assert got.shape == want.shape
-    tol = 1 if mode == 2 else 0
-    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
-    assert np.minimum(d, 256 - d).max() <= tol
-    if mode == 2:
-        assert (d != 0).mean() < 0.02, "FM: only isolated bytes may differ"
+    assert (got == want).all()                             # every mode, FM (2) included since round 5
     st = ring.stats()
     assert st[2] > 0 and st[3] > 0, "the schedule should exercise both the drop and the repeat branch"
 

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 import torch
 from hackrfdiags_amd import api
 BLK = 262144
+NSVC = int(os.environ.get("HRFD_NSVC", "6")); NSTREAM = 16 - NSVC
 C, B = int(os.environ.get('HRFD_C', '256')), 16
 dev = torch.device("cuda:0")
 x = torch.randint(-128, 128, (C, B, BLK), dtype=torch.int8, device=dev)
@@ -33,14 +34,14 @@ pr = st[:, 24:32].mean(axis=0)
 if pr.sum() > 0:
     # the stamp rows accumulate over the N launches of the burst
     print("probe, cycles per stream wave per launch: loop-top %d | grab+issue qb %d | carry (waits c16, qa) %d | ring wait %d | piece 0 %d | issue next %d | piece 1 %d | publish %d"
-          % tuple((pr / N / 12).tolist()))
-    print("   sum %.0f" % (pr.sum() / N / 12))
+          % tuple((pr / N / NSTREAM).tolist()))
+    print("   sum %.0f" % (pr.sum() / N / NSTREAM))
 sp = st[:, 32:42].mean(axis=0)
 if sp.sum() > 0:
     names = ["loop-top", "wait units", "patch", "partial sums", "wait P(g-1)", "seed+warm+tile", "wait order", "verify+U0+store", "D12+D40", "chk+publish"]
     print("service probe, cycles per service wave per launch (16 generations each):")
-    print("   " + " | ".join(f"{n} {v:.0f}" for n, v in zip(names, (sp / N / 4).tolist())))
-    print("   sum %.0f" % (sp.sum() / N / 4))
+    print("   " + " | ".join(f"{n} {v:.0f}" for n, v in zip(names, (sp / N / NSVC).tolist())))
+    print("   sum %.0f" % (sp.sum() / N / NSVC))
 tl = st[:, 42:47]
 if tl[:, 0].min() > 0:
     t0 = tl[:, 0].min()
