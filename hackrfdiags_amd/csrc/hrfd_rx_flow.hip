@@ -56,7 +56,10 @@
 #define HRFD_FLOW_SVC_WB 6          /* service waves of the re-split WBFM kernel (they do a third of the work now) */
 #endif
 #ifndef HRFD_FLOW_RING2
-#define HRFD_FLOW_RING2 512         /* its ring, in tiles of 64 samples (a power of two) */
+#define HRFD_FLOW_RING2 512         /* its ring, in tiles of 64 samples (a power of two; 256: -1.8 %, profiles/r5_flow_split_ab_4_prio_ring.txt) */
+#endif
+#ifndef HRFD_FLOW_SVC_PRIO_WB
+#define HRFD_FLOW_SVC_PRIO_WB 0     /* s_setprio of its service waves: with a third of the work they need no head start (3: -0.4 % at 1024 channels, same file) */
 #endif
 // diagnostic build: -DHRFD_FLOW_PROBE accumulates, per stream wave, the cycles between the marks of its unit loop
 // (slots 24..31 of its workgroup's stamp row are summed over the waves; read with tools/gpu_flow_times.py)
@@ -2075,7 +2078,7 @@ struct Flow
     // (the per-generation records -- lastdw, wcar / wflag, parr, pflag -- have eight slots: at most SVC generations are
     //  in flight, consecutive ones, because a generation completes only behind the one in front: verification order)
     static_assert(SVC <= 7, "per-generation records of the re-split service waves");
-    __builtin_amdgcn_s_setprio(HRFD_FLOW_SVC_PRIO);
+    __builtin_amdgcn_s_setprio(HRFD_FLOW_SVC_PRIO_WB);
     const float a1 = DEEMPH_A1;
     const int fa_t = first ? 0 : (wt + M);               // first tile that can be started properly
     const uint32_t pcm_off = (uint32_t)(hal >> 5);       // PCM samples that the history in front would yield
@@ -2204,15 +2207,27 @@ struct Flow
             pp = first ? p_in : 0.0f;
           }
         }
+        // (eight lookups are put in flight before the first is used: behind each other, as the loop over the words would
+        //  have them, every pair exposes the LDS latency -- a quarter of this stretch when the wave is alone on its
+        //  SIMD, which it is behind the stream's last sample)
 #pragma unroll
         for (int j = 0; j < 8; j++)
         {
           const uint32_t w4[4] = {row[j].x, row[j].y, row[j].z, row[j].w};
+          uint32_t xs[4], tw[8];
 #pragma unroll
           for (int k = 0; k < 4; k++)
           {
-            const uint32_t x = w4[k] ^ 0x80808080u, a = abs4_s8(x);
-            const float th0 = theta_quad<0>(x, a, tquad), th1 = theta_quad<1>(x, a, tquad);
+            xs[k] = w4[k] ^ 0x80808080u;
+            const uint32_t a = abs4_s8(xs[k]);
+            tw[2 * k] = tquad[theta_quad_index<0>(a)];
+            tw[2 * k + 1] = tquad[theta_quad_index<1>(a)];
+          }
+          asm volatile("" ::: "memory");                 // (the compiler may not sink the reads back to their uses)
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+          {
+            const float th0 = theta_quad_word<0>(xs[k], tw[2 * k]), th1 = theta_quad_word<1>(xs[k], tw[2 * k + 1]);
             const float p0 = numerator_p<true>(th0, thp, kgain);
             const float p1 = numerator_p<true>(th1, th0, kgain);
             v[8 * j + 2 * k] = p0 + pp;

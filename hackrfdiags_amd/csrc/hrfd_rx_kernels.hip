@@ -400,13 +400,18 @@ __device__ __forceinline__ uint32_t abs4_s8(uint32_t x)
   return (x ^ m) + s;                                    // ~b + 1 <= 128: no carry leaves a byte
 }
 
-// theta of sample k (0 or 1) of the word: x signed bytes, a = abs4_s8(x), tq = the table in LDS
+// theta of sample k (0 or 1) of the word, in two halves so that a caller can put many lookups in flight before it
+// uses the first: the table index (x signed bytes, a = abs4_s8(x)) ...
 template <int K>
-__device__ __forceinline__ float theta_quad(uint32_t x, uint32_t a, const uint32_t *tq)
+__device__ __forceinline__ uint32_t theta_quad_index(uint32_t a)
 {
   const uint32_t coef = (K == 0) ? 0x00008101u : 0x81010000u;       // |i| + 129 |q| of sample K
-  const uint32_t idx = __builtin_amdgcn_udot4(a, coef, 0u, false);
-  const uint32_t w = tq[idx];
+  return __builtin_amdgcn_udot4(a, coef, 0u, false);
+}
+// ... and theta from the table's word w
+template <int K>
+__device__ __forceinline__ float theta_quad_word(uint32_t x, uint32_t w)
+{
   const uint32_t t = w & 0x3fffffffu;
   const int32_t fix = (int32_t)w >> 30;
   const uint32_t pv = f2u(kPiF - u2f(t)) + (uint32_t)fix;
@@ -415,6 +420,11 @@ __device__ __forceinline__ float theta_quad(uint32_t x, uint32_t a, const uint32
   // sign of q: bit 15 (sample 0) / bit 31 (sample 1) of x
   const uint32_t sg = (K == 0) ? (x << 16) : x;
   return u2f(__builtin_amdgcn_bitop3_b32(mag, sg, 0x80000000u, 0xF8));   // mag | (sg & 0x80000000): index = 4a + 2b + c
+}
+template <int K>
+__device__ __forceinline__ float theta_quad(uint32_t x, uint32_t a, const uint32_t *tq)
+{
+  return theta_quad_word<K>(x, tq[theta_quad_index<K>(a)]);
 }
 
 // deltaTheta wrap (WbFmDemodulator.cc:417-425).  The reference compares the

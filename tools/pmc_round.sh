@@ -6,7 +6,7 @@
 # for that code.  Per workload: the sum over ALL hrfd:: kernels of a step (the batch kernel and whatever runs behind it),
 # per step; the two plain stream kernels of the denominators (k_membw_*) are not counted.
 # usage: tools/pmc_round.sh <tag>            -> gpurun_out/pmc_<tag>/pmc_traffic.json (+ per-kernel table)
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp
 export HRFD_BENCH_SETTLE=0          # counters, not clocks: no settling launches
 R=$GRAFT_REPO_ROOT
@@ -17,7 +17,7 @@ one() {   # name, bench args...
   local name=$1; shift
   for CNT in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/raw_${name}_$CNT -- \
-      python3 $R/bench.py --steps $STEPS --warmup $WARM --no-cpu --no-extras "$@" > $O/${name}_$CNT.json 2> $O/${name}_$CNT.log || echo "FAILED $name $CNT"
+      python3 $R/bench.py --steps $STEPS --warmup $WARM --no-cpu --no-extras --verify 0 "$@" > $O/${name}_$CNT.json 2> $O/${name}_$CNT.log || echo "FAILED $name $CNT"
   done
   echo "done $name" >> $O/progress.txt
 }
@@ -34,6 +34,7 @@ one ssbmod_1024x16 --workload ssbmod
 one ammod_1024x16 --workload ammod
 one fmmod_1024x16 --workload fmmod
 one wbfmmod_1024x16 --workload wbfmmod
+one wbfm_4096x16 --channels 4096
 python3 - "$O" "$R" $STEPS $WARM <<'PY'
 import csv, glob, collections, json, os, sys
 O, R, STEPS, WARM = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
@@ -56,7 +57,9 @@ for d in sorted(glob.glob(O + "/raw_*_FETCH_SIZE")):
                     acc[k].append(float(r["Counter_Value"]))
         if not acc:
             continue
-        steps_total = STEPS + WARM                      # HRFD_BENCH_SETTLE=0: these are all the steps the bench ran
+        # HRFD_BENCH_SETTLE=0: warm-up + timed steps are all the steps the bench ran -- plus, for the receive workloads, the
+        # min(8, steps) single launches it samples behind the timed region (bench.measure_rx, round 5)
+        steps_total = STEPS + WARM + (0 if name.endswith(("mod_1024x16", "mod_8192x16")) else min(8, STEPS))
         tot = 0.0
         for k, v in sorted(acc.items()):
             per_step = len(v) / steps_total

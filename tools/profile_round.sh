@@ -3,14 +3,14 @@
 # a second argument is given): per-kernel call counts and durations.  (The HBM traffic counters are tools/pmc_round.sh,
 # the SQ counters tools/sq_round.sh: counters are collected in runs of their own, never with --stats.)
 # usage: tools/profile_round.sh <tag> [all]
-TAG=${1:-r3}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 stats() {   # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -- python3 $R/bench.py --no-cpu --no-extras "$@" > $O/bench_under_rocprof_$name.json 2> $O/trace_$name.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$name -- python3 $R/bench.py --no-cpu --no-extras --verify 0 "$@" > $O/bench_under_rocprof_$name.json 2> $O/trace_$name.log
   python3 - "$O" "$name" <<'PY'
 import csv, glob, sys
 O, name = sys.argv[1], sys.argv[2]
