@@ -186,6 +186,11 @@ __device__ __forceinline__ void lds_add_async(uint32_t &ret, const uint32_t *p, 
   const uint32_t off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)p;
   asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(ret) : "v"(off), "v"(val) : "memory");
 }
+__device__ __forceinline__ void lds_or_async(uint32_t &ret, const uint32_t *p, uint32_t val)
+{
+  const uint32_t off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)p;
+  asm volatile("ds_or_rtn_b32 %0, %1, %2" : "=v"(ret) : "v"(off), "v"(val) : "memory");
+}
 __device__ __forceinline__ void lds_landed(uint32_t &ret)
 {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ret) : : "memory");
@@ -414,6 +419,24 @@ struct FlowLds
 };
 constexpr int kCtlRel = 24;                     // ctl[]: re-split, generations whose ring rows have been read (released to the stream waves)
 constexpr int kCtlTab = 25;                     // ... service waves that have copied their share of the table
+// The stream's LAST generation is made together: behind the last sample nothing else runs on the CU, and a lane's 64
+// samples of theta / wrap / numerator are 3.5 us of one wave while five service waves idle.  Its tiles are cut into
+// four QUARTERS of 16 samples; the generation's wave and every service wave that has run out of generations claim
+// quarters (a bit each in ctl[kCtlCoopNext]), put their v into a scratch area of the ring (rows that nobody reads or writes any
+// more) and the generation's wave collects its 64 per lane from there.  Same operations on the same operands: same bits.
+// MEASURED AND SWITCHED OFF (profiles/r5_flow_coop_ab_LOSES.txt, alternating runs on one box): 0.2094 against 0.2081 ms
+// at 256 channels, 0.7978 against 0.7965 at 1024 -- the helpers' claims, the second pass over LDS and four separate
+// stretches (each re-deriving the two samples in front of it) cost what the shared work saves; the service tail stays
+// at 7.8 us.  Kept as a build flag (bit-exact, the GPU suite and the stress build pass with it on).
+#ifndef HRFD_FLOW_COOP
+#define HRFD_FLOW_COOP 0
+#endif
+constexpr int kCtlCoopOpen = 26;                // ... the last generation's rows may be read (its units are in the ring): g + 1
+constexpr int kCtlCoopNext = 27;                // ... the quarters that are taken, one bit each
+constexpr int kCtlCoopDone = 28;                // ... quarters finished
+constexpr int kCoopStride = 68;                 // dwords per tile in the scratch area: 16 lanes' 128-bit accesses fall into 64 different banks
+constexpr int kCoopRows = (64 * kCoopStride + 128 + kFStride2 - 1) / kFStride2;   // ring rows of the scratch area (v, then theta and b0*x of every tile's last sample)
+static_assert(384 + kCoopRows <= kFRing2 || kFRing2 < 512, "the scratch area fits beside the last generation's rows");
 
 // The flow kernel as an object: what the sections below share -- the workgroup's LDS arrays, the channel, the run's
 // geometry, the carried state, the failure code -- are its members, set once by setup(); the sections are member
@@ -2062,6 +2085,117 @@ struct Flow
     }
   }
 
+  // ------------------------------------------------------ theta / wrap / numerator of 8 NG samples (re-split)
+  // w: NG groups of four ring words (bytes i0 q0 i1 q1, offset binary); thp / pp: theta and b0*x of the sample in front,
+  // updated to the last sample's; v: the FIR half of the de-emphasis filter (WbFmDemodulator.cc:404-430,
+  // IirFilter.cc:161-176: v = b0 x + b1 x[n-1], b1 == b0).  Eight table lookups are in flight before the first is used:
+  // behind each other every pair exposes the LDS latency -- a quarter of this stretch when the wave is alone on its SIMD.
+  template <int NG>
+  __device__ __forceinline__ void theta_to_v(const uint32_t (&w)[4 * NG], float &thp, float &pp, float (&v)[8 * NG])
+  {
+#pragma unroll
+    for (int j = 0; j < NG; j++)
+    {
+      uint32_t xs[4], tw[8];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        xs[k] = w[4 * j + k] ^ 0x80808080u;
+        const uint32_t a = abs4_s8(xs[k]);
+        tw[2 * k] = tquad[theta_quad_index<0>(a)];
+        tw[2 * k + 1] = tquad[theta_quad_index<1>(a)];
+      }
+      asm volatile("" ::: "memory");                     // (the compiler may not sink the reads back to their uses)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        const float th0 = theta_quad_word<0>(xs[k], tw[2 * k]), th1 = theta_quad_word<1>(xs[k], tw[2 * k + 1]);
+        const float p0 = numerator_p<true>(th0, thp, kgain);
+        const float p1 = numerator_p<true>(th1, th0, kgain);
+        v[8 * j + 2 * k] = p0 + pp;
+        v[8 * j + 2 * k + 1] = p1 + p0;
+        thp = th1;
+        pp = p1;
+      }
+    }
+  }
+  // theta and b0*x of the two samples in the ring word in front of a stretch (tile 0 of the stream, quarter 0: the
+  // carried ones when the stream continues the previous call; a run that re-derives its history starts from zeros --
+  // on silent input that IS the truth: a transient there would never die away bit for bit and fail the cross-run check)
+  __device__ __forceinline__ void theta_in_front(const uint32_t prevw, const bool stream_start, const float theta_in, const float p_in,
+                                                 float &thp, float &pp)
+  {
+    const uint32_t x = prevw ^ 0x80808080u, a = abs4_s8(x);
+    const float tm2 = theta_quad<0>(x, a, tquad), tm1 = theta_quad<1>(x, a, tquad);
+    thp = tm1;
+    pp = numerator_p<true>(tm1, tm2, kgain);
+    if (stream_start)
+    {
+      thp = first ? theta_in : 0.0f;
+      pp = first ? p_in : 0.0f;
+    }
+  }
+  // The last generation's quarters (kCtlCoop*): claimed one at a time by whoever is there -- the generation's own wave
+  // and the service waves that have run out of generations -- until all four are taken
+  // FROM_END: the helpers take the quarters from the other end, so that they and the generation's wave meet in the middle.
+  // (A loop that runs until a claim counter says "none left" never came back from the GPU, with atomicAdd() and with the
+  // inline-assembly add alike, while the same body under a fixed four-turn loop did -- bring-up builds
+  // -DHRFD_FLOW_COOP=2 / 3.  Hence four fixed turns and one claim BIT per quarter: the loop's shape does not depend on
+  // what the other waves do, only whether a turn's body runs.)
+  template <bool FROM_END>
+  __device__ __forceinline__ void coop_quarters(const int g, const float theta_in, const float p_in)
+  {
+    const int t0 = 64 * g;
+    const int ntl = min(64, n_tiles - t0);
+    const int t = t0 + lane;
+    const int r0 = t0 & (kFRing2 - 1);
+    uint32_t *vs = ring + ((r0 >= 384) ? 0 : r0 + 64) * kFStride2;   // rows that nobody reads or writes any more
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const int q = FROM_END ? 3 - k : k;
+      uint32_t old = 0;
+      if (lane == 0)
+      {
+        lds_or_async(old, &ctl[kCtlCoopNext], 1u << q);
+      }
+      lds_landed(old);
+      const bool taken = (((uint32_t)__builtin_amdgcn_readfirstlane((int)old) >> q) & 1u) != 0u;
+      if (!taken)
+      {
+        if (lane < ntl)
+        {
+          const uint32_t *tp = ring + (t & (kFRing2 - 1)) * kFStride2;
+          const uint4 a = reinterpret_cast<const uint4 *>(tp)[2 * q], b = reinterpret_cast<const uint4 *>(tp)[2 * q + 1];
+          const uint32_t *pp_ = (q != 0) ? tp + 8 * q - 1
+                                : (lane == 0) ? &lastdw[(g - 1) & 7] : ring + ((t - 1) & (kFRing2 - 1)) * kFStride2 + 31;
+          const uint32_t prevw = *pp_;
+          float thp, pp;
+          theta_in_front(prevw, t == 0 && q == 0, theta_in, p_in, thp, pp);
+          const uint32_t w8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+          float v16[16];
+          theta_to_v<2>(w8, thp, pp, v16);
+          uint4 *dq = reinterpret_cast<uint4 *>(vs + lane * kCoopStride + 16 * q);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+          {
+            dq[i] = make_uint4(f2u(v16[4 * i]), f2u(v16[4 * i + 1]), f2u(v16[4 * i + 2]), f2u(v16[4 * i + 3]));
+          }
+          if (q == 3)
+          {
+            vs[64 * kCoopStride + lane] = f2u(thp);
+            vs[64 * kCoopStride + 64 + lane] = f2u(pp);
+          }
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0)
+        {
+          atomicAdd(&ctl[kCtlCoopDone], 1u);             // (LDS runs a wave's operations in order: behind its stores)
+        }
+      }
+    }
+  }
+
   // --------------------------------------------------------------- service waves, WBFM, re-split (round 5)
   __device__ __forceinline__ void service_waves_wbfm2()
   {
@@ -2087,7 +2221,10 @@ struct Flow
     unsigned long long sprobe[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sprev = __builtin_readcyclecounter();
     (void)sprobe; (void)sprev;
     // the carried state of a stream that continues the previous call (requested before the table: one round trip)
-    const float y_in = st->wb_y, theta_in = st->wb_theta, p_in = st->wb_p;
+    // (wave-uniform, and said so: three scalar registers instead of three vector ones held for the whole stream)
+    const float y_in = u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(st->wb_y)));
+    const float theta_in = u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(st->wb_theta)));
+    const float p_in = u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(st->wb_p)));
     // The table comes into LDS through the service waves while the stream waves already run (they do not need it):
     // 66 KB per workgroup that the round-4 kernel loaded in front of everything.
     {
@@ -2192,52 +2329,53 @@ struct Flow
           lds_st(&ctl[kCtlRel], (uint32_t)g + 1u);
         }
         flow_hold_up(P, 9, g);
-        float thp, pp;
+        constexpr bool kCoop = (HRFD_FLOW_COOP != 0) && SVC >= 2;
+        if (kCoop && g + 1 == n_gens)
         {
-          const uint32_t x = prevw ^ 0x80808080u, a = abs4_s8(x);
-          const float tm2 = theta_quad<0>(x, a, tquad), tm1 = theta_quad<1>(x, a, tquad);
-          thp = tm1;
-          pp = numerator_p<true>(tm1, tm2, kgain);
-          if (t == 0)
+          // the stream's last generation: its quarters are made by whoever is there (coop_quarters)
+          if (lane == 0)
           {
-            // the stream's first sample: theta and b0*x in front of it are the carried ones when the stream continues the
-            // previous call; a run that re-derives its history starts it from zeros (on silent input that IS the truth:
-            // a transient there would never die away bit for bit and fail the cross-run check)
-            thp = first ? theta_in : 0.0f;
-            pp = first ? p_in : 0.0f;
+            lds_st(&ctl[kCtlCoopOpen], (uint32_t)g + 1u);
           }
-        }
-        // (eight lookups are put in flight before the first is used: behind each other, as the loop over the words would
-        //  have them, every pair exposes the LDS latency -- a quarter of this stretch when the wave is alone on its
-        //  SIMD, which it is behind the stream's last sample)
+          coop_quarters<false>(g, theta_in, p_in);
+          {
+            const unsigned long long tw0 = __builtin_readcyclecounter();
+            FlowSpin sp;
+            while (lds_ld(&ctl[kCtlCoopDone]) != 4u && !sp.expired(P, ctl, fail_code, 12))
+            {
+              __builtin_amdgcn_s_sleep(1);
+            }
+            waited += __builtin_readcyclecounter() - tw0;
+            lds_order();
+          }
+          const int r0 = t0 & (kFRing2 - 1);
+          const uint32_t *vs = ring + ((r0 >= 384) ? 0 : r0 + 64) * kFStride2;
+          const uint4 *sq = reinterpret_cast<const uint4 *>(vs + lane * kCoopStride);
 #pragma unroll
-        for (int j = 0; j < 8; j++)
+          for (int i = 0; i < 16; i++)
+          {
+            const uint4 x4 = sq[i];
+            v[4 * i] = u2f(x4.x);
+            v[4 * i + 1] = u2f(x4.y);
+            v[4 * i + 2] = u2f(x4.z);
+            v[4 * i + 3] = u2f(x4.w);
+          }
+          th_last = u2f(vs[64 * kCoopStride + lane]);
+          p_last = u2f(vs[64 * kCoopStride + 64 + lane]);
+        }
+        else
         {
-          const uint32_t w4[4] = {row[j].x, row[j].y, row[j].z, row[j].w};
-          uint32_t xs[4], tw[8];
+          float thp, pp;
+          theta_in_front(prevw, t == 0, theta_in, p_in, thp, pp);
 #pragma unroll
-          for (int k = 0; k < 4; k++)
+          for (int j = 0; j < 8; j++)
           {
-            xs[k] = w4[k] ^ 0x80808080u;
-            const uint32_t a = abs4_s8(xs[k]);
-            tw[2 * k] = tquad[theta_quad_index<0>(a)];
-            tw[2 * k + 1] = tquad[theta_quad_index<1>(a)];
+            const uint32_t w4[4] = {row[j].x, row[j].y, row[j].z, row[j].w};
+            theta_to_v<1>(w4, thp, pp, *reinterpret_cast<float (*)[8]>(&v[8 * j]));
           }
-          asm volatile("" ::: "memory");                 // (the compiler may not sink the reads back to their uses)
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-          {
-            const float th0 = theta_quad_word<0>(xs[k], tw[2 * k]), th1 = theta_quad_word<1>(xs[k], tw[2 * k + 1]);
-            const float p0 = numerator_p<true>(th0, thp, kgain);
-            const float p1 = numerator_p<true>(th1, th0, kgain);
-            v[8 * j + 2 * k] = p0 + pp;
-            v[8 * j + 2 * k + 1] = p1 + p0;
-            thp = th1;
-            pp = p1;
-          }
+          th_last = thp;
+          p_last = pp;
         }
-        th_last = thp;
-        p_last = pp;
       }
       SVC_MARK(2)
       // 3. geometric partial sum of v over the own tile: P = sum_k c^k v[63 - k], c = -a1 (approximate on purpose)
@@ -2503,8 +2641,12 @@ struct Flow
         const int x = 64 * t + 768 - hal;                // = (number of blocks completed) * n256 when this is such a tile
         if (x >= 0)
         {
-          const int q = x / n256;
-          if (q * n256 == x)
+          // (behind an opaque copy: left alone the compiler keeps the division's reciprocal -- and the lane's addresses of
+          //  the end-of-stream block below -- in vector registers for the whole stream, which the tile's 64 do not leave room for)
+          int nn = n256;
+          asm volatile("" : "+s"(nn));
+          const int q = x / nn;
+          if (q * nn == x)
           {
             const uint32_t b = b_first + (uint32_t)q;    // the block this value stands in front of
             if (q == 0)
@@ -2541,13 +2683,15 @@ struct Flow
             reinterpret_cast<uint32_t *>(so->wb_s)[0] = fs0;
             reinterpret_cast<uint32_t *>(so->wb_s)[1] = fs1;
           }
-          if (lane < 4)
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          if (ln < 4)
           {
-            reinterpret_cast<uint32_t *>(so->wb_u)[lane] = uring[(8 * n_tiles - 4 + lane) & (kFUDw - 1)];
+            reinterpret_cast<uint32_t *>(so->wb_u)[ln] = uring[(8 * n_tiles - 4 + ln) & (kFUDw - 1)];
           }
-          if (lane < 19)
+          if (ln < 19)
           {
-            reinterpret_cast<uint32_t *>(so->wb_v)[lane] = vring[(2 * n_tiles - 19 + lane) & (kFVDw - 1)];
+            reinterpret_cast<uint32_t *>(so->wb_v)[ln] = vring[(2 * n_tiles - 19 + ln) & (kFVDw - 1)];
           }
           if (local)
           {
@@ -2561,13 +2705,13 @@ struct Flow
               lds_st(&finl[132], fs0);
               lds_st(&finl[133], fs1);
             }
-            if (lane < 4)
+            if (ln < 4)
             {
-              lds_st(&finl[134 + lane], uring[(8 * n_tiles - 4 + lane) & (kFUDw - 1)]);
+              lds_st(&finl[134 + ln], uring[(8 * n_tiles - 4 + ln) & (kFUDw - 1)]);
             }
-            if (lane < 20)
+            if (ln < 20)
             {
-              lds_st(&finl[138 + lane], lane < 19 ? vring[(2 * n_tiles - 19 + lane) & (kFVDw - 1)] : 0u);
+              lds_st(&finl[138 + ln], ln < 19 ? vring[(2 * n_tiles - 19 + ln) & (kFVDw - 1)] : 0u);
             }
           }
         }
@@ -2579,6 +2723,20 @@ struct Flow
       }
       flow_hold_up(P, 6, g);
       SVC_MARK(9)
+    }
+    // Out of generations: help with the stream's last one (coop_quarters), once its wave says that its rows can be read
+    if ((HRFD_FLOW_COOP == 1) && SVC >= 2 && fail_code == 0u && n_gens > 0 && !(HRFD_ABLATE & 1024))   // (2: no helpers, bring-up)
+    {
+      FlowSpin sp;
+      while (lds_ld(&ctl[kCtlCoopOpen]) != (uint32_t)n_gens && lds_ld(&ctl[kCtlCoopNext]) != 15u && !sp.expired(P, ctl, fail_code, 13))
+      {
+        __builtin_amdgcn_s_sleep(4);
+      }
+      lds_order();
+      if (fail_code == 0u && lds_ld(&ctl[kCtlCoopOpen]) == (uint32_t)n_gens)
+      {
+        coop_quarters<true>(n_gens - 1, theta_in, p_in);
+      }
     }
     FLOW_TIME_MAX(45)
 #ifdef HRFD_FLOW_PROBE

@@ -93,6 +93,10 @@ __device__ __forceinline__ uint32_t lane63(uint32_t v)
 // ONE packed shift (v_pk_lshrrev_b16: the fields cannot leak into each other, nothing to mask), stage 3's constant rides
 // on the three-input add that forms T, and the doubled centre tap of stage 3 on a shift-and-add.
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+// (the packed forms below wrap modulo 2^16 per field on purpose: UNSIGNED fields, for which that is defined -- signed
+//  ext-vector arithmetic would be undefined on overflow; the same v_pk_mad_u16 / v_pk_sub_u16 are emitted)
+__device__ __forceinline__ us2 as_us2(uint32_t u) { return __builtin_bit_cast(us2, u); }
+__device__ __forceinline__ uint32_t as_u32u(us2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ uint32_t pk_shr(uint32_t v, unsigned short k)
 {
   return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, v) >> k));
@@ -101,7 +105,7 @@ __device__ __forceinline__ uint32_t pk_shr(uint32_t v, unsigned short k)
 __device__ __forceinline__ uint32_t hb2_sum(uint32_t a, uint32_t b2, uint32_t c)
 {
   const uint32_t t = a + c;
-  const uint32_t k = pk_shr(as_u32(as_s2(t) * (short)57 + (short)1792), 13);    // 0..3 per field
+  const uint32_t k = pk_shr(as_u32u(as_us2(t) * (unsigned short)57 + (unsigned short)1792), 13);    // 0..3 per field
   return t + b2 + k;
 }
 // b = b' (the centre tap as the previous stage's output, NOT doubled).  T' = T + (-8 + 4*256) per field feeds the
@@ -109,7 +113,7 @@ __device__ __forceinline__ uint32_t hb2_sum(uint32_t a, uint32_t b2, uint32_t c)
 __device__ __forceinline__ uint32_t hb3_sum(uint32_t a, uint32_t b, uint32_t c)
 {
   const uint32_t t = a + c + 0x03f803f8u;
-  const uint32_t k = pk_shr(as_u32(as_s2(t) * (short)29 + (short)38888), 10);   // 2..17 per field
+  const uint32_t k = pk_shr(as_u32u(as_us2(t) * (unsigned short)29 + (unsigned short)38888), 10);   // 2..17 per field (modulo 2^16: unsigned fields, defined wrap-around)
   return ((b << 1) + t) + k;
 }
 // a stage-2 sum (<= 1023 per field) as the next stage's tap y'
@@ -1897,14 +1901,14 @@ __device__ __forceinline__ uint32_t mix_fs4_const(uint32_t y3)
   }
   if (ROT == 2)
   {
-    return as_u32(as_s2(0x01000100u) - as_s2(y3)) & 0x00ff00ffu;
+    return as_u32u(as_us2(0x01000100u) - as_us2(y3)) & 0x00ff00ffu;
   }
-  const s2 sw = as_s2(__builtin_amdgcn_alignbit(y3, y3, 16));
+  const us2 sw = as_us2(__builtin_amdgcn_alignbit(y3, y3, 16));
   if (ROT == 1)
   {
-    return as_u32(sw * s2{(short)-1, (short)1} + s2{(short)256, (short)0}) & 0x00ff00ffu;
+    return as_u32u(sw * us2{(unsigned short)0xffff, (unsigned short)1} + us2{(unsigned short)256, (unsigned short)0}) & 0x00ff00ffu;
   }
-  return as_u32(sw * s2{(short)1, (short)-1} + s2{(short)0, (short)256}) & 0x00ff00ffu;
+  return as_u32u(sw * us2{(unsigned short)1, (unsigned short)0xffff} + us2{(unsigned short)0, (unsigned short)256}) & 0x00ff00ffu;
 }
 
 struct QuadCarry

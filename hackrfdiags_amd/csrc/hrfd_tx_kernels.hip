@@ -1251,7 +1251,7 @@ __device__ __forceinline__ void pr_add(float &x, const float w, const float st)
   "global_store_dwordx4 %[voff], v[76:79], s[42:43] offset:4\n" \
   "s_mov_b64 exec, s[52:53]\n" \
   "global_store_dwordx3 %[voff], v[76:78], s[42:43] offset:4\n" \
-  "s_mov_b64 exec, -1\n" \
+  "s_mov_b64 exec, s[54:55]\n" \
   "4:\n"
 
 // w: the accumulator in front of the run in (lane 15 of the row is the one that counts: the first add takes it into lane
@@ -1264,6 +1264,7 @@ __device__ __forceinline__ uint32_t pr_pipeline(float &w, float (&held)[4], bool
   const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)nchunks);
   uint32_t done, flag;
   asm volatile(
+      "s_mov_b64 s[54:55], exec\n"                          // (the last chunk's stores mask lanes: the entry mask comes back behind them)
       "s_mov_b32 s40, 0\n"
       "s_mov_b32 s41, 0\n"
       "s_sub_u32 s44, %[n], 1\n"
@@ -1309,7 +1310,7 @@ __device__ __forceinline__ uint32_t pr_pipeline(float &w, float (&held)[4], bool
       "s_mov_b32 %[flag], s41\n"
       : [w] "+v"(w), [h0] "=&v"(held[0]), [h1] "=&v"(held[1]), [h2] "=&v"(held[2]), [h3] "=&v"(held[3]), [done] "=&s"(done), [flag] "=&s"(flag)
       : [voff] "v"(voff), [b0] "s"(b0), [b1] "s"(b1), [n] "s"(n)
-      : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s51", "s52", "s53",
+      : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s51", "s52", "s53", "s54", "s55",
         "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
         "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
         "v80", "v81", "v82");
@@ -1322,7 +1323,11 @@ __device__ __forceinline__ uint32_t pr_pipeline(float &w, float (&held)[4], bool
 #undef HRFD_PR_LANE
 #undef HRFD_PR_WRAP
 
-// steps: a multiple of 64, and 4 * row_stride cells must fit a 32-bit byte offset (the host sees to both).
+// steps: a multiple of 64, and 4 * row_stride cells must fit a 32-bit byte offset (the host sees to both).  row_stride
+// need NOT be a multiple of four cells: the FM modulator's time slices pass the call's length (4163 in the tests), so a
+// channel's row may start on any 4-byte boundary and the 16-byte loads and stores here (and the stores' offset:4) rely on
+// gfx9's unaligned access mode for global memory (SH_MEM_CONFIG.alignment_mode = unaligned: what ROCm runs compute queues
+// in).  tests/test_gpu_tx_nco.py::test_fm_modulator_time_slices keeps an odd stride with five channels.
 // The call is a sequence of RUNS: the pipeline as far as it gets, then -- in front of a chunk it refuses, or while the
 // accumulator is above pi -- one chunk with the reference's loops in the same arrangement, then the pipeline again.
 // A run writes exactly its own cells: lane 15 of its last chunk keeps its last value (the accumulator for the run behind:
