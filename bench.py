@@ -903,6 +903,12 @@ def also_lines(api, shard, device, args):
         r = measure_mod(api, shard, device, None, wl, C, 16, K, W, settle, 0, 1, extras=False)
         out[name] = brief(r, f"{C} {r['kname']} modulator channels, 16 blocks of 512 PCM samples per step"
                           + (" (BASELINE config 5)" if wl == "ssbmod" else ""), {"steps": K, "warmup": W, "settle_steps": settle, "name": name})
+    # The WBFM modulator's phase recurrence is serial per channel and costs the same 3.2 ms for 64 or 8192 channels
+    # (DESIGN.md 3.3): 1024 channels is the WORST point to quote its per-GPU throughput at.  What a chip-filling bank
+    # reaches (32 GiB of IQ per step; the recurrence runs two waves per SIMD, the passes around it are what takes the time):
+    r = measure_mod(api, shard, device, None, "wbfmmod", 8192, 16, 6, 2, 4, 0, 1, extras=False)
+    out["wbfmmod_8192x16"] = brief(r, "8192 WBFM modulator channels, 16 blocks of 512 PCM samples per step (the largest bank "
+                                      "k_phase_rows takes: 32 GiB of IQ out per step)", {"steps": 6, "warmup": 2, "settle_steps": 4, "name": "wbfmmod_8192x16"})
     # What the fallbacks cost: shapes the flow kernels do not take run on the round-1/2 block kernels
     # (one workgroup per channel-block, k_rx_finish behind them).
     r = measure_rx(api, shard, device, None, **{**common, "workload": "am", "C": 32, "B": 16, "signal": "fmtone"})

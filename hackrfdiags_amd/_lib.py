@@ -89,6 +89,7 @@ def load() -> C.CDLL:
     L.hrfd_rx_debug_atan_eval.argtypes = [_vp, _f32p]
     L.hrfd_rx_debug_atan_eval_tab.argtypes = [_vp, _f32p]
     L.hrfd_rx_debug_atan_eval_quad.argtypes = [_vp, _f32p]
+    L.hrfd_debug_atan2_quadrant.argtypes = [_u32p, _i32p]
     L.hrfd_rx_debug_counters.argtypes = [_vp, _u32p]
     L.hrfd_rx_debug_set_stagger.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_expire.argtypes = [_vp, C.c_int]

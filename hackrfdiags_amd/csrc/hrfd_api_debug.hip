@@ -40,6 +40,19 @@ extern "C" int hrfd_rx_debug_atan_eval_tab(hrfd_rx *h, float *out65536)
 {
   return atan_eval(h, out65536, true);
 }
+// host only (no device needed): the first-quadrant table as hrfd_rx_create builds and proves it (build_atan_quadrant):
+// out[16644] words, *ok = the proof's verdict on this host's libm
+extern "C" int hrfd_debug_atan2_quadrant(uint32_t *out16644, int *ok)
+{
+  if (out16644 == nullptr || ok == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_debug_atan2_quadrant: NULL");
+  }
+  std::vector<float> lut(65536);
+  build_atan2(lut.data());
+  *ok = build_atan_quadrant(lut.data(), out16644) ? 1 : 0;
+  return HRFD_OK;
+}
 // ... and the first-quadrant table of the re-split flow kernel (theta_quad)
 extern "C" int hrfd_rx_debug_atan_eval_quad(hrfd_rx *h, float *out65536)
 {

@@ -32,6 +32,8 @@ int hrfd_rx_debug_timing_every(hrfd_rx *h, int n);
 int hrfd_rx_debug_atan_eval(hrfd_rx *h, float *out65536);
 int hrfd_rx_debug_atan_eval_tab(hrfd_rx *h, float *out65536);
 int hrfd_rx_debug_atan_eval_quad(hrfd_rx *h, float *out65536);   /* first-quadrant table (the re-split WBFM flow kernel) */
+/* host only: that table as hrfd_rx_create builds it (16644 words) and the verdict of its proof against hrfd_atan2_table() */
+int hrfd_debug_atan2_quadrant(uint32_t *out16644, int *ok);
 /* per-workgroup cycle stamps of k_rx_wbfm (probe builds); the cross-block check values of the latest launch */
 int hrfd_rx_debug_stamps(hrfd_rx *h, uint32_t cap_groups, unsigned long long *host_out);
 int hrfd_rx_debug_chk(hrfd_rx *h, float *pub, float *spec, uint32_t n);
