@@ -45,7 +45,10 @@ import torch  # noqa: E402
 BLOCK = 262144
 # untimed launches in front of the timed region, at least (clock settling); HRFD_BENCH_SETTLE=0 for counter passes,
 # where every dispatch is serialized by the profiler and the clock is not what is measured
-SETTLE_STEPS = int(os.environ.get("HRFD_BENCH_SETTLE", "100"))
+# (round 5: 160, was 100 -- profiles/r5_clock_ramp.txt: consecutive regions of 20 launches from a cold start run at 0.253,
+#  0.251, 0.227, 0.215, 0.210, 0.207 and from the seventh on 0.2057 +- 0.0007 ms per launch: the governor takes ~140
+#  launches, 30 ms of this load, and a timed region that starts at launch 100 still carries 0.7 % of the ramp)
+SETTLE_STEPS = int(os.environ.get("HRFD_BENCH_SETTLE", "160"))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 

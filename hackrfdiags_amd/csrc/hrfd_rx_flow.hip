@@ -55,6 +55,13 @@
 #ifndef HRFD_FLOW_SVC_WB
 #define HRFD_FLOW_SVC_WB 6          /* service waves of the re-split WBFM kernel (they do a third of the work now) */
 #endif
+// MEASURED AS NOTHING and left off: the stream waves requesting their first unit BEFORE the workgroup's barriers and state
+// loads (two memory round trips to the first sample instead of five: profiles/r5_flow_early_ab_NOTHING.txt, 0.2061 against
+// 0.2065 ms at 256 channels, 0.7984 against 0.7967 at 1024, alternating runs) -- the service waves have nothing to do for
+// the first generation's 3 us either way.  The waves' FIRST units are fixed (wave - SVC) in both builds.
+#ifndef HRFD_FLOW_EARLY
+#define HRFD_FLOW_EARLY 0
+#endif
 #ifndef HRFD_FLOW_RING2
 #define HRFD_FLOW_RING2 512         /* its ring, in tiles of 64 samples (a power of two; 256: -1.8 %, profiles/r5_flow_split_ab_4_prio_ring.txt) */
 #endif
@@ -599,13 +606,21 @@ struct Flow
     wt = P.warm_tiles, M = P.seed_terms;
     st = P.state + c;
     so = P.state_out + c;
+    t_kernel = __builtin_readcyclecounter();
+    waited = 0;
+    fail_code = 0;                                // which wait expired, if any (diagnostics)
+    return true;
+  }
+
+  // The second half of the set-up: the channel's configuration, control words and carried pipelines into LDS, and the
+  // kernel's only two workgroup barriers.  Every wave calls it exactly once: the service waves at their start, the stream
+  // waves in front of (or, -DHRFD_FLOW_EARLY=1, behind) the requests for their first unit
+  __device__ __forceinline__ void setup_lds()
+  {
     cfg = P.cfg[c];
     kgain = cfg.gain_wbfm / 75000.0f;                // K = (gain/75000)*32767 in float, that order (WbFmDemodulator.cc:392-395)
     kgain = kgain * 32767.0f;
     small_y = fabsf(kgain) * 3.3f < 2147483000.0f;   // |y| <= |K| pi: the int32 cast cannot overflow
-    t_kernel = __builtin_readcyclecounter();
-    waited = 0;
-    fail_code = 0;                                // which wait expired, if any (diagnostics)
     FLOW_TIME_SET(42)
 
     // tables and control words
@@ -627,7 +642,9 @@ struct Flow
     }
     else if (tid >= 768 && tid < 800)
     {
-      ctl[tid - 768] = 0u;
+      // (ctl[0], the next unit: the stream waves' FIRST units are fixed -- wave - SVC, requested before this barrier --
+      //  and the counter starts behind them; GATED: everything is taken from the counter)
+      ctl[tid - 768] = (tid == 768 && kWb && !GATED) ? (uint32_t)(kWaves - SVC) : 0u;
     }
 
     else if (tid >= 800 && tid < 808)
@@ -717,7 +734,7 @@ struct Flow
       {
         gctl[2] = 0u;                                       // AM / SSB: generations through their 8 kS/s recurrence
         gctl[3] = 0u;                                       // SSB: generations whose 8 kS/s rails are in their rings
-        ctl[0] = 1u;                                        // the stream waves start with unit 1
+        ctl[0] = 1u + (GATED ? 0u : (uint32_t)(kWaves - SVC));   // the stream starts with unit 1; the waves' first units are fixed (see above)
         uflag[0] = 1u;                                      // unit 0, the history, is in the ring
         thfin[0] = thfin[1] = thfin[2] = thfin[3] = 0u;
       }
@@ -728,8 +745,6 @@ struct Flow
     }
     __syncthreads();                                       // the only workgroup barriers of the kernel
     FLOW_TIME_SET(43)
-
-    return true;
   }
 
   // ------------------------------------------------------------------------------------------ stream waves
@@ -738,7 +753,6 @@ struct Flow
     // =================================================================== stream waves: raw IQ -> v
     StreamCtx X;
     X.P = &P;
-    X.kgain = kgain;
     X.atc = atcorr;
     X.ati = att0;
     X.lane = lane;
@@ -840,14 +854,6 @@ struct Flow
 #else
 #define VM_WAIT(n, ...) asm volatile("s_waitcnt vmcnt(" #n ")" : __VA_ARGS__ : : "memory")
 #endif
-    // the carried state of a stream that continues the previous call, read once, long before the loop
-    const uint32_t theta_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(st->wb_theta));
-    const uint32_t p_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(st->wb_p));
-    uint32_t tail_in[4];
-    for (int i = 0; i < 4; i++)
-    {
-      tail_in[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t *>(st->fe_tail)[i]);
-    }
     // lane constant: where this lane's four samples of a piece go (tile lane / 16 of the piece, 4 (lane % 16) inside)
     const int lane_dw = kSplit ? kFStride2 * (lane >> 4) + ((2 * lane) & 31)   // re-split: one dword per PAIR of samples, bytes i0 q0 i1 q1
                         : kWb  ? kFStride * (lane >> 4) + ((4 * lane) & 63)    // one dword per sample
@@ -886,7 +892,14 @@ struct Flow
       }
       pend = false;
     };
-    int u = grab();
+    // The wave's FIRST unit is fixed (wave - SVC: ctl[0] starts behind these) and requested BEFORE the workgroup's barriers
+    // and the state's loads (setup_lds, below): a workgroup's first raw bytes are in flight one memory round trip into
+    // its life.  GATED: the units come from the list of allowed blocks, which setup() has built; everything from the counter.
+    if (GATED || !HRFD_FLOW_EARLY)
+    {
+      setup_lds();
+    }
+    int u = GATED ? grab() : (kWb ? 0 : 1) + (wave - SVC);
     u32x4 qa[4], qb[4], c16;
     for (int j = 0; j < 4; j++)
     {
@@ -910,6 +923,18 @@ struct Flow
         store_nothing();
       }
     }
+    // the carried state of a stream that continues the previous call: requested behind the unit, looked at behind the barriers
+    const float th_v = st->wb_theta, p_v = st->wb_p;
+    const uint4 tailv = *reinterpret_cast<const uint4 *>(st->fe_tail);
+    if (!GATED && HRFD_FLOW_EARLY)
+    {
+      setup_lds();
+    }
+    X.kgain = kgain;
+    const uint32_t theta_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(th_v));
+    const uint32_t p_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(p_v));
+    const uint32_t tail_in[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)tailv.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)tailv.y),
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)tailv.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)tailv.w)};
     while (u < n_units)
     {
       FLOW_MARK(0)
@@ -1195,6 +1220,7 @@ struct Flow
   // --------------------------------------------------------------------------- service waves, FIR modes
   __device__ __forceinline__ void service_waves_fir()
   {
+    setup_lds();                                         // (the stream waves call it behind their first requests)
     // =================================================================== service waves, FIR modes: rails -> PCM
     // Generations of 64 tiles as for WBFM, one tile (64 samples of both rails) per lane:
     //   a. the lane's tile through the FIRST decimator, straight out of the ring with the few samples of the tile in
@@ -1681,6 +1707,7 @@ struct Flow
   // -------------------------------------------------------------------------------- service waves, WBFM
   __device__ __forceinline__ void service_waves_wbfm()
   {
+    setup_lds();                                         // (the stream waves call it behind their first requests)
     // =================================================================== service waves: v -> PCM
     __builtin_amdgcn_s_setprio(HRFD_FLOW_SVC_PRIO);      // long dependent chains, few issue slots
     const float a1 = DEEMPH_A1;
@@ -2199,6 +2226,7 @@ struct Flow
   // --------------------------------------------------------------- service waves, WBFM, re-split (round 5)
   __device__ __forceinline__ void service_waves_wbfm2()
   {
+    setup_lds();                                         // (the stream waves call it behind their first requests)
     // =================================================================== service waves: (q, i) pairs -> PCM
     // A generation is 64 tiles, one per lane, as in service_waves_wbfm -- but the lane makes its tile's v ITSELF, from the
     // ring's (q, i) pairs (theta_quad, wrap, gain, the FIR half of the de-emphasis filter: WbFmDemodulator.cc:404-430,
