@@ -101,6 +101,13 @@ static int mod_free(hrfd_mod *h)
 // Which build of glibc's sinf / cosf does this host run?  x86-64 glibc dispatches between a plain and an -mfma build of
 // the same source; they differ on 34 floats with |x| < 120 (all above 17: tools/proofs/sincosf_glibc.c).  1: the fused
 // build (what an FMA-capable CPU gets), 0: the plain one.  The device restates that one (glibc_sinf / glibc_cosf).
+// MEASURED AND SWITCHED OFF: the FM modulator's cos / sin pass (k_fm_rails) as part of the cascade's stage-0 load
+// (k_mod<FM_PHASE>: VERDICT round 4, item 5).  Bit-exact, but 0.958 ms against 0.940 for the pass on the second stream
+// (profiles/r5_fmmod_fused_ab_LOSES.txt, alternating runs): a tile also makes the rails of the 64 samples of history in
+// front of it, so every cos / sin is evaluated twice, and in the cascade's own waves instead of beside them.
+#ifndef HRFD_FM_FUSED
+#define HRFD_FM_FUSED 0
+#endif
 static int libm_variant()
 {
   auto f = [](uint32_t u) { float x; memcpy(&x, &u, 4); return x; };
@@ -576,9 +583,17 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
       {
         hipLaunchKernelGGL(k_fm_step, dim3(gs), dim3(256), 0, s, B);
         phase_scan(h, reinterpret_cast<uint32_t *>(h->d_phase), (size_t)n_per_channel, (size_t)n_per_channel, h->d_acc, h->n_channels, s);
+        // (round 5: cos / sin, x 16000 and the narrowing happen in the cascade's stage-0 load -- k_mod<FM_PHASE> reads the
+        //  phases; rounds 1-4 ran a pass of its own, k_fm_rails, in front)
+#if HRFD_FM_FUSED
+        M.in = reinterpret_cast<const int16_t *>(h->d_phase);
+        M.libm_fma = libm_variant();
+        hipLaunchKernelGGL(k_mod<HRFD_MOD_FM_PHASE>, dim3(grid), dim3(kModThreads), 0, s, M);
+#else
         hipLaunchKernelGGL(k_fm_rails, dim3(gs), dim3(256), 0, s, B);
         M.in = h->d_rails;
         hipLaunchKernelGGL(k_mod<HRFD_MOD_RAILS>, dim3(grid), dim3(kModThreads), 0, s, M);
+#endif
       }
       else
       {
@@ -601,18 +616,23 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
           const uint32_t lo = cut[k], len = cut[k + 1] - lo;
           // (the slices' recurrences follow each other in stream order: the accumulators carry over in d_acc)
           phase_scan(h, reinterpret_cast<uint32_t *>(h->d_phase) + lo, (size_t)len, (size_t)n_per_channel, h->d_acc, h->n_channels, h->s_scan);
+#if !HRFD_FM_FUSED
           B.lo = lo;
           B.len = len;
           hipLaunchKernelGGL(k_fm_rails, dim3((uint32_t)(((size_t)len * h->n_channels + 255) / 256)), dim3(256), 0, h->s_scan, B);
+#endif
           HIP_TRY(hipEventRecord(h->ev_scan[k], h->s_scan));
         }
-        M.in = h->d_rails;
+        // (round 5: no k_fm_rails beside the cascade any more -- the cascade's stage-0 load makes the rails from the phases)
+        M.in = HRFD_FM_FUSED ? reinterpret_cast<const int16_t *>(h->d_phase) : h->d_rails;
+        M.libm_fma = libm_variant();
         for (int k = 0; k < 3; k++)
         {
           HIP_TRY(hipStreamWaitEvent(s, h->ev_scan[k], 0));
           M.tile0 = cut[k] / kModTile;
           M.tiles_launch = (cut[k + 1] - cut[k] + kModTile - 1) / kModTile;
-          hipLaunchKernelGGL(k_mod<HRFD_MOD_RAILS>, dim3(groups8 * M.tiles_launch), dim3(kModThreads), 0, s, M);
+          if (HRFD_FM_FUSED) hipLaunchKernelGGL(k_mod<HRFD_MOD_FM_PHASE>, dim3(groups8 * M.tiles_launch), dim3(kModThreads), 0, s, M);
+          else hipLaunchKernelGGL(k_mod<HRFD_MOD_RAILS>, dim3(groups8 * M.tiles_launch), dim3(kModThreads), 0, s, M);
         }
         M.tile0 = 0;
         M.tiles_launch = 0;

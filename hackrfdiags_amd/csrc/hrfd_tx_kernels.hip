@@ -31,6 +31,7 @@ namespace hrfd {
 constexpr int HRFD_MOD_RAILS = 100;     // internal kind: int16 (I,Q) rails in, modulator tables
 constexpr int HRFD_MOD_WB_HEAD = 101;   // WBFM modulator: (pcm, 0) pairs in, rail 0 after stage 5 out (x32)
 constexpr int HRFD_MOD_WB_TAIL = 102;   // WBFM modulator: 256 kS/s (I,Q) rails in, stages 6-8 (x8)
+constexpr int HRFD_MOD_FM_PHASE = 103;  // FM modulator: the Nco PHASE of every 8 kS/s sample in (float), cos / sin -> rails in the stage-0 load (round 5)
 #ifndef HRFD_MOD_TILE
 #define HRFD_MOD_TILE 64
 #endif
@@ -54,6 +55,7 @@ struct ModParams
   const uint32_t *wbtail;   // WB_TAIL: [C][2] the last two (I,Q) rail pairs of the previous call
   uint32_t n;               // input samples per channel
   uint32_t n_channels;
+  int libm_fma;             // FM_PHASE: which build of glibc's sinf / cosf the host has (glibc_sinf)
   uint32_t tile0, tiles_launch;   // this launch covers tiles [tile0, tile0 + tiles_launch) of every channel (tiles_launch 0: all of
                                   // them) -- the WBFM modulator runs its passes in time slices beside the phase recurrence
 };
@@ -200,6 +202,148 @@ __device__ __forceinline__ void wg_loop(const int tid, F &&body)
   }
 }
 
+// ---- glibc 2.35 sinf / cosf, restated (round 5) --------------------------------------------------------------
+// The reference calls cos(float) / sin(float) under <math.h> + `using namespace std`: C++ overload resolution makes
+// that cosf / sinf (Nco.cc:186-199, signals/pm.cc:41-53, fm.cc:44-77; SURVEY 8c).  glibc's are the ARM
+// optimized-routines algorithm (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, s_sincosf_data.c): reduction by
+// pi/2 in double (n = round(x * 2/pi) by an integer trick, x - n * pi/2), then one of two double polynomials, rounded
+// to float once -- deterministic, so it can be the device's arithmetic as well: tools/proofs/sincosf_glibc.c checks
+// this restatement against the host's libm on EVERY float with |x| < 120 (2.2e9 values): 0 mismatches with the
+// fused multiply-adds of the -mfma build that x86-64 glibc dispatches to on an FMA-capable CPU, 34 (all at |x| > 17)
+// without them.  FMA: which of the two the host's libm is -- probed by the host (libm_variant, hrfd_api_tx.hip).
+// Outside the restated range (|x| >= 120, NaN) the double-precision cos / sin rounded to float stand in (never reached:
+// every caller wraps its phase into (-2 pi, 2 pi)).
+struct SinCosTab
+{
+  double c0, c1, c2, c3, c4, s1, s2, s3;
+};
+__device__ __forceinline__ SinCosTab sincos_tab(const bool flip)
+{
+  // __sincosf_table[0] and [1] (the second has the cosine polynomial negated)
+  const double sg = flip ? -1.0 : 1.0;
+  SinCosTab t;
+  t.c0 = sg * 0x1p0;
+  t.c1 = sg * -0x1.ffffffd0c621cp-2;
+  t.c2 = sg * 0x1.55553e1068f19p-5;
+  t.c3 = sg * -0x1.6c087e89a359dp-10;
+  t.c4 = sg * 0x1.99343027bf8c3p-16;
+  t.s1 = -0x1.555545995a603p-3;
+  t.s2 = 0x1.1107605230bc4p-7;
+  t.s3 = -0x1.994eb3774cf24p-13;
+  return t;
+}
+template <bool FMA>
+__device__ __forceinline__ double sc_ma(double a, double b, double c)
+{
+  if (FMA)
+  {
+    return __builtin_fma(a, b, c);
+  }
+  const double p = a * b;                                // (-ffp-contract=off: two roundings)
+  return p + c;
+}
+// sinf_poly (sincosf.h): n even -> the sine polynomial of x, odd -> the cosine polynomial
+template <bool FMA>
+__device__ __forceinline__ float sc_poly(double x, double x2, const SinCosTab &p, int n)
+{
+  if ((n & 1) == 0)
+  {
+    const double x3 = x * x2;
+    const double s1 = sc_ma<FMA>(x2, p.s3, p.s2);
+    const double x7 = x3 * x2;
+    const double s = sc_ma<FMA>(x3, p.s1, x);
+    return (float)sc_ma<FMA>(x7, s1, s);
+  }
+  const double x4 = x2 * x2;
+  const double c2 = sc_ma<FMA>(x2, p.c4, p.c3);
+  const double c1 = sc_ma<FMA>(x2, p.c1, p.c0);
+  const double x6 = x4 * x2;
+  const double c = sc_ma<FMA>(x4, p.c2, c1);
+  return (float)sc_ma<FMA>(x6, c2, c);
+}
+// COS = false: sinf(y); true: cosf(y)
+template <bool FMA, bool COS>
+__device__ __forceinline__ float glibc_sincosf_v(float y)
+{
+  const uint32_t top = (__builtin_bit_cast(uint32_t, y) >> 20) & 0x7ffu;    // abstop12
+  double x = (double)y;
+  if (top >= 0x42fu)                                     // |y| >= 120 (abstop12(120.0f)), infinity, NaN: outside the restated range
+  {
+    return COS ? (float)cos(x) : (float)sin(x);
+  }
+  if (top < 0x3f4u)                                      // |y| < pi / 4 (abstop12(0x1.921FB6p-1f))
+  {
+    if (top < 0x398u)                                    // |y| < 2^-12
+    {
+      return COS ? 1.0f : y;
+    }
+    return sc_poly<FMA>(x, x * x, sincos_tab(false), COS ? 1 : 0);
+  }
+  // reduce_fast: n = round(x * 2/pi) through r = x * (2/pi * 2^24), (int32)r + 2^23 >> 24
+  const double r = x * 0x1.45F306DC9C883p+23;
+  const int n = ((int)r + 0x800000) >> 24;
+  const double hpi = 0x1.921FB54442D18p0;
+  x = FMA ? __builtin_fma(-(double)n, hpi, x) : x - (double)n * hpi;
+  const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign[] = {1, -1, -1, 1}
+  return sc_poly<FMA>(x * s, x * x, sincos_tab((n & 2) != 0), COS ? (n ^ 1) : n);
+}
+// Both at once (the callers always want both): ONE range reduction and one x^2 -- the two polynomials are evaluated
+// exactly as above (glibc's own sincosf_poly shares them the same way), so the pair equals (cosf(y), sinf(y)) bit for bit.
+template <bool FMA>
+__device__ __forceinline__ void glibc_sincosf_pair_v(float y, float &sn, float &cs)
+{
+  const uint32_t top = (__builtin_bit_cast(uint32_t, y) >> 20) & 0x7ffu;
+  double x = (double)y;
+  if (top >= 0x42fu)
+  {
+    sn = (float)sin(x);
+    cs = (float)cos(x);
+    return;
+  }
+  if (top < 0x3f4u)
+  {
+    if (top < 0x398u)
+    {
+      sn = y;
+      cs = 1.0f;
+      return;
+    }
+    const double x2 = x * x;
+    const SinCosTab t = sincos_tab(false);
+    sn = sc_poly<FMA>(x, x2, t, 0);
+    cs = sc_poly<FMA>(x, x2, t, 1);
+    return;
+  }
+  const double r = x * 0x1.45F306DC9C883p+23;
+  const int n = ((int)r + 0x800000) >> 24;
+  const double hpi = 0x1.921FB54442D18p0;
+  x = FMA ? __builtin_fma(-(double)n, hpi, x) : x - (double)n * hpi;
+  const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+  const SinCosTab t = sincos_tab((n & 2) != 0);
+  const double xs = x * s, x2 = x * x;
+  sn = sc_poly<FMA>(xs, x2, t, n);
+  cs = sc_poly<FMA>(xs, x2, t, n ^ 1);
+}
+__device__ __forceinline__ void glibc_sincosf(float y, int fma_variant, float &sn, float &cs)
+{
+  if (fma_variant)
+  {
+    glibc_sincosf_pair_v<true>(y, sn, cs);
+  }
+  else
+  {
+    glibc_sincosf_pair_v<false>(y, sn, cs);
+  }
+}
+__device__ __forceinline__ float glibc_sinf(float y, int fma_variant)
+{
+  return fma_variant ? glibc_sincosf_v<true, false>(y) : glibc_sincosf_v<false, false>(y);
+}
+__device__ __forceinline__ float glibc_cosf(float y, int fma_variant)
+{
+  return fma_variant ? glibc_sincosf_v<true, true>(y) : glibc_sincosf_v<false, true>(y);
+}
+
 template <int KIND>
 __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 {
@@ -209,7 +353,9 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   // INTERP and RAILS take int16 (I,Q) pairs; RAILS (the AM / FM modulators' baseband, produced by
   // k_am_rails / k_fm_rails) runs them through the modulators' stage-1 table, INTERP through
   // interpolateSignal's own
-  constexpr bool kPairs = (KIND == HRFD_MOD_INTERP) || (KIND == HRFD_MOD_RAILS) || (KIND == HRFD_MOD_WB_HEAD);
+  constexpr bool kPairs = (KIND == HRFD_MOD_INTERP) || (KIND == HRFD_MOD_RAILS) || (KIND == HRFD_MOD_WB_HEAD) || (KIND == HRFD_MOD_FM_PHASE);
+  constexpr bool kPhase = (KIND == HRFD_MOD_FM_PHASE);   // the input is [C][n] float phases: Nco::run's cosf / sinf, x 16000, (int16_t) here
+                                                         // (FmModulator.cc:600-612; rounds 1-4: a pass of its own, k_fm_rails, on a second stream)
   constexpr bool kMono = (KIND == HRFD_MOD_WB_HEAD);      // the input is the PCM itself, [C][n]: rail 0, rail 1 is zero (WbFmModulator.cc:389-425)
   const uint32_t tiles = (M.n + kModTile - 1) / kModTile;
   const uint32_t tiles_l = (M.tiles_launch != 0u) ? M.tiles_launch : tiles;
@@ -253,8 +399,18 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   }
   else if (!(HRFD_MOD_ABLATE & 4))                        // (4: TIMING EXPERIMENT ONLY, stages 0 .. 5 skipped)
   {
-    const int16_t *in = M.in + (size_t)c * M.n * ((kPairs && !kMono) ? 2 : 1);
+    const int16_t *in = M.in + (size_t)c * M.n * ((kPairs && !kMono) ? 2 : 1);   // (kPhase: n floats per channel = 2 n int16)
     const int16_t *tin = M.tail_in + (size_t)c * 4 * kModTail;
+    // kPhase: the rail pair of input sample g from its phase
+    auto fm_pair = [&](const int g, int &a, int &b) {
+      const float phase = reinterpret_cast<const float *>(in)[g];
+      float iv, qv;
+      glibc_sincosf(phase, M.libm_fma, qv, iv);
+      iv = iv * 16000.0f;
+      qv = qv * 16000.0f;
+      a = (int)(short)(int)iv;
+      b = (int)(short)(int)qv;
+    };
 
     // ---- stage-0 source: scaled PCM (SSB) or the IQ pair (INTERP), history first
     wg_loop<kModTail + kModTile>(tid, [&](const int t)
@@ -271,6 +427,10 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
         if (kMono)
         {
           a = in[g];
+        }
+        else if (kPhase)
+        {
+          fm_pair(g, a, b);
         }
         else if (kPairs)
         {
@@ -305,6 +465,10 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
         else if (kMono)
         {
           a = in[g];
+        }
+        else if (kPhase)
+        {
+          fm_pair(g, a, b);
         }
         else if (kPairs)
         {
@@ -563,6 +727,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 template __global__ void k_mod<HRFD_MOD_SSB>(const ModParams);
 template __global__ void k_mod<HRFD_MOD_INTERP>(const ModParams);
 template __global__ void k_mod<HRFD_MOD_RAILS>(const ModParams);
+template __global__ void k_mod<HRFD_MOD_FM_PHASE>(const ModParams);
 template __global__ void k_mod<HRFD_MOD_WB_HEAD>(const ModParams);
 template __global__ void k_mod<HRFD_MOD_WB_TAIL>(const ModParams);
 
@@ -573,100 +738,6 @@ namespace hrfd {
 // ---- AM / FM modulator basebands ---------------------------------------
 // AmModulator::modulateSignal (AmModulator.cc:574-612): I = Q = (int16)(((pcm/32768)*m + 1)/2*128*250),
 // float operations in that order.  One thread per sample; rails [C][2n] int16 (I,Q pairs).
-// ---- glibc 2.35 sinf / cosf, restated (round 5) --------------------------------------------------------------
-// The reference calls cos(float) / sin(float) under <math.h> + `using namespace std`: C++ overload resolution makes
-// that cosf / sinf (Nco.cc:186-199, signals/pm.cc:41-53, fm.cc:44-77; SURVEY 8c).  glibc's are the ARM
-// optimized-routines algorithm (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, s_sincosf_data.c): reduction by
-// pi/2 in double (n = round(x * 2/pi) by an integer trick, x - n * pi/2), then one of two double polynomials, rounded
-// to float once -- deterministic, so it can be the device's arithmetic as well: tools/proofs/sincosf_glibc.c checks
-// this restatement against the host's libm on EVERY float with |x| < 120 (2.2e9 values): 0 mismatches with the
-// fused multiply-adds of the -mfma build that x86-64 glibc dispatches to on an FMA-capable CPU, 34 (all at |x| > 17)
-// without them.  FMA: which of the two the host's libm is -- probed by the host (libm_variant, hrfd_api_tx.hip).
-// Outside the restated range (|x| >= 120, NaN) the double-precision cos / sin rounded to float stand in (never reached:
-// every caller wraps its phase into (-2 pi, 2 pi)).
-struct SinCosTab
-{
-  double c0, c1, c2, c3, c4, s1, s2, s3;
-};
-__device__ __forceinline__ SinCosTab sincos_tab(const bool flip)
-{
-  // __sincosf_table[0] and [1] (the second has the cosine polynomial negated)
-  const double sg = flip ? -1.0 : 1.0;
-  SinCosTab t;
-  t.c0 = sg * 0x1p0;
-  t.c1 = sg * -0x1.ffffffd0c621cp-2;
-  t.c2 = sg * 0x1.55553e1068f19p-5;
-  t.c3 = sg * -0x1.6c087e89a359dp-10;
-  t.c4 = sg * 0x1.99343027bf8c3p-16;
-  t.s1 = -0x1.555545995a603p-3;
-  t.s2 = 0x1.1107605230bc4p-7;
-  t.s3 = -0x1.994eb3774cf24p-13;
-  return t;
-}
-template <bool FMA>
-__device__ __forceinline__ double sc_ma(double a, double b, double c)
-{
-  if (FMA)
-  {
-    return __builtin_fma(a, b, c);
-  }
-  const double p = a * b;                                // (-ffp-contract=off: two roundings)
-  return p + c;
-}
-// sinf_poly (sincosf.h): n even -> the sine polynomial of x, odd -> the cosine polynomial
-template <bool FMA>
-__device__ __forceinline__ float sc_poly(double x, double x2, const SinCosTab &p, int n)
-{
-  if ((n & 1) == 0)
-  {
-    const double x3 = x * x2;
-    const double s1 = sc_ma<FMA>(x2, p.s3, p.s2);
-    const double x7 = x3 * x2;
-    const double s = sc_ma<FMA>(x3, p.s1, x);
-    return (float)sc_ma<FMA>(x7, s1, s);
-  }
-  const double x4 = x2 * x2;
-  const double c2 = sc_ma<FMA>(x2, p.c4, p.c3);
-  const double c1 = sc_ma<FMA>(x2, p.c1, p.c0);
-  const double x6 = x4 * x2;
-  const double c = sc_ma<FMA>(x4, p.c2, c1);
-  return (float)sc_ma<FMA>(x6, c2, c);
-}
-// COS = false: sinf(y); true: cosf(y)
-template <bool FMA, bool COS>
-__device__ __forceinline__ float glibc_sincosf_v(float y)
-{
-  const uint32_t top = (__builtin_bit_cast(uint32_t, y) >> 20) & 0x7ffu;    // abstop12
-  double x = (double)y;
-  if (top >= 0x42fu)                                     // |y| >= 120 (abstop12(120.0f)), infinity, NaN: outside the restated range
-  {
-    return COS ? (float)cos(x) : (float)sin(x);
-  }
-  if (top < 0x3f4u)                                      // |y| < pi / 4 (abstop12(0x1.921FB6p-1f))
-  {
-    if (top < 0x398u)                                    // |y| < 2^-12
-    {
-      return COS ? 1.0f : y;
-    }
-    return sc_poly<FMA>(x, x * x, sincos_tab(false), COS ? 1 : 0);
-  }
-  // reduce_fast: n = round(x * 2/pi) through r = x * (2/pi * 2^24), (int32)r + 2^23 >> 24
-  const double r = x * 0x1.45F306DC9C883p+23;
-  const int n = ((int)r + 0x800000) >> 24;
-  const double hpi = 0x1.921FB54442D18p0;
-  x = FMA ? __builtin_fma(-(double)n, hpi, x) : x - (double)n * hpi;
-  const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign[] = {1, -1, -1, 1}
-  return sc_poly<FMA>(x * s, x * x, sincos_tab((n & 2) != 0), COS ? (n ^ 1) : n);
-}
-__device__ __forceinline__ float glibc_sinf(float y, int fma_variant)
-{
-  return fma_variant ? glibc_sincosf_v<true, false>(y) : glibc_sincosf_v<false, false>(y);
-}
-__device__ __forceinline__ float glibc_cosf(float y, int fma_variant)
-{
-  return fma_variant ? glibc_sincosf_v<true, true>(y) : glibc_sincosf_v<false, true>(y);
-}
-
 struct BaseParams
 {
   const int16_t *pcm;       // [C][n]
@@ -732,8 +803,10 @@ __global__ void k_sig_rails(const BaseParams B)
   {
     s = s / 60000.0f;
     s = (float)((double)s * 3.14159265358979323846);
-    const float ci = glibc_cosf(s, B.libm_fma) * 16000.0f;      // pm.cc:41-53: cos(float) is cosf
-    const float sq = glibc_sinf(s, B.libm_fma) * 16000.0f;
+    float cs_, sn_;
+    glibc_sincosf(s, B.libm_fma, sn_, cs_);                  // pm.cc:41-53: cos(float) is cosf
+    const float ci = cs_ * 16000.0f;
+    const float sq = sn_ * 16000.0f;
     vi = (int)ci;
     vq = (int)sq;
   }
@@ -768,8 +841,10 @@ __global__ void k_sig_fm(const BaseParams B)
     {
       theta = (float)((double)theta + two_pi);
     }
-    const float ci = glibc_cosf(theta, B.libm_fma) * 16000.0f;
-    const float sq = glibc_sinf(theta, B.libm_fma) * 16000.0f;
+    float cs_, sn_;
+    glibc_sincosf(theta, B.libm_fma, sn_, cs_);
+    const float ci = cs_ * 16000.0f;
+    const float sq = sn_ * 16000.0f;
     out[k] = ((uint32_t)(int)ci & 0xffffu) | ((uint32_t)(int)sq << 16);
   }
   B.acc[c] = theta;
@@ -1457,7 +1532,8 @@ __global__ void k_fm_rails(const BaseParams B)
     t = c * B.n + B.lo + (t - c * len);
   }
   const float phase = B.phase[t];
-  float iv = glibc_cosf(phase, B.libm_fma), qv = glibc_sinf(phase, B.libm_fma);
+  float iv, qv;
+  glibc_sincosf(phase, B.libm_fma, qv, iv);
   iv = iv * 16000.0f;
   qv = qv * 16000.0f;
   const int i16 = (int)(short)(int)iv, q16 = (int)(short)(int)qv;
@@ -1584,8 +1660,7 @@ __global__ void k_nco(const NcoParams N)
     else
     {
       // Nco::run (:186-199) calls libm cosf/sinf: glibc's algorithm, restated (glibc_cosf: bit for bit)
-      iv = glibc_cosf(phase, N.libm_fma);
-      qv = glibc_sinf(phase, N.libm_fma);
+      glibc_sincosf(phase, N.libm_fma, qv, iv);
     }
     N.i_out[(size_t)c * N.count + k] = iv;
     N.q_out[(size_t)c * N.count + k] = qv;
