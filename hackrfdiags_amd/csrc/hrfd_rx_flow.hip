@@ -546,6 +546,14 @@ struct Flow
     {
       return false;
     }
+#ifdef HRFD_FLOW_XCDSWAP
+    // EXPERIMENT ONLY (profiles/r5_xcd_swap_experiment.txt): does the 4-5 us by which the XCDs with odd numbers trail the
+    // even ones follow the XCD or the channel's place in memory?  Neighbouring channels change places.
+    if ((ci ^ 1u) < P.n_list)
+    {
+      ci ^= 1u;
+    }
+#endif
     c = P.chan_list[ci];
     n256 = (int)P.n256;
     tid = threadIdx.x;
