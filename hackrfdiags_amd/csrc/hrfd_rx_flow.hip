@@ -62,6 +62,21 @@
 #ifndef HRFD_FLOW_EARLY
 #define HRFD_FLOW_EARLY 0
 #endif
+// The stream's LAST generation: behind the last sample nothing else runs on the CU and the generation's wave makes its
+// 64 samples of theta per lane alone (3.5 us at a lone wave's rate).  Theta is a function of the sample alone (no
+// neighbour), so the STREAM waves -- ten of them, each with 8 samples per lane of a unit -- make it for the last
+// generation's units as they pass through and put the floats into a scratch area of the ring (rows that nobody reads or
+// writes any more: the same place HRFD_FLOW_COOP uses); the generation's wave takes them from there and is left with
+// the wrap and the numerator.  Same operations on the same operands: same bits.
+// MEASURED AND SWITCHED OFF (profiles/r5_flow_lasttheta_ab_LOSES.txt, alternating runs): the service tail does fall, from
+// 7.9 to 6.8 us, but 256 channels take the same time (0.2065 against 0.2062 ms) and 1024 channels 1.2 % MORE (0.8047
+// against 0.7952).  Bit-exact, the GPU suite and the stress build pass with it on.
+#ifndef HRFD_FLOW_LASTTHETA
+#define HRFD_FLOW_LASTTHETA 0
+#endif
+#ifndef HRFD_FLOW_RING14
+#define HRFD_FLOW_RING14 384        /* AM / SSB: tiles of their ring (512 fits their LDS: the A/B of profiles/r5_fir_ring_ab.txt) */
+#endif
 #ifndef HRFD_FLOW_RING2
 #define HRFD_FLOW_RING2 512         /* its ring, in tiles of 64 samples (a power of two; 256: -1.8 %, profiles/r5_flow_split_ab_4_prio_ring.txt) */
 #endif
@@ -107,16 +122,19 @@ static_assert(kFRing2 / kFUnitTiles + 16 <= kFEdges2, "unit records must outlive
 static_assert(kFRingTiles == 256 || kFRingTiles == 320 || kFRingTiles == 384, "ring_slot knows these sizes");
 static_assert(kFRingTiles / kFUnitTiles + 16 <= kFEdges, "unit records must outlive the ring");
 
-__device__ __forceinline__ int ring_slot(const int t)
+template <int N>
+__device__ __forceinline__ int ring_slot_n(const int t)
 {
-  if (kFRingTiles == 256)
+  static_assert(N == 256 || N == 320 || N == 384 || N == 512, "ring_slot knows these sizes");
+  if (N == 256 || N == 512)
   {
-    return t & 255;
+    return t & (N - 1);
   }
   const uint32_t h = (uint32_t)t >> 6;                   // t / 64 < 2^15
-  const uint32_t q = (kFRingTiles == 320) ? (h * 0xCCCDu) >> 18 : (h * 0xAAABu) >> 18;   // h / 5, h / 6
-  return t - (int)q * kFRingTiles;
+  const uint32_t q = (N == 320) ? (h * 0xCCCDu) >> 18 : (h * 0xAAABu) >> 18;   // h / 5, h / 6
+  return t - (int)q * N;
 }
+__device__ __forceinline__ int ring_slot(const int t) { return ring_slot_n<kFRingTiles>(t); }
 
 // Hand-offs between the waves of the workgroup go through LDS only.  LDS executes a wave's operations in order
 // and has no cache, so "my LDS accesses so far are done" is all a hand-off needs.  A workgroup-scope fence
@@ -390,9 +408,9 @@ struct FlowLds
   static constexpr int kRails = (MODE == 14) ? 2 : 1;    // AM / SSB keep both rails through all three decimators
   static constexpr int kVDw = (MODE == 14) ? 2 * kFVDw : kFVDw;   // V ring per rail (AM / SSB: four generations, fir service c)
   static constexpr int k8k = (MODE == 14) ? 512 : 4;     // AM / SSB: int16 per rail of the 8 kS/s rings (four generations)
-  static constexpr int kRingTiles = kSplit ? kFRing2 : kFRingTiles;
+  static constexpr int kRingTiles = kSplit ? kFRing2 : (MODE == 14) ? HRFD_FLOW_RING14 : kFRingTiles;
   static constexpr int kStride = kSplit ? kFStride2 : kFStride;
-  static constexpr int kEdges = kSplit ? kFEdges2 : kFEdges;
+  static constexpr int kEdges = (kSplit || kRingTiles > 384) ? kFEdges2 : kFEdges;
   static constexpr int oTq = 0;                          // re-split: the first-quadrant table FIRST (its index is the LDS address)
   static constexpr int oRing = kSplit ? kQuadDwords : 0;
   static constexpr int oAtcorr = oRing + kRingTiles * kStride;
@@ -405,7 +423,7 @@ struct FlowLds
   static constexpr int oRcar = oYs + ((MODE == 14) ? 128 : 4);
   static constexpr int oThfin = oRcar + 4;
   static constexpr int oEdges = oThfin + 4;
-  static constexpr int oUflag = oEdges + (kSplit ? 4 : 4 * kEdges);   // (the re-split kernel has no unit edges)
+  static constexpr int oUflag = oEdges + ((kSplit || MODE != 3) ? 4 : 4 * kEdges);   // (unit edges: the round-4 WBFM build only)
   static constexpr int oParr = oUflag + kEdges;
   static constexpr int oPflag = oParr + kFPRing;
   static constexpr int oCtl = oPflag + 8;
@@ -867,6 +885,7 @@ struct Flow
                         : kWb  ? kFStride * (lane >> 4) + ((4 * lane) & 63)    // one dword per sample
                                : kFStride * (lane >> 4) + ((2 * lane) & 31);   // FIR modes: one dword per PAIR, I rail at 0, Q rail at 32
     int bu0 = hal >> 9, blk = 0;                         // first unit and index (in the run) of the block a unit belongs to
+    bool scratch_ok = false;                             // (HRFD_FLOW_LASTTHETA: the scratch area and the table are there)
     unsigned long long probe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
     (void)probe; (void)tprev;
     // the unit that completes a block (its count came back as upb - 1) finishes the block: block-mean magnitude,
@@ -989,10 +1008,30 @@ struct Flow
           break;                                         // the workgroup is aborting: the channel will be replayed
         }
       }
+      // (re-split, HRFD_FLOW_LASTTHETA) the units of the stream's last generation also leave their thetas: in a scratch
+      // area whose rows belonged to generations <= n_gens - 6 (read by then: kCtlRel), from the table the service waves
+      // have brought (kCtlTab: a stream of one generation gets here before they have)
+      const bool lastgen = kSplit && (HRFD_FLOW_LASTTHETA != 0) && u >= 8 * (n_gens - 1);
+      if (lastgen && !scratch_ok)
+      {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        FlowSpin sp;
+        while (((int)lds_ld(&ctl[kCtlRel]) < n_gens - 5 || lds_ld(&ctl[kCtlTab]) != (uint32_t)SVC) && !sp.expired(P, ctl, fail_code, 14))
+        {
+          __builtin_amdgcn_s_sleep(4);
+        }
+        waited += __builtin_readcyclecounter() - t0;
+        lds_order();
+        if (fail_code != 0u)
+        {
+          break;
+        }
+        scratch_ok = true;
+      }
       finish_block();                                    // of the previous unit
       FLOW_MARK(3)
       // (uniform, and said so: left to itself the compiler computes the row offset per lane with a quarter-rate v_mul_lo_u32)
-      const int slot0 = __builtin_amdgcn_readfirstlane(kSplit ? ((8 * u) & (kFRing2 - 1)) : ring_slot(8 * u));   // NT is a multiple of 8: a unit never wraps
+      const int slot0 = __builtin_amdgcn_readfirstlane(kSplit ? ((8 * u) & (kFRing2 - 1)) : ring_slot_n<Lds::kRingTiles>(8 * u));   // NT is a multiple of 8: a unit never wraps
       uint32_t *dst = ring + slot0 * Lds::kStride + lane_dw;
       uint32_t v[4], mag4, magsum;
       uint32_t iqb[2] = {0u, 0u};
@@ -1145,6 +1184,25 @@ struct Flow
         store_dump(iqb, u, 1);
       }
       magsum += mag4;
+      if (lastgen)
+      {
+        // the lane's eight thetas of this unit, from the ring words it has just stored (LDS executes a wave's operations in
+        // order; here, behind both pieces, the front end's registers are dead: inside them the same code spilled):
+        // tile 8 (u - first unit of the generation) + 4 half + lane / 16 of the generation, samples 4 (lane % 16) .. + 3 of it
+        const int r0 = (64 * (n_gens - 1)) & (kFRing2 - 1);
+        uint32_t *vs = ring + ((r0 >= 384) ? 0 : r0 + 64) * kFStride2;
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+        {
+          const uint2 w = *reinterpret_cast<const uint2 *>(dst + half * 4 * kFStride2);
+          const uint32_t x0 = w.x ^ 0x80808080u, x1 = w.y ^ 0x80808080u;
+          const uint32_t a0 = abs4_s8(x0), a1 = abs4_s8(x1);
+          const float t0 = theta_quad<0>(x0, a0, tquad), t1 = theta_quad<1>(x0, a0, tquad);
+          const float t2 = theta_quad<0>(x1, a1, tquad), t3 = theta_quad<1>(x1, a1, tquad);
+          const int tile = 8 * (u - 8 * (n_gens - 1)) + 4 * half + (lane >> 4);
+          *reinterpret_cast<uint4 *>(vs + tile * kCoopStride + 4 * (lane & 15)) = make_uint4(f2u(t0), f2u(t1), f2u(t2), f2u(t3));
+        }
+      }
       if (kWb && !kSplit)
       {
         e2 = (uint32_t)__builtin_amdgcn_readlane((int)f2u(theta[2]), 63);
@@ -1293,7 +1351,7 @@ struct Flow
         FlowSpin sp;
         for (;;)
         {
-          const bool ok = (uu >= uhi) || lds_ld(&uflag[uu & (kFEdges - 1)]) == (uint32_t)uu + 1u;
+          const bool ok = (uu >= uhi) || lds_ld(&uflag[uu & (Lds::kEdges - 1)]) == (uint32_t)uu + 1u;
           if (__all(ok) || sp.expired(P, ctl, fail_code, 3))
           {
             break;
@@ -1306,8 +1364,8 @@ struct Flow
       {
         break;
       }
-      const uint32_t *tp = ring + ring_slot(t) * kFStride;
-      const uint32_t *hp = ring + ring_slot(t > 0 ? t - 1 : 0) * kFStride;
+      const uint32_t *tp = ring + ring_slot_n<Lds::kRingTiles>(t) * kFStride;
+      const uint32_t *hp = ring + ring_slot_n<Lds::kRingTiles>(t > 0 ? t - 1 : 0) * kFStride;
       uint32_t ud[kRails][8];                            // the lane's 16 first-decimator outputs per rail, packed pairs
       float th[16];                                      // FM: theta of the lane's 16 samples at 64 kS/s
 #pragma unroll
@@ -1666,7 +1724,7 @@ struct Flow
         for (int m = lane; m < kTailPairs; m += 64)
         {
           const int pr = 32 * n_tiles - kTailPairs + m;  // pair index in the stream
-          const uint32_t *sp = ring + ring_slot(pr >> 5) * kFStride + (pr & 31);
+          const uint32_t *sp = ring + ring_slot_n<Lds::kRingTiles>(pr >> 5) * kFStride + (pr & 31);
           const uint32_t ip = sp[0], qp = sp[32];
           tail[m] = (ip & 0xffu) | ((qp & 0xffu) << 8) | (ip & 0x00ff0000u) | ((qp & 0x00ff0000u) << 8);
         }
@@ -2399,6 +2457,32 @@ struct Flow
           th_last = u2f(vs[64 * kCoopStride + lane]);
           p_last = u2f(vs[64 * kCoopStride + 64 + lane]);
         }
+        else if ((HRFD_FLOW_LASTTHETA != 0) && g + 1 == n_gens)
+        {
+          // the stream's last generation: the stream waves have left its thetas in the scratch area (they are in LDS with
+          // the units' flags: a wave's stores are executed in order); what is left is wrap, gain and the filter's FIR half
+          float thp, pp;
+          theta_in_front(prevw, t == 0, theta_in, p_in, thp, pp);
+          const int r0 = t0 & (kFRing2 - 1);
+          const uint32_t *vs = ring + ((r0 >= 384) ? 0 : r0 + 64) * kFStride2;
+          const uint4 *sq = reinterpret_cast<const uint4 *>(vs + lane * kCoopStride);
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+          {
+            const uint4 x4 = sq[i];
+            const float th[4] = {u2f(x4.x), u2f(x4.y), u2f(x4.z), u2f(x4.w)};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+              const float pk = numerator_p<true>(th[k], thp, kgain);
+              v[4 * i + k] = pk + pp;
+              thp = th[k];
+              pp = pk;
+            }
+          }
+          th_last = thp;
+          p_last = pp;
+        }
         else
         {
           float thp, pp;
@@ -2430,7 +2514,9 @@ struct Flow
         float p = __builtin_fmaf(pab.x, cc, pab.y);
         if (first && t == 0)
         {
-          p += deemph_pow(kFT) * y_in;                   // the stream's past, as seen from the end of tile 0
+          float yy = y_in;
+          asm volatile("" : "+s"(yy));                   // (or the product is kept in a vector register for the whole stream: the bank kernel spilled it)
+          p += deemph_pow(kFT) * yy;                     // the stream's past, as seen from the end of tile 0
         }
         parr[t & (kFPRing - 1)] = p;
       }
