@@ -88,8 +88,9 @@ def load() -> C.CDLL:
     L.hrfd_rx_debug_set_atan.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_atan_eval.argtypes = [_vp, _f32p]
     L.hrfd_rx_debug_atan_eval_tab.argtypes = [_vp, _f32p]
-    L.hrfd_rx_debug_atan_eval_quad.argtypes = [_vp, _f32p]
-    L.hrfd_debug_atan2_quadrant.argtypes = [_u32p, _i32p]
+    for name, args in (("hrfd_rx_debug_atan_eval_quad", [_vp, _f32p]), ("hrfd_debug_atan2_quadrant", [_u32p, _i32p])):
+        if hasattr(L, name):                               # (round-5 hooks: an older build named by HRFD_LIB, as tools/flow_ab.sh compares, has none)
+            getattr(L, name).argtypes = args
     L.hrfd_rx_debug_counters.argtypes = [_vp, _u32p]
     L.hrfd_rx_debug_set_stagger.argtypes = [_vp, C.c_int]
     L.hrfd_rx_debug_expire.argtypes = [_vp, C.c_int]
