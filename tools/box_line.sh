@@ -1,5 +1,5 @@
 # one default bench line on this box, reduced to the figures that are compared from box to box
-python bench.py --no-cpu 2>/dev/null | tail -1 | python -c "
+python3 bench.py --no-cpu 2>/dev/null | tail -1 | python3 -c "
 import json, sys
 d = json.loads(sys.stdin.read())
 a = d['also']
