@@ -895,6 +895,9 @@ def also_lines(api, shard, device, args):
     out["mixed_256x16"]["verification"] = r.get("verification")
     # config 4's whole bank on ONE GPU (16 GiB of IQ per launch): the N = 1 point of its strong-scaling curve
     rx("wbfm_4096x16", workload="wbfm", C=4096, B=16, signal="fmtone", steps=10, warmup=3, settle=10)
+    # the headline's 256 channels with 64 blocks per launch (4 GiB; SURVEY 8d: "B >= 16 ... time over >= 64 blocks"): what
+    # the per-launch costs of the 16-block step -- launch hand-over, the XCDs' spread, the service tail -- are worth
+    rx("wbfm_256x64", workload="wbfm", C=256, B=64, signal="fmtone", steps=20, warmup=5, settle=35)
     rx("wbfm_256x16_random", workload="wbfm", C=256, B=16, signal="random")
     # what a caller sees that launches into an idle GPU (the reference's cadence is one block per 64 ms): the driver's
     # own warm-up, no settling launches, after a second of idleness

@@ -35,6 +35,7 @@ one ammod_1024x16 --workload ammod
 one fmmod_1024x16 --workload fmmod
 one wbfmmod_1024x16 --workload wbfmmod
 one wbfm_4096x16 --channels 4096
+one wbfm_256x64 --blocks 64
 one wbfmmod_8192x16 --workload wbfmmod --channels 8192
 python3 - "$O" "$R" $STEPS $WARM <<'PY'
 import csv, glob, collections, json, os, sys
