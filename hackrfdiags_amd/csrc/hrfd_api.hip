@@ -860,8 +860,10 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     if (mode == HRFD_MODE_WBFM)
     {
       // runs of consecutive blocks per workgroup (only a run's first block re-produces the history in front of it):
-      // as long as possible (16) while the launch still fills the chip
-      run_len = (h->run_len > 0) ? (uint32_t)h->run_len : 16u;
+      // as long as possible while the launch still fills the chip -- up to the 64 blocks a workgroup can finish from LDS
+      // (round 5; rounds 2-4 stopped at 16: a 64-block batch of 256 channels was four runs per channel, each with its own
+      // table copy, re-derived history and service tail -- `also.wbfm_256x64` of the bench line)
+      run_len = (h->run_len > 0) ? (uint32_t)h->run_len : 64u;
       run_len = std::min(run_len, n_blocks);
       while (h->run_len <= 0 && run_len > 1 && groups * ((n_blocks + run_len - 1) / run_len) < 256u)
       {

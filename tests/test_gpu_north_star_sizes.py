@@ -33,6 +33,14 @@ def test_wbfm_512_and_1024_channels(oracle, C):
     check_rx_bank_distinct(oracle, api, C, 16, lambda c: WBFM, twin=lambda rx2: rx2.debug_set_stream(0))
 
 
+def test_wbfm_256_channels_batches_of_48_blocks(oracle):
+    """batches longer than 16 blocks: since round 5 a workgroup streams up to 64 blocks of its channel as ONE run (one table
+    copy, no re-derived history, one service tail; rounds 2-4: runs of 16).  256 channels x 48 blocks (3 GiB) per launch,
+    two launches, every channel an input of its own; 48 channels of the whole range against the oracle, the block kernel
+    agreeing on all 256."""
+    check_rx_bank_distinct(oracle, api, 256, 48, lambda c: WBFM, n_check=48, twin=lambda rx2: rx2.debug_set_stream(0))
+
+
 def test_wbfm_1024_channels_all_channels_period_7(oracle):
     """the all-channel property at 1024 channels with a period coprime to the 8 XCDs: equal input => equal output"""
     check_rx_bank_period(oracle, api, 1024, 16, lambda c: WBFM, seed=500)

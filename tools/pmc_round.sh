@@ -13,8 +13,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_$TAG
 mkdir -p $O
 STEPS=6; WARM=2
-one() {   # name, bench args...
+one() {   # name, bench args...   (ONLY=<name>: that workload alone, merged into profiles/latest_pmc_traffic.json of the same device code)
   local name=$1; shift
+  if [ -n "$ONLY" ] && [ "$ONLY" != "$name" ]; then return; fi
   for CNT in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/raw_${name}_$CNT -- \
       python3 $R/bench.py --steps $STEPS --warmup $WARM --no-cpu --no-extras --verify 0 "$@" > $O/${name}_$CNT.json 2> $O/${name}_$CNT.log || echo "FAILED $name $CNT"
@@ -71,6 +72,11 @@ for d in sorted(glob.glob(O + "/raw_*_FETCH_SIZE")):
         w[cnt + "_KiB"] = tot
     if len(w) == 2:
         out["workloads"][name] = w
+if os.environ.get("ONLY"):
+    prev = json.load(open(R + "/profiles/latest_pmc_traffic.json"))
+    assert prev["kernel_code_tag"] == out["kernel_code_tag"], "the summary to merge into is of another device code"
+    prev["workloads"].update(out["workloads"])
+    out = prev
 json.dump(out, open(O + "/pmc_traffic.json", "w"), indent=1)
 with open(O + "/pmc_per_kernel.txt", "w") as f:
     f.write("workload, counter, kernel, dispatches, per step, mean KiB per dispatch\n")
