@@ -845,7 +845,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   const bool flow = flow_shape && n_wb != 0;              // the WBFM channels run on the flow kernel
   const bool fir_shape = flow_shape && h->fir_flow != 0 && n_blocks <= 64u;
   const int kinds = (n_wb != 0) + (n_as != 0) + (n_fm != 0);
-  const bool bank = fir_shape && kinds >= 2 && n_blocks <= 16u && h->fir_flow != 2 && (h->fir_flow > 0 || list_count[9] >= 48u);
+  const bool bank = fir_shape && kinds >= 2 && h->fir_flow != 2 && (h->fir_flow > 0 || list_count[9] >= 48u);
   const bool as_flow = !bank && fir_shape && n_as != 0 && (h->fir_flow > 0 || n_as >= 48u);
   const bool fm_flow = !bank && fir_shape && n_fm != 0 && (h->fir_flow > 0 || n_fm >= 48u);
   const bool may_close = (int64_t)h->wbfm_max_threshold > -42 - (int64_t)gain_db;   // can a WBFM gate close at all? (see below)

@@ -74,6 +74,9 @@
 #ifndef HRFD_FLOW_LASTTHETA
 #define HRFD_FLOW_LASTTHETA 0
 #endif
+#ifndef HRFD_FLOW_FINISH_FIRST
+#define HRFD_FLOW_FINISH_FIRST 1    /* a completed block is finished in front of the iteration's waits (0: behind the ring-space wait, rounds 2-4) */
+#endif
 #ifndef HRFD_FLOW_RING14
 #define HRFD_FLOW_RING14 384        /* AM / SSB: tiles of their ring (512 fits their LDS: the A/B of profiles/r5_fir_ring_ab.txt) */
 #endif
@@ -443,6 +446,7 @@ struct FlowLds
                 (kFinWords % 4) == 0, "16-byte alignment of what is accessed as 128-bit words");
 };
 constexpr int kCtlRel = 24;                     // ctl[]: re-split, generations whose ring rows have been read (released to the stream waves)
+constexpr int kCtlBlk = 29;                     // ctl[29], ctl[30]: one bit per block of the run (<= 64): finished (its magnitude slot and unit count are free again)
 constexpr int kCtlTab = 25;                     // ... service waves that have copied their share of the table
 // The stream's LAST generation is made together: behind the last sample nothing else runs on the CU, and a lane's 64
 // samples of theta / wrap / numerator are 3.5 us of one wave while five service waves idle.  Its tiles are cut into
@@ -542,8 +546,10 @@ struct Flow
     ctl = lds + Lds::oCtl;                    // 0 next unit, 1 generations verified (their v is released), 2 generations complete (U, V, PCM), 3 blocks finished,
                                                             // 4 next generation, 5 waves of the workgroup that are through,
                                                             // 8..23 units done (per block, mod 16)
-    magl = reinterpret_cast<uint32_t (*)[64]>(lds + Lds::oMagl);   // per block (mod 16: more blocks than the ring
-                                             // can span) and lane: sum of the sample magnitudes.  One word per lane: a
+    magl = reinterpret_cast<uint32_t (*)[64]>(lds + Lds::oMagl);   // per block (mod 16: a wave with a unit of block
+                                             // b >= 16 waits for block b - 16 to be finished, kCtlBlk -- blocks of the
+                                             // shortest size are 4 units, sixteen of them no more than the ring spans)
+                                             // and lane: sum of the sample magnitudes.  One word per lane: a
                                              // same-address atomic from 64 lanes becomes a 64-step scalar loop (LLVM's atomic
                                              // optimizer), measured at half of the kernel's time
     dbfs8 = reinterpret_cast<int8_t *>(lds + Lds::oDbfs);   // the reachable part of the dBFS table
@@ -914,6 +920,7 @@ struct Flow
           dbfs = (int32_t)((uint32_t)dbfs - P.gain_db);
           blkout[pend_blk & 63] = mean_mag | ((dbfs >= cfg.threshold) ? 0x80000000u : 0u);
           lds_st(&ctl[8 + pend_slot], 0u);
+          atomicOr(&ctl[kCtlBlk + ((pend_blk >> 5) & 1)], 1u << (pend_blk & 31));   // the slot is block pend_blk + 16's now
           atomicAdd(&ctl[3], 1u);                        // blocks finished
         }
       }
@@ -990,6 +997,12 @@ struct Flow
       cy.theta = (first && u == 0) ? theta_in : 0u;
       cy.p = (first && u == 0) ? p_in : 0u;
       FLOW_MARK(2)
+      // the previous unit's block, if that unit completed it -- in front of every wait of this iteration: a wave that waits
+      // for a block to be finished (below, its magnitude slot) never waits for a wave that is waiting itself
+      if (HRFD_FLOW_FINISH_FIRST)
+      {
+        finish_block();
+      }
       // ring space: the tiles this unit overwrites must not be anybody's warm-up any more
       // (re-split: a generation's rows are free as soon as its service wave has READ them -- kCtlRel -- and nobody reads
       //  a row twice: no slack for warm-ups)
@@ -1028,7 +1041,10 @@ struct Flow
         }
         scratch_ok = true;
       }
-      finish_block();                                    // of the previous unit
+      if (!HRFD_FLOW_FINISH_FIRST)
+      {
+        finish_block();                                  // (where it stood until round 5)
+      }
       FLOW_MARK(3)
       // (uniform, and said so: left to itself the compiler computes the row offset per lane with a quarter-rate v_mul_lo_u32)
       const int slot0 = __builtin_amdgcn_readfirstlane(kSplit ? ((8 * u) & (kFRing2 - 1)) : ring_slot_n<Lds::kRingTiles>(8 * u));   // NT is a multiple of 8: a unit never wraps
@@ -1223,6 +1239,25 @@ struct Flow
           blk++;
         }
         slot = blk & 15;
+        if (blk >= 16)
+        {
+          // The slot was block blk - 16's.  That block's units are 64 or more behind this one -- out of the ring or about
+          // to be -- and the wave that counted its last unit finishes it at the top of its next iteration; only a wave that
+          // was held up for many units' time at that very point is still to come (the stress build does that; blocks of
+          // the shortest size, batches of more than 16).  Until round 5 nothing waited here: the late block's sum and
+          // count took this unit's with them, the run's block count never became whole and the channel was replayed.
+          const int ob = blk - 16;
+          FlowSpin sp;
+          while (((lds_ld(&ctl[kCtlBlk + ((ob >> 5) & 1)]) >> (ob & 31)) & 1u) == 0u && !sp.expired(P, ctl, fail_code, 15))
+          {
+            __builtin_amdgcn_s_sleep(2);
+          }
+          lds_order();
+          if (fail_code != 0u)
+          {
+            break;
+          }
+        }
         atomicAdd(&magl[slot][lane], magsum);
       }
       // LDS executes a wave's operations in order: the flag and the block's unit count go out behind the data

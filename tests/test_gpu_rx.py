@@ -94,7 +94,7 @@ def test_fir_modes_on_the_flow_kernel(oracle, mode):
     the shortest, 17 blocks (more than four generations, ragged last one), three calls (the carried input tail, the FM
     pipelines with the gain of their time, the SSB rails and the dc-removal filter's x[n-1], y[n-1] across calls), a
     gain change between calls, a channel count that is not a multiple of 8, mean magnitudes and n_pcm."""
-    for bb, B in ((262144, 3), (65536, 17), (32768, 5)):
+    for bb, B in ((262144, 3), (65536, 17), (32768, 5), (32768, 45)):
         C = 5
         raw = np.concatenate([synth.make_input("amtone" if c % 2 else "lcg", 210 + c, (3 * B * bb + BLK - 1) // BLK)[: 3 * B * bb]
                               for c in range(C)]).reshape(C, 3 * B, bb)
@@ -126,8 +126,18 @@ def test_mixed_mode_bank(oracle, fir_flow):
     one handle, two calls.  A bank this small is dispatched per mode by default; the hook forces what a bank of 48
     channels or more gets: ONE launch of k_rx_flow_bank, one persistent workgroup per channel, the mode read per
     workgroup (mode NONE keeps its own kernel) -- or, with 0, the block kernels of the FIR modes in front of the flow kernel."""
+    _mixed_bank(oracle, fir_flow, 3)
+
+
+def test_mixed_bank_of_long_batches(oracle):
+    """the same bank with 21 blocks per call: ONE launch of k_rx_flow_bank as well since round 5 (until then a mixed batch of
+    more than 16 blocks went out as a launch per kind), every channel one run of 21 blocks"""
+    _mixed_bank(oracle, 1, 21)
+
+
+def _mixed_bank(oracle, fir_flow, B):
     modes = [AM, FM, WBFM, LSB, USB, NONE, WBFM, AM, FM, USB]
-    C, B = len(modes), 3
+    C = len(modes)
     xs = np.stack([synth.make_input("lcg" if c % 2 else "amtone", 60 + c, 2 * B) for c in range(C)])
     xs = xs.reshape(C, 2 * B, BLK)
     rx = api.Rx(C)
@@ -832,6 +842,30 @@ def test_wbfm_batches_with_ragged_runs(oracle, C, B, bb):
             assert (pcm[c, b, :len(p)] == p).all(), (C, B, bb, c, b)
             assert int(mag[c, b]) == m
     assert rx.debug_counters()[5] == 0
+
+
+@pytest.mark.parametrize("C,B,bb", [(3, 61, 32768), (2, 64, 32768), (2, 40, 65536)])
+def test_wbfm_long_runs_of_short_blocks(oracle, C, B, bb):
+    """ONE run per channel (the hook: what a bank of 256 channels or more gets) of far more than 16 blocks of the
+    shortest sizes the flow kernel takes (four and eight units): the per-block squelch sums live in sixteen slots, and
+    sixteen blocks of four units are no more than the ring spans -- a unit of block b waits for block b - 16 to be
+    finished (round 5; the stress build finds the hole without the wait within seconds).  Two calls."""
+    raw = np.concatenate([synth.make_input("lcg" if c % 2 else "fmtone", 300 + c, (2 * B * bb + BLK - 1) // BLK)[: 2 * B * bb]
+                          for c in range(C)]).reshape(C, 2 * B, bb)
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    rx.debug_set_run_len(64)
+    got = [rx.process_block(np.ascontiguousarray(raw[:, :B]), B), rx.process_block(np.ascontiguousarray(raw[:, B:]), B)]
+    pcm = np.concatenate([g[0] for g in got], axis=1)
+    mag = np.concatenate([g[2] for g in got], axis=1)
+    for c in range(C):
+        o = oracle.rx()
+        o.set_mode(WBFM)
+        for b in range(2 * B):
+            p, m, _, _ = o.process(raw[c, b])
+            assert (pcm[c, b, :len(p)] == p).all(), (C, B, bb, c, b)
+            assert int(mag[c, b]) == m
+    assert rx.debug_counters()[5] == 0, "a launch was not committed"
 
 
 def test_setters_from_a_second_thread(oracle):
