@@ -967,3 +967,56 @@ def test_random_walk_of_calls_against_the_oracle(oracle, seed):
                 p, m, a, _ = orc[c].process(xs[c, b])
                 assert n_pcm[c, b] == len(p) and int(mag[c, b]) == m and bool(allowed[c, b]) == a, (seed, call, c, b, modes[c], bb, B)
                 assert (pcm[c, b, :len(p)] == p).all(), (seed, call, c, b, modes[c], bb, B)
+
+
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(_os.environ.get("HRFD_WALK_SEEDS", "8")))))
+def test_random_walk_of_long_batches(oracle, seed):
+    """The same kind of walk where the first one does not go: batches of 17..64 blocks, the shortest blocks the flow kernels
+    take (32 KiB = four units) among them, small banks FORCED onto the shapes a large bank gets (one run of up to 64 blocks
+    per channel, the FIR modes on the flow kernel, several kinds in ONE launch of k_rx_flow_bank), three calls, state carried
+    across them; one walk in four with squelch thresholds that close gates inside the batches.  A walk without thresholds
+    and with one run per channel must not have needed a single replay (the stress build of the code before the block-slot
+    wait fails 4 of the first 24 walks on exactly that: profiles/r5_walk_long.txt)."""
+    rng = np.random.default_rng(5000 + seed)
+    C = int(rng.integers(2, 11))
+    all_modes = [NONE, AM, FM, WBFM, LSB, USB]
+    modes = [all_modes[int(rng.integers(1, 6))] if rng.random() < 0.9 else NONE for _ in range(C)]
+    if seed % 3 == 0:
+        modes = [WBFM] * C
+    rx = api.Rx(C)
+    run_len = int(rng.choice([0, 16, 64, 64]))
+    rx.debug_set_run_len(run_len)
+    rx.debug_set_fir_flow(int(rng.choice([1, 1, 2, -1])))
+    gates = seed % 4 == 0
+    orc = []
+    for c in range(C):
+        rx.set_mode(modes[c], channel=c)
+        o = oracle.rx(); o.set_mode(modes[c]); orc.append(o)
+    kinds = ["fmtone", "lcg", "amtone", "zeros", "dc_neg", "impulse"]
+    seeds = [int(rng.integers(0, 10000)) for _ in range(C)]
+    ckind = [kinds[int(rng.integers(0, len(kinds)))] if rng.random() < 0.5 else "fmtone" for _ in range(C)]
+    for call in range(3):
+        bb = int(rng.choice([32768, 32768, 65536, 131072, 262144]))
+        B = int(rng.choice([17, 24, 33, 47, 64]))
+        B = min(B, (8 << 20) // bb)                        # (at most 8 MiB per channel and call: the oracle's time)
+        need = (B * bb + BLK - 1) // BLK
+        xs = np.stack([synth.make_input(ckind[c], seeds[c] + 17 * call, need)[:B * bb].reshape(B, bb) for c in range(C)])
+        for c in range(C):
+            r = rng.random()
+            if r < 0.15 and modes[c] != NONE:
+                g = float(rng.choice([1.0, 300.0, 4000.0, 40743.6]))
+                gm = LSB if modes[c] == USB else modes[c]
+                rx.set_gain(gm, g, channel=c); orc[c].set_gain(gm, g)
+            elif r < 0.45 and gates:
+                t = int(rng.choice([-200, -60, -30, -22]))
+                rx.set_threshold(t, channel=c); orc[c].set_threshold(t)
+        pcm, n_pcm, mag, allowed, _ = rx.process_block(xs, B)
+        for c in range(C):
+            for b in range(B):
+                p, m, a, _ = orc[c].process(xs[c, b])
+                assert n_pcm[c, b] == len(p) and int(mag[c, b]) == m and bool(allowed[c, b]) == a, (seed, call, c, b, modes[c], bb, B)
+                assert (pcm[c, b, :len(p)] == p).all(), (seed, call, c, b, modes[c], bb, B)
+    if not gates and run_len == 64:
+        # (a WBFM channel cut into several runs speculates across the cuts: on inputs like a full-scale DC the history
+        #  re-derived in front of a run is not the stream's, the check says so and the channel is replayed -- by design)
+        assert rx.debug_counters()[5] == 0, ("a launch was not committed", seed)
