@@ -974,7 +974,7 @@ def test_random_walk_of_long_batches(oracle, seed):
     """The same kind of walk where the first one does not go: batches of 17..64 blocks, the shortest blocks the flow kernels
     take (32 KiB = four units) among them, small banks FORCED onto the shapes a large bank gets (one run of up to 64 blocks
     per channel, the FIR modes on the flow kernel, several kinds in ONE launch of k_rx_flow_bank), three calls, state carried
-    across them; one walk in four with squelch thresholds that close gates inside the batches.  A walk without thresholds
+    across them; one walk in four with squelch thresholds that close gates inside the batches, the iq dump on in a third of the calls.  A walk without thresholds
     and with one run per channel must not have needed a single replay (the stress build of the code before the block-slot
     wait fails 4 of the first 24 walks on exactly that: profiles/r5_walk_long.txt)."""
     rng = np.random.default_rng(5000 + seed)
@@ -1010,12 +1010,15 @@ def test_random_walk_of_long_batches(oracle, seed):
             elif r < 0.45 and gates:
                 t = int(rng.choice([-200, -60, -30, -22]))
                 rx.set_threshold(t, channel=c); orc[c].set_threshold(t)
-        pcm, n_pcm, mag, allowed, _ = rx.process_block(xs, B)
+        dump = rng.random() < 0.3                          # (`enable iqdump`: the DUMP builds of the kernels, the 256 kS/s stream out as well)
+        pcm, n_pcm, mag, allowed, iq256 = rx.process_block(xs, B, want_iq256=dump)
         for c in range(C):
             for b in range(B):
-                p, m, a, _ = orc[c].process(xs[c, b])
+                p, m, a, d = orc[c].process(xs[c, b])
                 assert n_pcm[c, b] == len(p) and int(mag[c, b]) == m and bool(allowed[c, b]) == a, (seed, call, c, b, modes[c], bb, B)
                 assert (pcm[c, b, :len(p)] == p).all(), (seed, call, c, b, modes[c], bb, B)
+                if dump:
+                    assert (iq256[c, b] == d).all(), (seed, call, c, b, modes[c], bb, B)
     if not gates and run_len == 64:
         # (a WBFM channel cut into several runs speculates across the cuts: on inputs like a full-scale DC the history
         #  re-derived in front of a run is not the stream's, the check says so and the channel is replayed -- by design)
