@@ -419,8 +419,11 @@ __device__ __forceinline__ float theta_quad_word(uint32_t x, uint32_t w)
   const uint32_t t = w & 0x3fffffffu;
   const int32_t fix = (int32_t)w >> 30;
   const uint32_t pv = f2u(kPiF - u2f(t)) + (uint32_t)fix;
-  const bool ineg = (x & (K == 0 ? 0x00000080u : 0x00800000u)) != 0u;
-  const uint32_t mag = ineg ? pv : t;
+  // i < 0 as a mask of 32 bits (one v_bfe_i32) and the choice as a bitfield insert: two instructions where a test, a
+  // compare and a select were three (and a wait state for vcc)
+  uint32_t ineg = (uint32_t)__builtin_amdgcn_sbfe((int32_t)x, (K == 0) ? 7u : 23u, 1u);
+  asm("" : "+v"(ineg));                                  // (seen through, the compiler turns it back into the three)
+  const uint32_t mag = (pv & ineg) | (t & ~ineg);
   // sign of q: bit 15 (sample 0) / bit 31 (sample 1) of x
   const uint32_t sg = (K == 0) ? (x << 16) : x;
   return u2f(__builtin_amdgcn_bitop3_b32(mag, sg, 0x80000000u, 0xF8));   // mag | (sg & 0x80000000): index = 4a + 2b + c
