@@ -183,6 +183,10 @@ extern "C" int hrfd_q15_table(const char *name, int16_t *out, int cap)
 }
 
 // ------------------------------------------------------------------ rx handle
+#ifndef HRFD_BANK_XCD_ORDER
+#define HRFD_BANK_XCD_ORDER 0      /* 1: the mixed bank's WBFM channels on the even XCDs -- MEASURED, NOTHING (profiles/r5_bank_order_ab_NOTHING.txt) */
+#endif
+
 struct hrfd_rx
 {
   int device = 0;
@@ -662,6 +666,27 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
           lists[(size_t)9 * h->n_channels + cnt[9]++] = c;   // list 9: every channel that has a demodulator (k_rx_flow_bank)
         }
       }
+      // List 9 runs as ONE launch, position p on XCD p % 8 (map_unit), a workgroup per channel; the workgroups on the XCDs
+      // with odd numbers are 3-5 % slower than the others in most launches (profiles/r5_xcd_swap_experiment.txt) and in the
+      // mixed bank the WBFM workgroups end ~10 us behind the FIR kinds'.  -DHRFD_BANK_XCD_ORDER=1 puts the WBFM channels on
+      // the even positions: MEASURED AND LEFT OFF -- sixteen WBFM workgroups on an XCD instead of eight run slower by what
+      // the placement was to gain (the XCDs' clocks are managed one by one), the bank takes the same time
+      // (profiles/r5_bank_order_ab_NOTHING.txt).  Which position a channel has changes nothing it computes.
+      {
+        std::vector<uint32_t> heavy, light;
+        for (uint32_t i = 0; i < cnt[9]; i++)
+        {
+          const uint32_t c = lists[(size_t)9 * h->n_channels + i];
+          (h->h_cfg[c].mode == HRFD_MODE_WBFM ? heavy : light).push_back(c);
+        }
+        size_t ih = 0, il = 0;
+        for (uint32_t p = 0; p < cnt[9] && HRFD_BANK_XCD_ORDER; p++)
+        {
+          const bool want_heavy = (p & 1u) == 0u;
+          const bool take_heavy = (want_heavy && ih < heavy.size()) || il >= light.size();
+          lists[(size_t)9 * h->n_channels + p] = take_heavy ? heavy[ih++] : light[il++];
+        }
+      }
       memcpy(h->list_count, cnt, sizeof(cnt));
       h->wbfm_max_threshold = INT32_MIN;
       for (uint32_t c = 0; c < h->n_channels; c++)
@@ -873,7 +898,7 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
     P.run_len = run_len;
     P.n_runs = (n_blocks + run_len - 1) / run_len;
     const uint32_t grid = groups * P.n_runs;
-    P.dbg = (h->d_dbg != nullptr && (size_t)grid * kDbgSlots <= h->dbg_cap && mode >= 0) ? h->d_dbg : nullptr;   // (probe builds: any one mode)
+    P.dbg = (h->d_dbg != nullptr && (size_t)grid * kDbgSlots <= h->dbg_cap) ? h->d_dbg : nullptr;   // (probe builds: one launch per call -- one mode, or the bank)
     P.warm_tiles = std::min(warm_tiles, HRFD_FLOW_WARM_TILES);   // tiles of 64 here (the FIR modes: ring tiles read below a generation)
     P.self_finish = 1;                                     // the last workgroup of a channel finishes it (finish_channel)
     P.dbg_flags |= h->expire_once << 16;
