@@ -453,6 +453,23 @@ def pmc_traffic(name):
     return int(w["FETCH_SIZE_KiB"] * 1024 * 2 + w["WRITE_SIZE_KiB"] * 1024), f"profiles/latest_pmc_traffic.json[{name}], device code {_PMC['kernel_code_tag']}"
 
 
+def issue_summary():
+    """what the headline kernel's SIMDs were doing (tools/valu_probe.sh: rocprofv3's derived VALUBusy / SALUBusy /
+    MemUnitStalled and raw SQ counters, PMC-only passes; committed as profiles/latest_valu_probe.json) -- quoted only when it
+    was taken with THIS device code.  The contract prices the kernel against HBM; these say what it is bound by."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_valu_probe.json")) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if d.get("kernel_code_tag") != kernel_code_tag():
+        return None
+    c = d.get("counters", {})
+    return {"valu_busy_pct": c.get("VALUBusy"), "valu_lane_utilization_pct": c.get("VALUUtilization"), "salu_busy_pct": c.get("SALUBusy"),
+            "mem_unit_stalled_pct": c.get("MemUnitStalled"), "lds_bank_conflict_pct": c.get("LDSBankConflict"),
+            "valu_instructions_per_launch": c.get("SQ_INSTS_VALU"), "source": "profiles/latest_valu_probe.json (" + d.get("how", "") + ")"}
+
+
 def under_profiler():
     """rocprofv3 preloads its tool library into the process: counter passes serialize every dispatch and change the
     clocks, so timings taken there are not comparable with each other (a 32768-workgroup stream kernel suffers more than a
@@ -1137,6 +1154,7 @@ def main():
                 "measured_stream_read_GBps": round(read_gbs, 1),
                 "frac_of_measured_read": round(achieved / read_gbs, 4),
                 "measured_stream_write_GBps": round(write_gbs, 1),
+                "issue": issue_summary() if (args.workload == "wbfm" and C == 256 and B == 16) else None,
                 "kernel": ("hrfd::k_rx_wbfm_flow<4, GATED=false, DUMP=%s, WBFM> (re-split, round 5: one persistent workgroup per CU, "
                            "10 stream waves put (q, i) pairs into a 512-tile LDS ring, 6 service waves do theta (first-quadrant "
                            "table in LDS), wrap, de-emphasis recurrence with the tile's v in registers, integer stages)%s"

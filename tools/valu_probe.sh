@@ -35,5 +35,19 @@ with open(O + "/valu_probe.txt", "w") as out:
             for c, v in sorted(cs.items()):
                 out.write("    %-28s n=%3d mean=%.6g\n" % (c, len(v), sum(v) / len(v)))
 print(open(O + "/valu_probe.txt").read())
+# the summary bench.py quotes in its line (roofline.issue), keyed by the device code like the PMC traffic
+import json
+sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+import bench
+want = ("VALUBusy", "VALUUtilization", "SALUBusy", "MemUnitStalled", "LDSBankConflict", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAVES")
+summ = {}
+txt = open(O + "/valu_probe.txt").read().split("\n")
+for line in txt:
+    f = line.split()
+    if len(f) >= 3 and f[0] in want and f[-1].startswith("mean="):
+        summ[f[0]] = float(f[-1][5:])
+json.dump({"kernel_code_tag": bench.kernel_code_tag(), "kernel": "k_rx_wbfm_flow<4, false, false, 3>, 256 channels x 16 blocks",
+           "how": "tools/valu_probe.sh: rocprofv3 --pmc (derived and raw SQ counters, PMC-only passes of bench.py --steps 6 --warmup 2), mean over the launches", "counters": summ},
+          open(O + "/valu_probe.json", "w"), indent=1)
 PY
 rm -rf $O/raw_*
