@@ -82,6 +82,11 @@ def load() -> C.CDLL:
     L.hrfd_rx_process_device.argtypes = [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                          _vp, _vp, _vp, _vp, _vp, _vp]
     L.hrfd_rx_sync.argtypes = [_vp, _u32p]
+    for name in ("hrfd_rx_pcm_capacity", "hrfd_rx_iq256_capacity", "hrfd_demod_pcm_capacity"):
+        getattr(L, name).argtypes = [C.c_uint32]
+        getattr(L, name).restype = C.c_uint32
+    L.hrfd_rx_pending_samples.argtypes = [_vp, _u32p]
+    L.hrfd_rx_debug_ragged.argtypes = [_vp, _i32p, C.POINTER(C.c_ulonglong)]
     L.hrfd_rx_reduce_sample_rate.argtypes = [_vp, _vp, C.c_uint32, _vp]
     L.hrfd_rx_failed_channels.argtypes = [_vp, C.c_void_p, C.c_uint32]
     L.hrfd_rx_debug_set_warm.argtypes = [_vp, C.c_int]

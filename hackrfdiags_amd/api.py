@@ -15,6 +15,16 @@ ALL = 0xFFFFFFFF
 BLOCK_BYTES = 262144
 
 
+def pcm_capacity(block_bytes: int) -> int:
+    """row length of the PCM output for a block length: ceil(block_bytes / 512) (hrfd_rx_pcm_capacity)"""
+    return (int(block_bytes) + 511) // 512
+
+
+def iq256_capacity(block_bytes: int) -> int:
+    """row length in bytes of the 256 kS/s dump for a block length: 2 * ceil(block_bytes / 16) (hrfd_rx_iq256_capacity)"""
+    return 2 * ((int(block_bytes) // 2 + 7) // 8)
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -58,12 +68,12 @@ class Rx:
         (pcm [C,B,npcm], n_pcm [C,B], magnitude [C,B], allowed [C,B], iq256 [C,B,bb/8] | None)"""
         iq = np.ascontiguousarray(iq, dtype=np.int8).reshape(self.n, n_blocks, -1)
         bb = iq.shape[2]
-        npcm = bb // 512
+        npcm = pcm_capacity(bb)                            # rows: what a call of any even length can complete at most
         pcm = np.zeros((self.n, n_blocks, npcm), dtype=np.int16)
         n_pcm = np.zeros((self.n, n_blocks), dtype=np.uint32)
         mag = np.zeros((self.n, n_blocks), dtype=np.uint32)
         allowed = np.zeros((self.n, n_blocks), dtype=np.uint8)
-        iq256 = np.zeros((self.n, n_blocks, bb // 8), dtype=np.int8) if want_iq256 else None
+        iq256 = np.zeros((self.n, n_blocks, iq256_capacity(bb)), dtype=np.int8) if want_iq256 else None
         check(self.L.hrfd_rx_process_block(self.h, _ptr(iq), bb, n_blocks, self.gain_db, _ptr(pcm),
                                            _ptr(n_pcm), _ptr(mag), _ptr(allowed), _ptr(iq256)),
               "hrfd_rx_process_block")
@@ -73,7 +83,7 @@ class Rx:
         """IqDataProcessor::reduceSampleRate for one block of every channel: iq int8 [C, block_bytes] -> the 256 kS/s
         stream int8 [C, block_bytes / 8] (with the Fs/4 rotation); only the decimator pipelines advance"""
         iq = np.ascontiguousarray(iq, dtype=np.int8).reshape(self.n, -1)
-        out = np.zeros((self.n, iq.shape[1] // 8), dtype=np.int8)
+        out = np.zeros((self.n, iq256_capacity(iq.shape[1])), dtype=np.int8)
         check(self.L.hrfd_rx_reduce_sample_rate(self.h, _ptr(iq), iq.shape[1], _ptr(out)), "hrfd_rx_reduce_sample_rate")
         return out
 
@@ -84,6 +94,13 @@ class Rx:
                                             self.gain_db, _ptr(d_pcm), _ptr(d_n_pcm), _ptr(d_magnitude),
                                             _ptr(d_allowed), _ptr(d_iq256), _ptr(stream)),
               "hrfd_rx_process_device")
+
+    def pending_samples(self) -> int:
+        """IQ samples the front end holds back after the calls so far (0..7): the next call of bb bytes completes
+        (pending + bb // 2) // 8 samples at 256 kS/s (IqDataProcessor::reduceSampleRate's count)"""
+        v = C.c_uint32(0)
+        check(self.L.hrfd_rx_pending_samples(self.h, C.byref(v)), "hrfd_rx_pending_samples")
+        return int(v.value)
 
     def sync(self) -> int:
         """waits for the last process_device; returns the number of channels that did not commit"""
@@ -110,6 +127,12 @@ class Rx:
               self.L.hrfd_rx_debug_atan_eval_tab if tab else self.L.hrfd_rx_debug_atan_eval)
         check(fn(self.h, out.ctypes.data_as(C.POINTER(C.c_float))), "hrfd_rx_debug_atan_eval")
         return out
+
+    def debug_ragged(self):
+        """(the handle left the 512-byte grid, launches that ran on the general-length kernel k_rx_ragged)"""
+        off, n = C.c_int32(0), C.c_ulonglong(0)
+        check(self.L.hrfd_rx_debug_ragged(self.h, C.byref(off), C.byref(n)), "hrfd_rx_debug_ragged")
+        return bool(off.value), int(n.value)
 
     def debug_set_run_len(self, blocks: int):
         """consecutive blocks of a channel per WBFM workgroup (0 = automatic)"""
@@ -194,9 +217,11 @@ class SingleChannelRx:
         self.rx.set_threshold(t)
 
     def process(self, iq):
+        pending = self.rx.pending_samples()
         pcm, n_pcm, mag, allowed, iq256 = self.rx.process_block(iq, 1, want_iq256=True)
         n = int(n_pcm[0, 0])
-        return pcm[0, 0, :n].copy(), int(mag[0, 0]), bool(allowed[0, 0]), iq256[0, 0]
+        n256 = 2 * ((pending + np.asarray(iq).size // 2) // 8)    # decimatedByteCount of this call
+        return pcm[0, 0, :n].copy(), int(mag[0, 0]), bool(allowed[0, 0]), iq256[0, 0, :n256]
 
 
 class Demod:
@@ -230,10 +255,11 @@ class Demod:
         """iq256: int8 [C, bytes] (or flat for C == 1) -> pcm int16 [C, bytes/64]"""
         iq256 = np.ascontiguousarray(iq256, dtype=np.int8).reshape(self.n, -1)
         nb = iq256.shape[1]
-        pcm = np.zeros((self.n, nb // 64), dtype=np.int16)
+        pcm = np.zeros((self.n, (nb + 63) // 64), dtype=np.int16)
         n_pcm = np.zeros(self.n, dtype=np.uint32)
         check(self.L.hrfd_demod_process(self.h, _ptr(iq256), nb, _ptr(pcm), _ptr(n_pcm)), "hrfd_demod_process")
-        assert (n_pcm == nb // 64).all()
+        assert (n_pcm == n_pcm[0]).all()                   # the channels of a handle have seen the same lengths
+        pcm = pcm[:, :int(n_pcm[0])]
         return pcm if self.n > 1 else pcm[0]
 
 
@@ -276,7 +302,7 @@ class Ingest:
         ps = [C.c_void_p() for _ in range(4)]
         check(self.L.hrfd_ingest_collect(self.h, *[C.byref(p) for p in ps]), "hrfd_ingest_collect")
         units = self.C * self.n_blocks
-        npcm = self.block_bytes // 512
+        npcm = pcm_capacity(self.block_bytes)
 
         def view(p, ctype, dtype, count):
             return np.frombuffer((ctype * count).from_address(p.value), dtype=dtype).copy()

@@ -24,6 +24,8 @@ __global__ void k_build_atan_corr(const float *, const float *, uint8_t *, uint3
 template <bool TAB> __global__ void k_atan_eval(const uint8_t *, const float *, float *);
 template <int MODE, bool S256, bool ARITH> __global__ void k_rx_fir(const RxParams);
 template <int MODE> __global__ void k_rx_post(const RxParams);
+__global__ void k_rx_ragged(const RagParams);
+__global__ void k_rag_expand(const ChanState *, RagState *, const float *, const uint32_t);
 __global__ void k_rx_finish(const EpilogueParams);
 } // namespace hrfd
 
@@ -263,6 +265,14 @@ struct hrfd_rx
   int gated_pass = 1;                  // test hook: 0 = no gated second pass on the device (closed gates go back to the host's replay)
   int expire_once = 0;                 // test hook: the next k_rx_wbfm_flow launch treats this wait (1..6) of workgroup 0 as expired
   uint32_t last_counters[kNumCounters] = {0};
+
+  // any block length (hrfd_rx_ragged.hip).  A handle is "on the grid" while every block it was given was a multiple of
+  // 512 bytes (inner API: 64): every commutator of the chain is at 0 between calls and ChanState is the whole state.
+  // The first block of another length takes it off the grid, for good: RagState per channel, every call on k_rx_ragged.
+  bool offgrid = false;
+  bool rag_built = false;              // k_rag_expand has run (ChanState -> RagState)
+  RagState *d_rag = nullptr;
+  uint64_t ragged_launches = 0;        // launches that ran on k_rx_ragged (diagnostic: hrfd_rx_debug_ragged)
 };
 
 static int rx_free(hrfd_rx *h)
@@ -275,7 +285,7 @@ static int rx_free(hrfd_rx *h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void *ptrs[] = {h->d_cfg, h->d_state, h->d_state_out, h->d_lut, h->d_atcorr, h->d_atinv, h->d_atcorr2, h->d_att0, h->d_atquad, h->d_dbfs, h->d_counters,
                   h->d_lists, h->d_sub_lists, h->d_chan, h->d_present, h->d_magnitude, h->d_chk_pub, h->d_chk_spec,
-                  h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq, h->d_dbg};
+                  h->d_iq, h->d_pcm, h->d_iq256, h->d_npcm, h->d_allowed, h->d_mag_out, h->d_ssb_iq, h->d_dbg, h->d_rag};
   for (void *p : ptrs)
   {
     if (p) (void)hipFree(p);
@@ -534,6 +544,29 @@ static int apply_resets(hrfd_rx *h, hipStream_t s, std::vector<std::pair<uint32_
 {
   for (auto &r : resets)
   {
+    if (h->rag_built)
+    {
+      // off the grid the state is RagState: Decimator_int16::resetFilterState (Decimator_int16.cc:131-147) clears the
+      // pipeline AND the commutator position
+      RagState *g = h->d_rag + r.first;
+      switch (r.second)
+      {
+        case HRFD_MODE_WBFM:
+          HIP_TRY(hipMemsetAsync(&g->wb.theta, 0, sizeof(float), s));
+          HIP_TRY(hipMemsetAsync(&g->wb.d1, 0, 3 * sizeof(RagQ15), s));
+          break;
+        case HRFD_MODE_FM:
+          HIP_TRY(hipMemsetAsync(&g->fm, 0, sizeof(RagFm), s));
+          break;
+        case HRFD_MODE_AM:
+          HIP_TRY(hipMemsetAsync(&g->am, 0, sizeof(RagAs), s));
+          break;
+        default:
+          HIP_TRY(hipMemsetAsync(&g->ssb, 0, sizeof(RagAs), s));
+          break;
+      }
+      continue;
+    }
     ChanState *d = h->d_state + r.first;
     switch (r.second)
     {
@@ -579,18 +612,18 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   {
     return fail(HRFD_EINVAL, "hrfd_rx_process: NULL handle or buffer");
   }
-  if (opt.src256)
+  // Lengths.  The reference takes any byteCount (IqDataProcessor.cc:926, DataConsumer.cc:229-241: short transfers are
+  // passed on); what it cannot take is refused here: more than its fixed arrays hold (DataConsumer clips to 262144
+  // before the call, DataConsumer.cc:229-233; the demodulators' members hold 32768 bytes) and odd counts (its Q loop
+  // then reads bufferPtr[byteCount], IqDataProcessor.cc:474: the caller rounds up, as hrfd_shim.cc does).
+  const uint32_t max_bytes = opt.src256 ? 32768u : HRFD_BLOCK_BYTES;
+  if (block_bytes == 0 || (block_bytes & 1u) != 0 || block_bytes > max_bytes)
   {
-    if (block_bytes == 0 || (block_bytes % 128u) != 0 || block_bytes > 32768u)
-    {
-      return fail(HRFD_EINVAL, "256 kS/s input must be a multiple of 128 bytes and <= 32768 (got %u)", block_bytes);
-    }
+    return fail(HRFD_EINVAL, "%s must be even, > 0 and <= %u (got %u)", opt.src256 ? "bytes_per_channel" : "block_bytes",
+                max_bytes, block_bytes);
   }
-  else if (block_bytes == 0 || (block_bytes % 1024u) != 0 || block_bytes > HRFD_BLOCK_BYTES)
-  {
-    return fail(HRFD_EINVAL, "block_bytes must be a multiple of 1024 and <= %u (got %u)",
-                HRFD_BLOCK_BYTES, block_bytes);
-  }
+  // the streaming kernels take whole 1 KiB chunks (inner API: 128 bytes) on a handle that never left the grid
+  const bool ragged = h->offgrid || (block_bytes % (opt.src256 ? 128u : 1024u)) != 0;
   if (n_blocks == 0 || opt.out_b0 + n_blocks > opt.out_blocks)
   {
     return fail(HRFD_EINVAL, "bad block count");
@@ -620,15 +653,15 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   const int ntiles = ((int)n256 + kNeedHist + 1 + kTile - 1) / kTile + sac;
   const int origin = (int)n256 - ntiles * kTile;
   const int hal = (-origin + 63) / 64 * 64;
-  if (ntiles > kMaxTiles)
+  if (!ragged && ntiles > kMaxTiles)
   {
     return fail(HRFD_EINVAL, "internal: %d de-emphasis tiles exceed %d", ntiles, kMaxTiles);
   }
-  if (hal > kMaxHal)
+  if (!ragged && hal > kMaxHal)
   {
     return fail(HRFD_EINVAL, "internal: history %d exceeds %d", hal, kMaxHal);
   }
-  if (n_blocks > 1 && (uint32_t)(hal + 64) * halo_unit > block_bytes)
+  if (!ragged && n_blocks > 1 && (uint32_t)(hal + 64) * halo_unit > block_bytes)
   {
     return fail(HRFD_EINVAL, "blocks of %u bytes are too short for a multi-block call "
                 "(need >= %u); submit them one per call", block_bytes, (uint32_t)(hal + 64) * halo_unit);
@@ -848,6 +881,75 @@ static int rx_launch(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stride, ui
   if (ev_slots)
   {
     HIP_TRY(hipEventRecord(h->ev[2 * ev_slot], s));
+  }
+  if (ragged)
+  {
+    // ---------------------------------------------------------------- any block length: k_rx_ragged
+    // One workgroup per channel, the call's blocks in order, every stage with its commutator position: exact, no
+    // speculation, every channel commits.  A length that is not a whole number of PCM samples (512 bytes; inner API
+    // 64) takes the handle off the grid for good: its state moves from ChanState to RagState (k_rag_expand, once).
+    if ((block_bytes % (opt.src256 ? 64u : 512u)) != 0)
+    {
+      h->offgrid = true;
+    }
+    if (h->offgrid && !h->rag_built)
+    {
+      if (h->d_rag == nullptr)
+      {
+        HIP_TRY(hipStreamSynchronize(s));
+        hipError_t e = hipMalloc((void **)&h->d_rag, sizeof(RagState) * h->n_channels);
+        if (e != hipSuccess)
+        {
+          h->d_rag = nullptr;
+          return fail(HRFD_ENOMEM, "hipMalloc(%zu) failed: %s", sizeof(RagState) * h->n_channels, hipGetErrorString(e));
+        }
+      }
+      HIP_TRY(hipMemsetAsync(h->d_rag, 0, sizeof(RagState) * h->n_channels, s));
+      hipLaunchKernelGGL(k_rag_expand, dim3(h->n_channels), dim3(kRagThreads), 0, s, h->d_state, h->d_rag, h->d_lut, h->n_channels);
+      HIP_TRY(hipGetLastError());
+      h->rag_built = true;
+    }
+    RagParams R;
+    memset(&R, 0, sizeof(R));
+    R.iq = d_iq;
+    R.ch_stride = channel_stride;
+    R.block_bytes = block_bytes;
+    R.n_blocks = n_blocks;
+    R.src256 = opt.src256;
+    R.offgrid = h->offgrid ? 1 : 0;
+    R.pcm_cap = opt.src256 ? (block_bytes + 63u) / 64u : (block_bytes + 511u) / 512u;
+    R.iq256_cap = 2u * ((block_bytes / 2u + 7u) / 8u);
+    R.out_blocks = opt.out_blocks;
+    R.out_b0 = opt.out_b0;
+    R.chan_list = (opt.subset != nullptr) ? d_lists + (size_t)6 * h->n_channels : nullptr;
+    R.n_list = (opt.subset != nullptr) ? list_count[6] : h->n_channels;
+    R.gain_db = gain_db;
+    R.state = h->d_state;
+    R.rag = h->d_rag;
+    R.cfg = h->d_cfg;
+    R.pcm = d_pcm;
+    R.n_pcm = d_n_pcm;
+    R.magnitude = (d_magnitude != nullptr) ? d_magnitude : h->d_magnitude;
+    R.allowed = d_allowed;
+    R.iq256 = d_iq256;
+    R.atan2_lut = h->d_lut;
+    R.dbfs = h->d_dbfs;
+    R.counters = local;
+    R.sticky = h->d_counters;
+    R.next_local = other;
+    R.first_channel = E.first_channel;
+    R.chan_fail = E.chan_fail;
+    R.chan_poison = E.chan_poison;
+    hipLaunchKernelGGL(k_rx_ragged, dim3(R.n_list), dim3(kRagThreads), 0, s, R);
+    HIP_TRY(hipGetLastError());
+    h->ragged_launches++;
+    if (ev_slots)
+    {
+      HIP_TRY(hipEventRecord(h->ev[2 * ev_slot + 1], s));
+      h->ev_launches++;
+    }
+    h->last_stream = s;
+    return HRFD_OK;
   }
   // ---------------------------------------------------------------- dispatch
   // Everything goes to the caller's stream, in this order of preference:
@@ -1187,7 +1289,7 @@ static int rx_replay(hrfd_rx *h, const std::vector<uint32_t> &subset, const int8
     return HRFD_OK;
   }
   // squelched units write no PCM: they must read as zeros, not as what a failed batch left there
-  const size_t row = (size_t)n_blocks * (block_bytes / 512) * sizeof(int16_t);
+  const size_t row = (size_t)n_blocks * ((block_bytes + 511u) / 512u) * sizeof(int16_t);
   const bool whole_bank = subset.size() == h->n_channels;
   if (pcm_is_clear)
   {
@@ -1255,17 +1357,19 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
   {
     return fail(HRFD_EINVAL, "hrfd_rx_process_block: NULL argument");
   }
-  if (block_bytes == 0 || (block_bytes % 1024u) != 0 || block_bytes > HRFD_BLOCK_BYTES || n_blocks == 0)
+  if (block_bytes == 0 || (block_bytes & 1u) != 0 || block_bytes > HRFD_BLOCK_BYTES || n_blocks == 0)
   {
-    return fail(HRFD_EINVAL, "block_bytes must be a multiple of 1024 and <= %u, n_blocks > 0", HRFD_BLOCK_BYTES);
+    return fail(HRFD_EINVAL, "block_bytes must be even, > 0 and <= %u, n_blocks > 0 (got %u, %u)", HRFD_BLOCK_BYTES,
+                block_bytes, n_blocks);
   }
   HIP_TRY(hipSetDevice(h->device));
   const uint32_t C = h->n_channels;
   const size_t units = (size_t)C * n_blocks;
-  const uint32_t npcm = block_bytes / 512;
+  const uint32_t npcm = (block_bytes + 511u) / 512u;        // row lengths: hrfd_rx_pcm_capacity / hrfd_rx_iq256_capacity
+  const uint32_t n256b = 2u * ((block_bytes / 2u + 7u) / 8u);
   const size_t iq_bytes = units * block_bytes;
   const size_t pcm_bytes = units * npcm * sizeof(int16_t);
-  const size_t iq256_bytes = units * (block_bytes / 8);
+  const size_t iq256_bytes = units * n256b;
   hipStream_t s = h->stream;
   int rc;
   HIP_TRY(hipStreamSynchronize(s));
@@ -1285,6 +1389,25 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
   const uint64_t stride = (uint64_t)block_bytes * n_blocks;
   int8_t *d_iq256 = iq256k_opt ? h->d_iq256 : nullptr;
   uint32_t viol = 0;
+  if (h->offgrid || (block_bytes % 1024u) != 0)
+  {
+    // any length: one launch of k_rx_ragged takes the whole call, block by block and exactly (rx_launch)
+    if (d_iq256 != nullptr)
+    {
+      HIP_TRY(hipMemsetAsync(d_iq256, 0, iq256_bytes, s));   // (a row is filled up to the call's own count)
+    }
+    const LaunchOpts opt = {n_blocks, 0, 0, 0};
+    rc = rx_launch(h, h->d_iq, stride, block_bytes, n_blocks, gain_db, h->d_pcm, h->d_npcm, h->d_mag_out, h->d_allowed,
+                   d_iq256, s, opt);
+    if (rc != HRFD_OK) return rc;
+    if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
+    if (viol != 0)
+    {
+      return fail(HRFD_ESTATE, "internal: the exact path reported %u uncommitted channel(s)", viol);
+    }
+  }
+  else
+  {
   std::vector<uint32_t> redo;                              // channels to run on the exact per-block path
   if (n_blocks > 1 && (uint32_t)(kMaxHal + 64) * 16u <= block_bytes)
   {
@@ -1308,6 +1431,7 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
                       h->d_allowed, d_iq256, s, !batch_ran)) != HRFD_OK)
   {
     return rc;
+  }
   }
   HIP_TRY(hipMemcpyAsync(pcm, h->d_pcm, pcm_bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(n_pcm, h->d_npcm, units * 4, hipMemcpyDeviceToHost, s));
@@ -1342,7 +1466,7 @@ extern "C" int hrfd_rx_reduce_sample_rate(hrfd_rx *h, const int8_t *iq, uint32_t
   const uint32_t C = h->n_channels;
   std::vector<int> modes(C);
   std::vector<uint32_t> tracking(C), npcm(C);
-  std::vector<int16_t> pcm((size_t)C * (block_bytes / 512 + 1));
+  std::vector<int16_t> pcm((size_t)C * (block_bytes / 512 + 2));
   {
     std::lock_guard<std::mutex> g(h->mu);
     for (uint32_t c = 0; c < C; c++)
@@ -1377,6 +1501,31 @@ extern "C" int hrfd_rx_reduce_sample_rate(hrfd_rx *h, const int8_t *iq, uint32_t
     return fail(HRFD_ENODEV, "hrfd_rx_reduce_sample_rate: %s", hipGetErrorString(e));
   }
   return rc;
+}
+
+// Row lengths of the outputs for a block length, and what the front end holds back between calls.
+extern "C" uint32_t hrfd_rx_pcm_capacity(uint32_t block_bytes) { return (block_bytes + 511u) / 512u; }
+extern "C" uint32_t hrfd_rx_iq256_capacity(uint32_t block_bytes) { return 2u * ((block_bytes / 2u + 7u) / 8u); }
+extern "C" uint32_t hrfd_demod_pcm_capacity(uint32_t bytes_per_channel) { return (bytes_per_channel + 63u) / 64u; }
+
+extern "C" int hrfd_rx_pending_samples(hrfd_rx *h, uint32_t *pending)
+{
+  if (h == nullptr || pending == nullptr)
+  {
+    return fail(HRFD_EINVAL, "hrfd_rx_pending_samples: NULL argument");
+  }
+  *pending = 0;
+  if (!h->rag_built)
+  {
+    return HRFD_OK;                                        // on the grid: every call ended on a whole 256 kS/s sample
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = h->last_stream ? h->last_stream : h->stream;
+  HIP_TRY(hipStreamSynchronize(s));
+  uint32_t p = 0;
+  HIP_TRY(hipMemcpy(&p, &h->d_rag->fe_phase, sizeof(p), hipMemcpyDeviceToHost));   // the same for every channel of the handle
+  *pending = p & 7u;
+  return HRFD_OK;
 }
 
 // ------------------------------------------------------------------ inner boundary
@@ -1465,13 +1614,13 @@ extern "C" int hrfd_demod_process(hrfd_demod *dh, const int8_t *iq256k, uint32_t
     return fail(HRFD_EINVAL, "hrfd_demod_process: NULL argument");
   }
   hrfd_rx *h = dh->rx;
-  if (bytes_per_channel == 0 || (bytes_per_channel % 128u) != 0 || bytes_per_channel > 32768u)
+  if (bytes_per_channel == 0 || (bytes_per_channel & 1u) != 0 || bytes_per_channel > 32768u)
   {
-    return fail(HRFD_EINVAL, "hrfd_demod_process: bytes_per_channel must be a multiple of 128 and <= 32768");
+    return fail(HRFD_EINVAL, "hrfd_demod_process: bytes_per_channel must be even, > 0 and <= 32768 (got %u)", bytes_per_channel);
   }
   HIP_TRY(hipSetDevice(h->device));
   const uint32_t C = h->n_channels;
-  const uint32_t npcm = bytes_per_channel / 64;
+  const uint32_t npcm = (bytes_per_channel + 63u) / 64u;   // hrfd_demod_pcm_capacity
   const size_t iq_bytes = (size_t)C * bytes_per_channel;
   const size_t pcm_bytes = (size_t)C * npcm * sizeof(int16_t);
   hipStream_t s = h->stream;
@@ -1480,6 +1629,7 @@ extern "C" int hrfd_demod_process(hrfd_demod *dh, const int8_t *iq256k, uint32_t
   if ((rc = grow((void **)&h->d_iq, &h->cap_iq, iq_bytes)) != HRFD_OK) return rc;
   if ((rc = grow((void **)&h->d_pcm, &h->cap_pcm, pcm_bytes)) != HRFD_OK) return rc;
   if ((rc = grow((void **)&h->d_npcm, &h->cap_npcm, (size_t)C * 4)) != HRFD_OK) return rc;
+  HIP_TRY(hipMemsetAsync(h->d_pcm, 0, pcm_bytes, s));
   HIP_TRY(hipMemcpyAsync(h->d_iq, iq256k, iq_bytes, hipMemcpyHostToDevice, s));
   const LaunchOpts opt = {1, 0, 0, 1};
   rc = rx_launch(h, h->d_iq, bytes_per_channel, bytes_per_channel, 1, 0, h->d_pcm, h->d_npcm, nullptr,

@@ -274,6 +274,17 @@ extern "C" int hrfd_rx_debug_set_fir_flow(hrfd_rx *h, int mode)
   return HRFD_OK;
 }
 
+extern "C" int hrfd_rx_debug_ragged(hrfd_rx *h, int *offgrid, unsigned long long *launches)
+{
+  if (h == nullptr || offgrid == nullptr || launches == nullptr)
+  {
+    return fail(HRFD_EINVAL, "NULL");
+  }
+  *offgrid = h->offgrid ? 1 : 0;
+  *launches = h->ragged_launches;
+  return HRFD_OK;
+}
+
 // test hook: 0 = no gated second pass on the device; a channel with a closed gate in a batch stays failed (the host replays it)
 extern "C" int hrfd_rx_debug_set_gated(hrfd_rx *h, int on)
 {

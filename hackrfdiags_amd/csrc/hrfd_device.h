@@ -178,6 +178,64 @@ struct RxParams
   unsigned long long *dbg;     // optional [grid][kDbgSlots] s_memtime stamps at phase boundaries (diagnostic builds of bench only)
 };
 
+// ---- any block length: the general-phase chain (k_rx_ragged, hrfd_rx_ragged.hip) ----------------
+// The reference's decimators keep a commutator position between calls (Decimator_int16.cc:321-362:
+// decimationBufferIndex), so IqDataProcessor::acceptIqData takes ANY byteCount (DataConsumer.cc:229-241
+// passes short USB transfers on).  While every block of a handle has been a multiple of 512 bytes all those
+// positions are 0 at every call boundary and ChanState (N - M inputs per stage) is the whole state.  The first
+// block of another length takes the handle "off the grid": from then on a channel's state is this structure --
+// every stage's last N - 1 inputs and its commutator position, exactly the reference's ring contents in effect.
+constexpr int kRagHead = 40;                   // >= N - 1 of the longest stage (D(40,2))
+struct RagQ15
+{
+  int16_t tail[kRagHead];                      // tail[0 .. N-2]: the last N - 1 inputs, oldest first
+  int32_t phase;                               // inputs since the last output, 0 .. M-1
+  int32_t pad;
+};
+struct RagWb { float theta, p, y, pad; RagQ15 d1, d2, d3; };                 // WbFmDemodulator: previousTheta, b1*x[n-1], y[n-1]
+struct RagFm { float th[4]; RagQ15 ti, tq, d2, d3; };                          // FmDemodulator: theta[n-4 .. n-1] (the differentiator's pipeline)
+struct RagAs { float x1, y1, pad0, pad1; RagQ15 s[2][3]; RagQ15 delay, hilbert; };   // Am / SsbDemodulator: dc-removal x[n-1], y[n-1]
+struct alignas(16) RagState
+{
+  uint32_t valid;                              // built from ChanState by k_rag_expand
+  uint32_t fe_phase;                           // front end: IQ samples since the last 256 kS/s output, 0 .. 7
+  uint32_t pad[2];
+  int8_t fe_raw[32];                           // the last 16 raw IQ samples (14 are read)
+  RagWb wb;
+  RagFm fm;
+  RagAs am, ssb;
+};
+
+struct RagParams
+{
+  const int8_t *iq;            // [C][n_blocks][block_bytes]
+  uint64_t ch_stride;
+  uint32_t block_bytes;        // even
+  uint32_t n_blocks;
+  int32_t src256;              // the input IS the mixed 256 kS/s stream (inner demodulator API)
+  int32_t offgrid;             // 0: state in ChanState (every commutator at 0), 1: state in RagState
+  uint32_t pcm_cap;            // samples per block row of pcm: ceil(block_bytes / 512) (src256: / 64)
+  uint32_t iq256_cap;          // bytes per block row of iq256: 2 * ceil(block_bytes / 16)
+  uint32_t out_blocks, out_b0; // layout of the outputs, as RxParams
+  const uint32_t *chan_list;   // nullptr: channels 0 .. n_list - 1
+  uint32_t n_list;
+  uint32_t gain_db;
+  ChanState *state;
+  RagState *rag;
+  const ChanCfg *cfg;
+  int16_t *pcm;
+  uint32_t *n_pcm;             // optional
+  uint32_t *magnitude;
+  uint8_t *allowed;            // optional
+  int8_t *iq256;               // optional
+  const float *atan2_lut;
+  const int32_t *dbfs;
+  // a launch's bookkeeping, the protocol of finish_apply (this kernel finishes its own channels and never speculates)
+  uint32_t *counters, *sticky, *next_local;
+  uint32_t first_channel;
+  uint32_t *chan_fail, *chan_poison;
+};
+
 constexpr uint32_t kFailGate = 1u, kFailSpec = 2u, kFailPoison = 4u, kFailExpired = 8u;
 
 constexpr int kCntRepair = 0;  // de-emphasis tiles re-run in place because their warm-up had not re-synchronised

@@ -216,21 +216,21 @@ extern "C" int hrfd_fanout_set_threshold(hrfd_fanout *f, uint32_t channel, int32
 
 static int fanout_buffers(hrfd_fanout *f, uint32_t block_bytes, uint32_t n_blocks)
 {
-  if (block_bytes == 0 || (block_bytes % 1024u) != 0 || block_bytes > HRFD_BLOCK_BYTES || n_blocks == 0)
+  if (block_bytes == 0 || (block_bytes & 1u) != 0 || block_bytes > HRFD_BLOCK_BYTES || n_blocks == 0)
   {
-    return fail(HRFD_EINVAL, "block_bytes must be a multiple of 1024 and <= %u, n_blocks > 0", HRFD_BLOCK_BYTES);
+    return fail(HRFD_EINVAL, "block_bytes must be even, > 0 and <= %u, n_blocks > 0", HRFD_BLOCK_BYTES);
   }
   for (hrfd_fanout::Shard &s : f->shards)
   {
     HIP_TRY(hipSetDevice(s.device));
     const size_t units = (size_t)s.count * n_blocks;
     int rc;
-    if (units * block_bytes > s.cap_iq || units * (block_bytes / 512) * 2 > s.cap_pcm || units * 4 > s.cap_npcm)
+    if (units * block_bytes > s.cap_iq || units * ((block_bytes + 511u) / 512u) * 2 > s.cap_pcm || units * 4 > s.cap_npcm)
     {
       HIP_TRY(hipStreamSynchronize(s.rx->stream));
     }
     if ((rc = grow((void **)&s.d_iq, &s.cap_iq, units * block_bytes)) != HRFD_OK) return rc;
-    if ((rc = grow((void **)&s.d_pcm, &s.cap_pcm, units * (block_bytes / 512) * sizeof(int16_t))) != HRFD_OK) return rc;
+    if ((rc = grow((void **)&s.d_pcm, &s.cap_pcm, units * ((block_bytes + 511u) / 512u) * sizeof(int16_t))) != HRFD_OK) return rc;
     if ((rc = grow((void **)&s.d_npcm, &s.cap_npcm, units * sizeof(uint32_t))) != HRFD_OK) return rc;
   }
   return HRFD_OK;
@@ -326,7 +326,7 @@ extern "C" int hrfd_fanout_process(hrfd_fanout *f, uint32_t gain_db)
   {
     HIP_TRY(hipSetDevice(s.device));
     // mode NONE and squelched units produce no PCM: they read as zeros, not as the previous batch
-    HIP_TRY(hipMemsetAsync(s.d_pcm, 0, (size_t)s.count * f->n_blocks * (f->block_bytes / 512) * sizeof(int16_t), s.rx->stream));
+    HIP_TRY(hipMemsetAsync(s.d_pcm, 0, (size_t)s.count * f->n_blocks * ((f->block_bytes + 511u) / 512u) * sizeof(int16_t), s.rx->stream));
     const int rc = hrfd_rx_process_device(s.rx, s.d_iq, (uint64_t)f->n_blocks * f->block_bytes, f->block_bytes, f->n_blocks,
                                           gain_db, s.d_pcm, s.d_npcm, nullptr, nullptr, nullptr, nullptr);
     if (rc != HRFD_OK)
@@ -349,7 +349,7 @@ extern "C" int hrfd_fanout_collect(hrfd_fanout *f, int dst_device, int16_t *d_pc
   {
     return fail(HRFD_ESTATE, "hrfd_fanout_collect: no batch in flight, or no destination");
   }
-  const uint32_t npcm = f->block_bytes / 512;
+  const uint32_t npcm = (f->block_bytes + 511u) / 512u;
   uint32_t replayed = 0;
   for (hrfd_fanout::Shard &s : f->shards)
   {

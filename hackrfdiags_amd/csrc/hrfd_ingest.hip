@@ -89,9 +89,9 @@ extern "C" int hrfd_ingest_create(hrfd_rx *rx, uint32_t block_bytes, uint32_t n_
                                   hrfd_ingest **out)
 {
   if (rx == nullptr || out == nullptr || n_blocks == 0 || n_slots < 2 || n_slots > 16 || block_bytes == 0 ||
-      (block_bytes % 1024u) != 0 || block_bytes > HRFD_BLOCK_BYTES)
+      (block_bytes & 1u) != 0 || block_bytes > HRFD_BLOCK_BYTES)
   {
-    return fail(HRFD_EINVAL, "hrfd_ingest_create: need a handle, block_bytes a multiple of 1024 <= %u, "
+    return fail(HRFD_EINVAL, "hrfd_ingest_create: need a handle, an even block_bytes <= %u, "
                              "n_blocks > 0, 2..16 slots", HRFD_BLOCK_BYTES);
   }
   *out = nullptr;
@@ -104,7 +104,7 @@ extern "C" int hrfd_ingest_create(hrfd_rx *rx, uint32_t block_bytes, uint32_t n_
   g->C = rx->n_channels;
   g->units = (size_t)g->C * n_blocks;
   g->iq_bytes = g->units * block_bytes;
-  g->pcm_elems = g->units * (block_bytes / 512);
+  g->pcm_elems = g->units * ((block_bytes + 511u) / 512u);   // rows of hrfd_rx_pcm_capacity(block_bytes) samples
   g->slots.resize(n_slots);
   hipError_t e = hipStreamCreateWithFlags(&g->s_in, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->s_out, hipStreamNonBlocking);

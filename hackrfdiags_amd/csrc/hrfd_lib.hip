@@ -4,6 +4,7 @@
 #include "hrfd_rx_kernels.hip"
 #include "hrfd_rx_flow.hip"
 #include "hrfd_rx_fir_kernels.hip"
+#include "hrfd_rx_ragged.hip"
 #include "../../include/hrfd.h"
 #include "hrfd_tx_kernels.hip"
 #include "hrfd_api.hip"

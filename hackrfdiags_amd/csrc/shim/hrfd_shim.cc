@@ -4,8 +4,9 @@
 //     g++ ... hrfd_shim.cc -I include -I hackrfdiags_amd/csrc/shim -lhrfd -lamdhip64
 // in place of lib/lib{Am,Fm,WbFm,Ssb}Demodulator.a, libSsbModulator.a and
 // src_diags/IqDataProcessor.cc (radioDiags/buildRadioDiags.sh:50-66).
-// Like the reference, the classes have no error channel: a failing C-ABI call is
-// reported on stderr and aborts (there is no CPU fallback to hide behind).
+// Like the reference, the classes have no error channel: a failing C-ABI call (no device, out of memory, a HIP
+// error) is reported on stderr and aborts (there is no CPU fallback to hide behind).  A buffer LENGTH never aborts:
+// acceptIqData takes whatever byteCount the reference's takes (sizeClip / the notes there).
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,6 +48,23 @@ void fatal(const char *what, int rc)
 {
   fprintf(stderr, "libhrfd: %s failed (%d): %s\n", what, rc, hrfd_last_error());
   abort();
+}
+
+// A buffer longer than the reference's fixed arrays: the reference overruns them (its caller, DataConsumer::acceptData,
+// clips first: DataConsumer.cc:229-233); the shim clips and says so once.
+uint32_t sizeClip(const char *what, unsigned long byteCount, uint32_t limit)
+{
+  static bool told = false;
+  if (byteCount > limit)
+  {
+    if (!told)
+    {
+      told = true;
+      nprintf(stderr, "libhrfd: %s: %lu bytes clipped to %u (the reference's arrays hold no more)\n", what, byteCount, limit);
+    }
+    return limit;
+  }
+  return (uint32_t)byteCount;
 }
 
 DemodulatorBase::DemodulatorBase(int mode, float defaultGain,
@@ -108,10 +126,23 @@ void DemodulatorBase::accept(int8_t *bufferPtr,uint32_t bufferLength)
     rc = hrfd_demod_set_gain(handle, 0, gain);
     if (rc != HRFD_OK) fatal("hrfd_demod_set_gain", rc);
   }
-  // 256 kS/s IQ in, PCM out; the reference's arrays hold at most 32768 bytes / 512 samples
-  rc = hrfd_demod_process(handle, bufferPtr, bufferLength, pcmData, &sampleCount);
-  if (rc != HRFD_OK) fatal("hrfd_demod_process", rc);
-  // sendPcmData: synchronously, on the caller's thread, buffer valid during the call
+  // Lengths, as the reference's loops treat them.  More than the member arrays hold (32768 bytes) overruns them
+  // there: clipped here.  An odd count: WbFmDemodulator::demodulateSignal takes bufferLength / 2 samples
+  // (WbFmDemodulator.cc:395); the other three run their Q loop to bufferPtr[bufferLength] (FmDemodulator.cc:426,
+  // AmDemodulator.cc:381, SsbDemodulator.cc:502), i.e. (bufferLength + 1) / 2 samples.
+  bufferLength = sizeClip("acceptIqData", bufferLength, 32768u);
+  if ((bufferLength & 1u) != 0)
+  {
+    bufferLength = (mode == HRFD_MODE_WBFM) ? bufferLength - 1u : bufferLength + 1u;
+  }
+  if (bufferLength != 0)
+  {
+    // 256 kS/s IQ in, PCM out; the reference's arrays hold at most 32768 bytes / 512 samples
+    rc = hrfd_demod_process(handle, bufferPtr, bufferLength, pcmData, &sampleCount);
+    if (rc != HRFD_OK) fatal("hrfd_demod_process", rc);
+  }
+  // sendPcmData: synchronously, on the caller's thread, buffer valid during the call -- with whatever count the
+  // decimators completed, 0 included (WbFmDemodulator.cc:341-356, :520-529)
   pcmCallbackPtr(pcmData, sampleCount);
 }
 
@@ -278,11 +309,26 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
 
   ensureHandle();
   pushGains();
+  // Lengths: whatever the reference takes.  DataConsumer passes short blocks on (DataConsumer.cc:229-241) and the
+  // decimators keep their commutator positions between calls, so any count works there and here; longer than the
+  // arrays is clipped (as DataConsumer does before it calls); an odd count makes the reference's Q loop read
+  // bufferPtr[byteCount] (IqDataProcessor.cc:474): the same byte is read here.  Nothing at all: the reference divides
+  // by zero in SignalDetector.cc:255; here the call is ignored.
+  uint32_t length = hrfd_shim::sizeClip("IqDataProcessor::acceptIqData", byteCount, HRFD_BLOCK_BYTES);
+  length += (length & 1u);
+  if (length == 0)
+  {
+    return;
+  }
+  uint32_t pending = 0;
+  int rc = hrfd_rx_pending_samples(handle, &pending);
+  if (rc != HRFD_OK) fatal("hrfd_rx_pending_samples", rc);
+  const uint32_t decimatedByteCount = 2u * ((pending + length / 2u) / 8u);     // reduceSampleRate's return value
   // reduceSampleRate + upconvertByFsOver4 + Squelch::run + demodulator, one launch
-  int rc = hrfd_rx_process_block(handle, bufferPtr, (uint32_t)byteCount, 1,
-                                 radio_adjustableReceiveGainInDb, pcmData, &sampleCount,
-                                 &signalMagnitude, &signalAllowed,
-                                 iqDumpEnabled ? decimatedData : NULL);
+  rc = hrfd_rx_process_block(handle, bufferPtr, length, 1,
+                             radio_adjustableReceiveGainInDb, pcmData, &sampleCount,
+                             &signalMagnitude, &signalAllowed,
+                             iqDumpEnabled ? decimatedData : NULL);
   if (rc != HRFD_OK) fatal("hrfd_rx_process_block", rc);
 
   // same order as the reference (IqDataProcessor.cc:953-1034)
@@ -290,11 +336,11 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
   {
     if (iqDumpSinkPtr != NULL)
     {
-      iqDumpSinkPtr(decimatedData, (uint32_t)(byteCount / 8), iqDumpContextPtr);
+      iqDumpSinkPtr(decimatedData, decimatedByteCount, iqDumpContextPtr);
     }
     else
     {
-      networkInterfacePtr->sendData(decimatedData, (int)(byteCount / 8));   // IqDataProcessor.cc:956
+      networkInterfacePtr->sendData(decimatedData, (int)decimatedByteCount);   // IqDataProcessor.cc:956
     }
   }
   if (signalNotificationEnabled && signalCallbackPtr != NULL)
@@ -305,7 +351,7 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
   {
     signalMagnitudeCallbackPtr(signalMagnitude, signalMagnitudeCallbackContextPtr);
   }
-  if (signalAllowed && sampleCount > 0)
+  if (signalAllowed)
   {
     hrfd_shim::DemodulatorBase *d = NULL;
     switch (demodulatorMode)
@@ -319,6 +365,8 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
     }
     if (d != NULL)
     {
+      // X::acceptIqData ends in sendPcmData with whatever the decimators completed -- a short block may complete
+      // nothing and the reference still calls back, with a count of 0 (e.g. WbFmDemodulator.cc:341-356)
       d->deliverPcm(pcmData, sampleCount);
     }
   }
@@ -332,10 +380,20 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp,
 uint32_t IqDataProcessor::reduceSampleRate(int8_t *bufferPtr,uint32_t bufferLength)
 {
   ensureHandle();
-  const int rc = hrfd_rx_reduce_sample_rate(handle, bufferPtr, bufferLength, work->decimatedData);
+  uint32_t length = hrfd_shim::sizeClip("IqDataProcessor::reduceSampleRate", bufferLength, HRFD_BLOCK_BYTES);
+  length += (length & 1u);                                   // the Q loop reads bufferPtr[bufferLength] (:474)
+  if (length == 0)
+  {
+    return 0;
+  }
+  uint32_t pending = 0;
+  int rc = hrfd_rx_pending_samples(handle, &pending);
+  if (rc != HRFD_OK) fatal("hrfd_rx_pending_samples", rc);
+  const uint32_t byteCount = 2u * ((pending + length / 2u) / 8u);
+  rc = hrfd_rx_reduce_sample_rate(handle, bufferPtr, length, work->decimatedData);
   if (rc != HRFD_OK) fatal("reduceSampleRate", rc);
-  downconvertByFsOver4(work->decimatedData, bufferLength / 8);
-  return bufferLength / 8;
+  downconvertByFsOver4(work->decimatedData, byteCount);
+  return byteCount;
 }
 
 // Stand-alone helpers of the reference's public interface (IqDataProcessor.h:55-56): multiply sample n of a

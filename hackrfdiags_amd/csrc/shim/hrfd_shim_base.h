@@ -47,6 +47,7 @@ class DemodulatorBase
 };
 
 void fatal(const char *what, int rc);
+uint32_t sizeClip(const char *what, unsigned long byteCount, uint32_t limit);
 
 } // namespace hrfd_shim
 

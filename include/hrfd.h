@@ -32,7 +32,7 @@ extern "C" {
 
 /* error codes */
 #define HRFD_OK            0
-#define HRFD_EINVAL       -1   /* bad argument (size not a multiple of 512 bytes, NULL, ...) */
+#define HRFD_EINVAL       -1   /* bad argument (NULL, a size the reference cannot take either: odd, 0, larger than its arrays) */
 #define HRFD_ENODEV       -2   /* no HIP device / HIP runtime failure */
 #define HRFD_ENOMEM       -3
 #define HRFD_ESTATE       -4   /* handle misuse */
@@ -83,23 +83,43 @@ int hrfd_rx_reset_demod(hrfd_rx *h, uint32_t channel, int mode);
 /* IqDataProcessor::acceptIqData (IqDataProcessor.cc:926-1038) for every channel,
  * n_blocks consecutive blocks per channel in one call.  Host buffers:
  *   iq            [n_channels][n_blocks][block_bytes] int8, interleaved I,Q, 2.048 MS/s
- *   block_bytes   multiple of 1024, <= 262144 (the reference's caller always
- *                 passes 262144, DataConsumer.cc:341)
+ *   block_bytes   ANY even count, 2 .. 262144, like the reference: DataConsumer::acceptData clips longer buffers and
+ *                 counts and PASSES ON shorter ones (DataConsumer.cc:229-241, :341-343; a USB transfer that ends early,
+ *                 hackRf/hackrf.c:1443), and every decimator keeps its commutator position between calls
+ *                 (Decimator_int16.cc:321-362).  What comes out per call is the reference's: the front end holds back
+ *                 p = 0..7 IQ samples (hrfd_rx_pending_samples), a call completes floor((p + block_bytes/2) / 8) samples
+ *                 at 256 kS/s, the Fs/4 rotation restarts at every call, the squelch mean is the call's own, the
+ *                 demodulator emits what its three stages complete.  Odd counts are refused: the reference's Q loop then
+ *                 reads bufferPtr[byteCount] (IqDataProcessor.cc:474) -- pass byteCount + 1 to get its result.  A call
+ *                 too short to complete one 256 kS/s sample makes the reference divide by zero (SignalDetector.cc:255);
+ *                 here it reports magnitude 0.
+ *                 Speed: multiples of 1024 on a handle whose blocks all were multiples of 512 run on the streaming
+ *                 kernels; other multiples of 512 (a transfer some USB packets short: 261632) pass through the exact
+ *                 general kernel and the stream is back on the streaming kernels with the next full block; the first
+ *                 block of any OTHER length moves the handle to the general kernel for good.
  *   gain_db       radio_adjustableReceiveGainInDb (Radio.cc:15) at call time
- *   pcm           [n_channels][n_blocks][block_bytes/512] int16   (out)
- *   n_pcm         [n_channels][n_blocks] samples actually produced: block_bytes/512,
- *                 or 0 when squelched / mode NONE (the reference then makes no
- *                 PCM callback)                                     (out)
+ *   pcm           [n_channels][n_blocks][hrfd_rx_pcm_capacity(block_bytes)] int16: a row holds n_pcm samples (out)
+ *   n_pcm         [n_channels][n_blocks] samples actually produced (block_bytes/512 for whole multiples of 512 on an
+ *                 open gate); 0 when squelched / mode NONE (the reference then makes no PCM callback)   (out)
  *   magnitude     [n_channels][n_blocks] Squelch::getSignalMagnitude() (out, may be NULL)
  *   signal_allowed[n_channels][n_blocks] Squelch::run() result       (out, may be NULL)
- *   iq256k_opt    [n_channels][n_blocks][block_bytes/8] decimatedData after the
- *                 Fs/4 mix -- what `enable iqdump` sends by UDP      (out, may be NULL)
+ *   iq256k_opt    [n_channels][n_blocks][hrfd_rx_iq256_capacity(block_bytes)] decimatedData after the Fs/4 mix -- what
+ *                 `enable iqdump` sends by UDP; block_bytes/8 bytes for multiples of 16   (out, may be NULL)
  * Blocking: returns when the outputs are in the host buffers.
  */
 int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t block_bytes,
                           uint32_t n_blocks, uint32_t gain_db, int16_t *pcm,
                           uint32_t *n_pcm, uint32_t *magnitude,
                           uint8_t *signal_allowed, int8_t *iq256k_opt);
+/* Row lengths of the outputs above: ceil(block_bytes / 512) PCM samples, 2 * ceil(block_bytes / 16) bytes of the
+ * 256 kS/s stream (what a call can complete at most, whatever the decimators hold). */
+uint32_t hrfd_rx_pcm_capacity(uint32_t block_bytes);
+uint32_t hrfd_rx_iq256_capacity(uint32_t block_bytes);
+/* IQ samples the front end's three half-band decimators hold back after the calls so far (0..7, the same for every
+ * channel of the handle; 0 while every block was a multiple of 16 bytes): the NEXT call of block_bytes bytes completes
+ * floor((pending + block_bytes / 2) / 8) samples at 256 kS/s = IqDataProcessor::reduceSampleRate's return value / 2
+ * (IqDataProcessor.cc:429-500).  Waits for the handle's last call. */
+int hrfd_rx_pending_samples(hrfd_rx *h, uint32_t *pending);
 
 /* IqDataProcessor::reduceSampleRate (IqDataProcessor.cc:429-500; public in the reference, not called by the
  * application): one block of every channel through the three half-band stages only -- the decimator pipelines advance,
@@ -111,7 +131,8 @@ int hrfd_rx_reduce_sample_rate(hrfd_rx *h, const int8_t *iq, uint32_t block_byte
 
 /* Same work with every buffer already resident in device memory (HBM); this is
  * the entry the batched benchmark drives.  d_iq is [n_channels][n_blocks]
- * [block_bytes] with channel_stride bytes between channels.  Asynchronous on
+ * [block_bytes] with channel_stride bytes between channels; block_bytes and the rows of the outputs as above
+ * (d_n_pcm may be NULL; a d_iq256k_opt row is written up to the call's own count).  Asynchronous on
  * `stream` (a hipStream_t, NULL = the handle's own stream).  Optional outputs
  * may be NULL.  When n_blocks > 1 the call is one continuous stream per channel (or, for small banks and odd block
  * sizes, blocks demodulated concurrently): it speculates that every squelch gate in the batch is open and that the
@@ -146,9 +167,11 @@ int hrfd_rx_failed_channels(hrfd_rx *h, uint8_t *out, uint32_t n);
  *           SsbDemodulator::set{Lsb,Usb}DemodulationMode
  *           (WbFmDemodulator.h:23-31, FmDemodulator.h:23-31, AmDemodulator.h:23-31,
  *            SsbDemodulator.h:24-34).
- * Input is 256 kS/s int8 IQ, already mixed; bytes_per_channel a multiple of 128 (two PCM samples: the kernels store PCM as 4-byte pairs),
- * <= 32768 (the reference's fixed member arrays).  The PCM callback of the
- * reference becomes the pcm/n_pcm output pair; the C++ shim invokes the callback.
+ * Input is 256 kS/s int8 IQ, already mixed; bytes_per_channel any even count <= 32768 (the reference's fixed member
+ * arrays; its loops take any count and the decimators keep their positions, e.g. WbFmDemodulator.cc:395, :460-500).
+ * pcm [n_channels][hrfd_demod_pcm_capacity(bytes_per_channel)], n_pcm [n_channels] (may be NULL) the samples produced:
+ * bytes_per_channel / 64 for whole multiples of 64.  The PCM callback of the reference becomes the pcm/n_pcm output
+ * pair; the C++ shim invokes the callback.
  */
 int hrfd_demod_create(int mode, uint32_t n_channels, int device, hrfd_demod **out);
 int hrfd_demod_destroy(hrfd_demod *h);
@@ -157,6 +180,7 @@ int hrfd_demod_set_gain(hrfd_demod *h, uint32_t channel, float gain);
 int hrfd_demod_set_sideband(hrfd_demod *h, uint32_t channel, int lsb);
 int hrfd_demod_process(hrfd_demod *h, const int8_t *iq256k, uint32_t bytes_per_channel,
                        int16_t *pcm, uint32_t *n_pcm);
+uint32_t hrfd_demod_pcm_capacity(uint32_t bytes_per_channel);   /* ceil(bytes_per_channel / 64) */
 
 /* ------------------------------------------------------------------------------
  * Block transport in front of hrfd_rx.  Replaces the role of
@@ -168,7 +192,7 @@ int hrfd_demod_process(hrfd_demod *h, const int8_t *iq256k, uint32_t bytes_per_c
  * ones (a batch whose speculation fails is replayed exactly, with the batches in flight behind it).
  *   producer:  hrfd_ingest_acquire (pinned input buffer of the next free slot; HRFD_ESTATE when
  *              none is free) -> fill -> hrfd_ingest_submit (returns at once)
- *   consumer:  hrfd_ingest_collect (oldest submitted batch; blocks; pcm [C][B][block_bytes/512],
+ *   consumer:  hrfd_ingest_collect (oldest submitted batch; blocks; pcm [C][B][hrfd_rx_pcm_capacity(block_bytes)],
  *              n_pcm / magnitude / signal_allowed [C][B]; pointers valid until that slot is
  *              acquired again)
  * The rx handle must not be used by other calls while batches are in flight.
@@ -198,7 +222,7 @@ int hrfd_ingest_replayed(hrfd_ingest *g, uint64_t *n_batches);
  *   hrfd_fanout_process   IqDataProcessor::acceptIqData (IqDataProcessor.cc:926-1038) for every channel, n_blocks
  *                         blocks each, all devices at once, asynchronous
  *   hrfd_fanout_collect   waits, replays exactly what failed its speculation (as hrfd_rx_process_block does), gathers
- *                         pcm [n_channels][n_blocks][block_bytes/512] and n_pcm [n_channels][n_blocks] (may be NULL)
+ *                         pcm [n_channels][n_blocks][hrfd_rx_pcm_capacity(block_bytes)] and n_pcm [n_channels][n_blocks] (may be NULL)
  *                         into buffers on dst_device; *n_replayed (may be NULL) = channels replayed
  * The setters take channel numbers of the whole bank (HRFD_ALL_CHANNELS: every shard).
  * (The multi-process counterpart -- one rank per GPU, RCCL -- is hackrfdiags_amd/shard.py, used by bench.py --gpus N.)

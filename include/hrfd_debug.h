@@ -37,6 +37,9 @@ int hrfd_debug_atan2_quadrant(uint32_t *out16644, int *ok);
 /* per-workgroup cycle stamps of k_rx_wbfm (probe builds); the cross-block check values of the latest launch */
 int hrfd_rx_debug_stamps(hrfd_rx *h, uint32_t cap_groups, unsigned long long *host_out);
 int hrfd_rx_debug_chk(hrfd_rx *h, float *pub, float *spec, uint32_t n);
+/* *offgrid: the handle was given a block that is not a whole number of PCM samples (512 bytes; inner API 64) and keeps
+ * its state in RagState since; *launches: launches so far that ran on k_rx_ragged (hrfd_rx_ragged.hip) */
+int hrfd_rx_debug_ragged(hrfd_rx *h, int *offgrid, unsigned long long *launches);
 
 /* two plain stream kernels -- kind 0 reads `bytes` of d_buf (d_sink: one dword that is never written, may be NULL),
  * kind 1 overwrites them; bytes a multiple of 256 KiB; asynchronous on `stream`.  bench.py times them in the same run

@@ -180,8 +180,9 @@ void ref_set_receive_gain_db(uint32_t gainInDb)
 
 // One IqDataProcessor::acceptIqData call.  Returns the number of PCM samples
 // the demodulator handed to the callback (0 when squelched or mode None).
-// iq256Out (optional, >= byteCount/8 bytes) receives decimatedData after the
-// Fs/4 mix; magnitudeOut (optional) the squelch's block-mean magnitude.
+// iq256Out (optional, >= 2 * ceil(byteCount / 16) bytes: what a call can complete at most) receives decimatedData
+// after the Fs/4 mix -- the call's own count is 2 * floor((held + byteCount / 2) / 8), ref_rx_reduce_sample_rate
+// returns it for the front end alone; magnitudeOut (optional) the squelch's block-mean magnitude.
 uint32_t ref_rx_process(void *hv,
                         const int8_t *bufferPtr,
                         uint32_t byteCount,
@@ -201,9 +202,24 @@ uint32_t ref_rx_process(void *hv,
   }
   if (iq256Out != nullptr)
   {
-    memcpy(iq256Out, h->proc->decimatedData, byteCount / 8);
+    memcpy(iq256Out, h->proc->decimatedData, 2u * ((byteCount / 2u + 7u) / 8u));
   }
   return drain(h->sink, pcmOut, pcmCapacity);
+}
+
+// IqDataProcessor::reduceSampleRate (IqDataProcessor.cc:429-500, public): the front end alone.  Returns its byteCount
+// and copies that many bytes of decimatedData (no Fs/4 mix).
+uint32_t ref_rx_reduce_sample_rate(void *hv, const int8_t *bufferPtr, uint32_t byteCount, int8_t *iq256Out)
+{
+  RefRx *h = (RefRx *)hv;
+  std::vector<int8_t> scratch(bufferPtr, bufferPtr + byteCount);
+  scratch.push_back(0);                                    // (an odd count reads one byte past the end, :474)
+  const uint32_t n = h->proc->reduceSampleRate(scratch.data(), byteCount);
+  if (iq256Out != nullptr)
+  {
+    memcpy(iq256Out, h->proc->decimatedData, n);
+  }
+  return n;
 }
 
 // WBFM only: copy the float stream produced by the last demodulateSignal call.

@@ -60,6 +60,10 @@ int hrfd_rx_reduce_sample_rate(hrfd_rx *h, const int8_t *iq, uint32_t block_byte
   return HRFD_OK;
 }
 int hrfd_rx_sync(hrfd_rx *, uint32_t *n) { if (n) *n = 0; return HRFD_OK; }
+int hrfd_rx_pending_samples(hrfd_rx *, uint32_t *pending) { *pending = 0; return HRFD_OK; }
+uint32_t hrfd_rx_pcm_capacity(uint32_t block_bytes) { return (block_bytes + 511u) / 512u; }
+uint32_t hrfd_rx_iq256_capacity(uint32_t block_bytes) { return 2u * ((block_bytes / 2u + 7u) / 8u); }
+uint32_t hrfd_demod_pcm_capacity(uint32_t bytes) { return (bytes + 63u) / 64u; }
 int hrfd_rx_failed_channels(hrfd_rx *h, uint8_t *out, uint32_t n) { memset(out, 0, n); (void)h; return HRFD_OK; }
 
 int hrfd_demod_create(int mode, uint32_t n, int, hrfd_demod **out) { *out = new hrfd_demod{n, mode}; return HRFD_OK; }

@@ -4,6 +4,9 @@
 //   IqDataProcessor::acceptIqData            (outer boundary, argv[2] == "outer")
 //   XDemodulator::acceptIqData on 256 kS/s   (inner boundary, argv[2] == "inner")
 // usage: shim_demo <mode 1..5> <outer|inner> <block_bytes> [iqdump udp port]
+//        (block_bytes may be a comma-separated list -- "1000,262144": the byte counts of consecutive calls, the last one
+//         repeating -- for short USB transfers; with HRFD_DEMO_COUNTS=1 every PCM callback also prints "pcm <count>" on
+//         stderr, a callback with nothing in it included)
 //        shim_demo <port> udp <bytes per sendData>            (stdin -> UdpClient datagrams)
 //        shim_demo <calls> provider <bytes per call> <file>   (DataProvider playback -> stdout)
 //        shim_demo <mode 0..5> bbp 0 <schedule of w/r/s/p>     (BasebandDataProcessor: PCM blocks on stdin through the ring
@@ -33,9 +36,14 @@ void nprintf(FILE *s, const char *formatPtr, ...)      // diagUi.cc:2881
   va_end(ap);
 }
 
+static bool g_counts = false;
 static void processPcmData(int16_t *bufferPtr, uint32_t bufferLength)   // radioApp.cc:103
 {
   fwrite(bufferPtr, sizeof(int16_t), bufferLength, stdout);
+  if (g_counts)
+  {
+    fprintf(stderr, "pcm %u\n", bufferLength);
+  }
 }
 
 int main(int argc, char **argv)
@@ -47,8 +55,19 @@ int main(int argc, char **argv)
   }
   const int mode = atoi(argv[1]);
   const bool outer = strcmp(argv[2], "outer") == 0;
-  const size_t blockBytes = (size_t)atoi(argv[3]);
-  std::vector<int8_t> buf(blockBytes);
+  size_t blockBytes = (size_t)atoi(argv[3]);
+  std::vector<size_t> sizes;                                   // "a,b,c": the byte counts of consecutive calls
+  for (const char *p = argv[3]; *p != 0;)
+  {
+    sizes.push_back((size_t)strtoul(p, NULL, 10));
+    p = strchr(p, ',');
+    if (p == NULL) break;
+    p++;
+  }
+  size_t longest = blockBytes;
+  for (size_t n : sizes) longest = n > longest ? n : longest;
+  std::vector<int8_t> buf(longest + 2);                        // (an odd count reads one byte further, as the reference does)
+  g_counts = getenv("HRFD_DEMO_COUNTS") != NULL;
 
   if (strcmp(argv[2], "ssbmod") == 0)
   {
@@ -192,8 +211,16 @@ int main(int argc, char **argv)
   proc.setDemodulatorMode((IqDataProcessor::demodulatorType)mode);
 
   unsigned long timeStamp = 0;
-  while (fread(buf.data(), 1, blockBytes, stdin) == blockBytes)
+  size_t call = 0;
+  while (true)
   {
+    blockBytes = sizes[call < sizes.size() ? call : sizes.size() - 1];
+    call++;
+    if (fread(buf.data(), 1, blockBytes, stdin) != blockBytes)
+    {
+      break;
+    }
+    buf[blockBytes] = 0;                                       // what an odd count reads one byte further
     if (outer)
     {
       proc.acceptIqData(timeStamp++, buf.data(), blockBytes);

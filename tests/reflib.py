@@ -29,6 +29,11 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
+def iq256_capacity(block_bytes: int) -> int:
+    """bytes of the 256 kS/s stream a call of block_bytes can complete at most: 2 * ceil(block_bytes / 16)"""
+    return 2 * ((int(block_bytes) // 2 + 7) // 8)
+
+
 def build_oracle():
     if not os.path.exists(ORACLE_SO) or (
             os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "hrfd_oracle.c"))):
@@ -199,6 +204,7 @@ class _OrcRx:
         self.lib = lib
         self.h = C.c_void_p(lib.orc_rx_create())
         self.gain_db = 0
+        self.pending = 0                                   # IQ samples the front end's decimators hold back (0..7)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -215,15 +221,17 @@ class _OrcRx:
         self.lib.orc_rx_set_threshold(self.h, t)
 
     def process(self, iq: np.ndarray):
-        """-> (pcm int16[n], magnitude, allowed, iq256 int8[bytes/8])"""
+        """-> (pcm int16[n], magnitude, allowed, iq256 int8[the call's decimatedByteCount: bytes/8 for multiples of 16])"""
         iq = np.ascontiguousarray(iq, dtype=np.int8)
         pcm = np.zeros(len(iq) // 512 + 8, dtype=np.int16)
         mag = C.c_uint32(0)
         allowed = C.c_int(0)
-        iq256 = np.zeros(len(iq) // 8, dtype=np.int8)
+        iq256 = np.zeros(iq256_capacity(len(iq)) + 16, dtype=np.int8)
         n = self.lib.orc_rx_process(self.h, _p(iq, _i8p), len(iq), self.gain_db, _p(pcm, _i16p), len(pcm),
                                     C.byref(mag), C.byref(allowed), _p(iq256, _i8p))
-        return pcm[:n].copy(), int(mag.value), bool(allowed.value), iq256
+        count = 2 * ((self.pending + len(iq) // 2) // 8)
+        self.pending = (self.pending + len(iq) // 2) % 8
+        return pcm[:n].copy(), int(mag.value), bool(allowed.value), iq256[:count]
 
     def wbfm_float_stream(self, count):
         out = np.zeros(count, dtype=np.float32)
@@ -411,6 +419,8 @@ class Ref:
         L.ref_rx_process.restype = C.c_uint32
         L.ref_rx_process.argtypes = [C.c_void_p, _i8p, C.c_uint32, _i16p, C.c_uint32, _u32p, _i8p]
         L.ref_rx_wbfm_float_stream.argtypes = [C.c_void_p, _f32p, C.c_uint32]
+        L.ref_rx_reduce_sample_rate.restype = C.c_uint32
+        L.ref_rx_reduce_sample_rate.argtypes = [C.c_void_p, _i8p, C.c_uint32, _i8p]
         L.ref_demod_create.restype = C.c_void_p
         L.ref_demod_create.argtypes = [C.c_int]
         L.ref_demod_destroy.argtypes = [C.c_void_p]
@@ -538,6 +548,7 @@ class _RefRx:
         self.lib = lib
         self.h = C.c_void_p(lib.ref_rx_create())
         self.gain_db = 0
+        self.pending = 0
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -558,11 +569,21 @@ class _RefRx:
         iq = np.ascontiguousarray(iq, dtype=np.int8)
         pcm = np.zeros(len(iq) // 512 + 8, dtype=np.int16)
         mag = C.c_uint32(0)
-        iq256 = np.zeros(len(iq) // 8, dtype=np.int8)
+        iq256 = np.zeros(iq256_capacity(len(iq)) + 16, dtype=np.int8)
         self.lib.ref_set_receive_gain_db(self.gain_db)
         n = self.lib.ref_rx_process(self.h, _p(iq, _i8p), len(iq), _p(pcm, _i16p), len(pcm),
                                     C.byref(mag), _p(iq256, _i8p))
-        return pcm[:n].copy(), int(mag.value), None, iq256
+        count = 2 * ((self.pending + len(iq) // 2) // 8)   # (the count reduceSampleRate returns: test_oracle_vs_ref checks it)
+        self.pending = (self.pending + len(iq) // 2) % 8
+        return pcm[:n].copy(), int(mag.value), None, iq256[:count]
+
+    def reduce_sample_rate(self, iq):
+        """IqDataProcessor::reduceSampleRate alone -> (byteCount it returns, decimatedData[:byteCount], no Fs/4 mix)"""
+        iq = np.ascontiguousarray(iq, dtype=np.int8)
+        out = np.zeros(iq256_capacity(len(iq)) + 16, dtype=np.int8)
+        n = self.lib.ref_rx_reduce_sample_rate(self.h, _p(iq, _i8p), len(iq), _p(out, _i8p))
+        self.pending = (self.pending + (len(iq) + 1) // 2) % 8
+        return int(n), out[:n].copy()
 
     def wbfm_float_stream(self, count):
         out = np.zeros(count, dtype=np.float32)

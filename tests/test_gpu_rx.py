@@ -317,11 +317,12 @@ def test_block_sizes(oracle, mode, bb):
 
 
 def test_invalid_sizes_are_rejected():
+    """what the reference itself cannot take (any other even length is demodulated: tests/test_gpu_short_blocks.py)"""
     rx = api.Rx(1)
     with pytest.raises(api.HrfdError):
-        rx.process_block(np.zeros((1, 1, 1000), dtype=np.int8), 1)     # not a multiple of 1024
+        rx.process_block(np.zeros((1, 1, 1001), dtype=np.int8), 1)     # odd: the reference's Q loop reads past the end (IqDataProcessor.cc:474)
     with pytest.raises(api.HrfdError):
-        rx.process_block(np.zeros((1, 1, 2 * 262144), dtype=np.int8), 1)  # larger than a block
+        rx.process_block(np.zeros((1, 1, 2 * 262144), dtype=np.int8), 1)  # larger than its arrays (DataConsumer clips first, DataConsumer.cc:229-233)
 
 
 def test_squelch_in_a_batch_falls_back_to_exact_path(oracle):
