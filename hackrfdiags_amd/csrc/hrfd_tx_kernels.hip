@@ -213,6 +213,10 @@ __device__ __forceinline__ void wg_loop(const int tid, F &&body)
 // without them.  FMA: which of the two the host's libm is -- probed by the host (libm_variant, hrfd_api_tx.hip).
 // Outside the restated range (|x| >= 120, NaN) the double-precision cos / sin rounded to float stand in (never reached:
 // every caller wraps its phase into (-2 pi, 2 pi)).
+// Provenance: the eight polynomial coefficients and the reduction constants below are the published values of glibc
+// 2.35's __sincosf_table (sysdeps/ieee754/flt-32/s_sincosf_data.c; ARM optimized-routines, dual-licensed MIT / Apache-2.0
+// WITH LLVM-exception upstream, LGPL-2.1-or-later as shipped in glibc).  Third-party ARITHMETIC the reference depends on
+// through libm, restated here because the device has no glibc; no code of the reference itself.
 struct SinCosTab
 {
   double c0, c1, c2, c3, c4, s1, s2, s3;

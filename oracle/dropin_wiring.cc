@@ -18,6 +18,7 @@
 //   dropin_app sizes                              sizeof of every class as THIS translation unit sees it
 #include <stdarg.h>
 #include <stdio.h>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
@@ -105,14 +106,28 @@ int main(int argc, char **argv)
     receiveDataProcessorPtr->registerSignalMagnitudeCallback(magnitudeSeen, NULL);   // what the AGC does (AutomaticGainControl.cc:45-70)
     receiveDataProcessorPtr->enableSignalMagnitudeNotification();
     dataConsumerPtr->start();
-    uint8_t *transfer = (uint8_t *)malloc(DATA_CONSUMER_BUFFER_SIZE);
+    // argv[4], when present: "a,b,c" -- the valid_length of consecutive USB transfers (hackRf/hackrf.c:1443: a transfer
+    // that ends early is handed on with its actual_length; the last entry repeats).  DataConsumer::acceptData counts a
+    // short one and passes it on, clips a long one (DataConsumer.cc:229-241).
+    std::vector<uint32_t> lengths;
+    for (const char *p = argc >= 5 ? argv[4] : ""; *p != 0;)
+    {
+      lengths.push_back((uint32_t)strtoul(p, NULL, 10));
+      p = strchr(p, ',');
+      if (p == NULL) break;
+      p++;
+    }
+    uint32_t longest = DATA_CONSUMER_BUFFER_SIZE;
+    for (uint32_t n : lengths) longest = n > longest ? n : longest;
+    uint8_t *transfer = (uint8_t *)malloc(longest);
     uint32_t receiveTimeStamp = 0;
     for (unsigned b = 0; b < nBlocks; b++)
     {
-      if (fread(transfer, 1, DATA_CONSUMER_BUFFER_SIZE, stdin) != DATA_CONSUMER_BUFFER_SIZE) { rc = 3; break; }
+      const uint32_t validLength = lengths.empty() ? DATA_CONSUMER_BUFFER_SIZE : lengths[b < lengths.size() ? b : lengths.size() - 1];
+      if (fread(transfer, 1, validLength, stdin) != validLength) { rc = 3; break; }
       // Radio::receiveCallbackProcedure (Radio.cc:3138-3164), "USB thread" = this thread
-      receiveTimeStamp += DATA_CONSUMER_BUFFER_SIZE >> 1;
-      dataConsumerPtr->acceptData(receiveTimeStamp, transfer, DATA_CONSUMER_BUFFER_SIZE);
+      receiveTimeStamp += validLength >> 1;
+      dataConsumerPtr->acceptData(receiveTimeStamp, transfer, validLength);
       // the radio delivers a block every 64 ms; here they come as fast as stdin gives them, so keep the 16-message
       // pool (DataConsumer.h:18) from being overrun: at most 8 blocks in front of the consumer thread
       for (int spin = 0; magnitudeCallbacks + 8 < b + 1 && spin < 20000; spin++) usleep(1000);

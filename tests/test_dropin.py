@@ -194,6 +194,30 @@ def test_reference_data_consumer_drives_the_shim(oracle, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [AM, FM, WBFM, LSB, USB])
+def test_reference_data_consumer_hands_short_transfers_to_the_shim(oracle, mode):
+    """USB transfers that end early (hackRf/hackrf.c:1443: valid_length = actual_length) through the reference's
+    unchanged DataConsumer::acceptData -- which counts them and passes them on (DataConsumer.cc:229-241) and clips one
+    that is too long -- into the shim's IqDataProcessor::acceptIqData: no abort, the oracle's PCM call for call."""
+    _need_app()
+    lengths = [262144, 261632, 262144, 16896, 245248, 1000, 262144, 262144 + 1024, 512, 262144]
+    x = synth.make_input("fmtone", 40 + mode, 8)
+    assert sum(lengths) <= len(x)
+    r = subprocess.run([APP, "rx", str(mode), str(len(lengths)), ",".join(str(n) for n in lengths)],
+                       input=x[:sum(lengths)].tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    got = np.frombuffer(r.stdout, dtype=np.int16)
+    o = oracle.rx(); o.set_mode(mode)
+    want, off = [], 0
+    for n in lengths:
+        want.append(o.process(x[off:off + min(n, BLOCK)])[0])   # (a transfer longer than the buffer is clipped, the rest is lost)
+        off += n
+    want = np.concatenate(want)
+    assert len(got) == len(want) and (got == want).all()
+    assert f"{len(lengths)} magnitude callbacks".encode() in r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
 def test_reference_declared_baseband_processor_on_the_shim(oracle, mode):
     """BasebandDataProcessor allocated through the reference's header (17 664 B), start() (the reader thread takes
