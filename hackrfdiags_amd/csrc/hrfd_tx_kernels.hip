@@ -38,6 +38,9 @@ constexpr int HRFD_MOD_FM_PHASE = 103;  // FM modulator: the Nco PHASE of every 
 #ifndef HRFD_MOD_ABLATE
 #define HRFD_MOD_ABLATE 0
 #endif
+#ifndef HRFD_MOD_ZNUM
+#define HRFD_MOD_ZNUM 1                  // round 6: the x8 tail takes two of its eight outputs per rail from stage 7's numerators (k_mod, `eight`)
+#endif
 constexpr int kModTile = HRFD_MOD_TILE;  // input samples per workgroup
 constexpr int kModThreads = 256;
 constexpr int kModTail = 64;            // carried input history per channel (>= 54)
@@ -671,8 +674,21 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       int b0, b1, b2, b3;
       const int q1 = (p1 + 1) >> 1;                       // y7[4j-1]
       (void)p0;
+#if HRFD_MOD_ZNUM
+      // (the numerators of b0 and b2 are kept: two of stage 8's outputs come straight from them, below; opaque to the
+      //  compiler, which otherwise folds "n + 32768" back into a second multiply-add with another constant)
+      int n0 = (1 << 14) + Q_INTERP_HB2[0] * (a0 + p1);
+      int n2 = (1 << 14) + Q_INTERP_HB2[0] * (a1 + a0);
+      asm("" : "+v"(n0));
+      asm("" : "+v"(n2));
+      b0 = n0 >> 15;                                      // y7[4j]
+      b1 = (a0 + 1) >> 1;                                 // y7[4j+1]
+      b2 = n2 >> 15;                                      // y7[4j+2]
+      b3 = (a1 + 1) >> 1;                                 // y7[4j+3]
+#else
       hb4<Q_INTERP_HB2[0]>(a0, p1, b0, b1);               // y7[4j], y7[4j+1]
       hb4<Q_INTERP_HB2[0]>(a1, a0, b2, b3);               // y7[4j+2], y7[4j+3]
+#endif
       // stage 8 (HB1): y8[8j .. 8j+7], (int8_t) narrowing (:607-610).  Only the low byte of an output is kept, so the
       // outputs are left as TWICE their Q15 numerators -- the byte wanted is then byte 2 of the word, which v_perm picks
       // from two words at a time: no shift and no mask per output (hb4z)
@@ -680,6 +696,14 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       hb4z<Q_INTERP_HB1[0]>(b1, b0, z[rail][2], z[rail][3]);
       hb4z<Q_INTERP_HB1[0]>(b2, b1, z[rail][4], z[rail][5]);
       hb4z<Q_INTERP_HB1[0]>(b3, b2, z[rail][6], z[rail][7]);
+#if HRFD_MOD_ZNUM
+      // round 6: where the input of a phase-1 output is itself a phase-0 output, b = N >> 15, byte 2 of (b << 15) + (1 << 15)
+      // is byte 2 of N + (1 << 15): the bits of N below 15 cannot carry into bit 15.  The compiler does not see that only
+      // byte 2 is looked at and builds (N & 0xffff8000) + 0x8000 -- two instructions with 32-bit literals, four times per
+      // sample -- where one add does.
+      z[rail][1] = n0 + (1 << 15);
+      z[rail][5] = n2 + (1 << 15);
+#endif
     }
 #pragma unroll
     for (int d = 0; d < 4; d++)

@@ -632,8 +632,15 @@ def test_inner_demod_sideband_switch_and_sizes(oracle):
         a = g.process(x[off:off + n]); b = o.process(x[off:off + n])
         assert (a == b).all(), n
         off += n
+    # round 6: any even count, like the reference's loops (WbFmDemodulator.cc:395): short and off-grid pieces continue the stream
+    for n in (64, 2, 190, 4096):
+        a = g.process(x[off:off + n]); b = o.process(x[off:off + n])
+        assert len(a) == len(b) and (a == b).all(), n
+        off += n
     with pytest.raises(api.HrfdError):
-        g.process(np.zeros(64, dtype=np.int8))          # multiples of 128 bytes only
+        g.process(np.zeros(63, dtype=np.int8))          # an odd count is half an IQ pair
+    with pytest.raises(api.HrfdError):
+        g.process(np.zeros(32770, dtype=np.int8))       # the reference's member arrays hold 32768
     with pytest.raises(api.HrfdError):
         api.Demod(WBFM, 1).set_sideband(True)
 
