@@ -39,7 +39,7 @@ constexpr int HRFD_MOD_FM_PHASE = 103;  // FM modulator: the Nco PHASE of every 
 #define HRFD_MOD_ABLATE 0
 #endif
 #ifndef HRFD_MOD_ZNUM
-#define HRFD_MOD_ZNUM 1                  // round 6: the x8 tail takes two of its eight outputs per rail from stage 7's numerators (k_mod, `eight`)
+#define HRFD_MOD_ZNUM 3                  // round 6: the x8 tail takes two of its eight outputs per rail from stage 7's numerators (k_mod, `eight`)
 #endif
 constexpr int kModTile = HRFD_MOD_TILE;  // input samples per workgroup
 constexpr int kModThreads = 256;
@@ -655,7 +655,28 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   // ---- stages 6, 7, 8 in registers: one 256 kS/s sample j -> 8 output IQ pairs
   const int valid = min(kModTile, n - t0);                // input samples really in this tile
   int8_t *out = M.out + ((size_t)c * M.n + t0) * 512;
-  auto eight = [&](const int j) -> uint4 {
+#if HRFD_MOD_ZNUM
+  int k8000;                                              // 1 << 15 in a scalar register: as a literal it doubles the size of every add that takes it
+  asm("s_mov_b32 %0, 0x8000" : "=s"(k8000));
+#endif
+  // the tail's inputs of sample j: x5[j], x5[j - 1], x5[j - 2] of both rails
+  struct In3
+  {
+    int v[2][3];
+  };
+  auto fetch = [&](const int j) -> In3 {
+    In3 f;
+#pragma unroll
+    for (int rail = 0; rail < 2; rail++)
+    {
+      const int16_t *x5 = &r[rail][kO5 + kH5];
+      f.v[rail][0] = x5[j];
+      f.v[rail][1] = x5[j - 1];
+      f.v[rail][2] = x5[j - 2];
+    }
+    return f;
+  };
+  auto eight_of = [&](const In3 &f, const int j) -> uint4 {
 #if (HRFD_MOD_ABLATE & 2)
     return make_uint4((uint32_t)j, (uint32_t)j * 3u, (uint32_t)tid, 7u);   // TIMING EXPERIMENT ONLY: no tail arithmetic
 #endif
@@ -664,8 +685,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 #pragma unroll
     for (int rail = 0; rail < 2; rail++)
     {
-      const int16_t *x5 = &r[rail][kO5 + kH5];
-      const int xa = x5[j], xb = x5[j - 1], xc = x5[j - 2];
+      const int xa = f.v[rail][0], xb = f.v[rail][1], xc = f.v[rail][2];
       // stage 6 (HB3): y6[2j-1] (phase 1 of j-1), y6[2j], y6[2j+1]
       int a0, a1, p0, p1;
       hb4<Q_INTERP_HB3[0]>(xb, xc, p0, p1);               // p1 = y6[2j-1]
@@ -692,17 +712,33 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       // stage 8 (HB1): y8[8j .. 8j+7], (int8_t) narrowing (:607-610).  Only the low byte of an output is kept, so the
       // outputs are left as TWICE their Q15 numerators -- the byte wanted is then byte 2 of the word, which v_perm picks
       // from two words at a time: no shift and no mask per output (hb4z)
+#if HRFD_MOD_ZNUM >= 2
+      // round 6, the same idea for the phase-1 inputs b1 and b3, themselves phase-1 outputs: with c1 = b1 + 1 = (a0 + 3) >> 1
+      // (the same two instructions as b1) the output is byte 2 of c1 << 15 -- a plain shift where (b1 << 15) + (1 << 15) is a
+      // 64-bit-encoded shift-add -- and the phase-0 outputs that take b1 take c1 with the 2 H subtracted from their constant
+      constexpr int kH1x2 = 2 * Q_INTERP_HB1[0];
+      const int c1 = (a0 + 3) >> 1, c3 = (a1 + 3) >> 1;   // b1 + 1, b3 + 1
+      (void)b1;
+      (void)b3;
+      hb4z<Q_INTERP_HB1[0]>(b0, q1, z[rail][0], z[rail][1]);
+      z[rail][2] = ((1 << 15) - kH1x2) + kH1x2 * (c1 + b0);
+      z[rail][3] = c1 << 15;
+      z[rail][4] = ((1 << 15) - kH1x2) + kH1x2 * (b2 + c1);
+      z[rail][6] = ((1 << 15) - kH1x2) + kH1x2 * (c3 + b2);
+      z[rail][7] = c3 << 15;
+#else
       hb4z<Q_INTERP_HB1[0]>(b0, q1, z[rail][0], z[rail][1]);
       hb4z<Q_INTERP_HB1[0]>(b1, b0, z[rail][2], z[rail][3]);
       hb4z<Q_INTERP_HB1[0]>(b2, b1, z[rail][4], z[rail][5]);
       hb4z<Q_INTERP_HB1[0]>(b3, b2, z[rail][6], z[rail][7]);
+#endif
 #if HRFD_MOD_ZNUM
       // round 6: where the input of a phase-1 output is itself a phase-0 output, b = N >> 15, byte 2 of (b << 15) + (1 << 15)
       // is byte 2 of N + (1 << 15): the bits of N below 15 cannot carry into bit 15.  The compiler does not see that only
       // byte 2 is looked at and builds (N & 0xffff8000) + 0x8000 -- two instructions with 32-bit literals, four times per
       // sample -- where one add does.
-      z[rail][1] = n0 + (1 << 15);
-      z[rail][5] = n2 + (1 << 15);
+      z[rail][1] = n0 + k8000;
+      z[rail][5] = n2 + k8000;
 #endif
     }
 #pragma unroll
@@ -715,6 +751,7 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
   };
+  auto eight = [&](const int j) -> uint4 { return eight_of(fetch(j), j); };
   if (valid == kModTile)
   {
     // (a whole tile, the usual case: eight rounds of stores without a predicate)
@@ -732,11 +769,40 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 #else
     // (nontemporal: the output is written once and read by nobody on this device -- 2.6 % on the whole kernel; sc0 / sc1
     //  beside or instead of nt: no better, alone 2-4 % worse)
+#if HRFD_MOD_ZNUM >= 3
+    // (round 6: the lane's byte offset is ONE register for all rounds and a round's 4 KiB step goes to the scalar base --
+    //  written as out + 16 j the compiler rebuilds j and its shift in vector registers every round)
+    {
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      static_assert((32 * kModTile) % kModThreads == 0, "whole rounds");
+      const uint32_t voff = (uint32_t)tid * 16u;
+      // (the store is opaque to the compiler, which moves no LDS read across it: the next round's reads stand in front of it)
+      In3 cur = fetch(tid);
+#pragma unroll
+      for (int k = 0; k < 32 * kModTile / kModThreads; k++)
+      {
+        In3 nxt = cur;
+        if (k + 1 < 32 * kModTile / kModThreads)
+        {
+          nxt = fetch(tid + (k + 1) * kModThreads);
+        }
+        const uint4 w4 = eight_of(cur, tid + k * kModThreads);
+        cur = nxt;
+        int8_t *base = out + (size_t)k * (16 * kModThreads);   // uniform: a scalar register pair
+        const u4 d4 = u4{w4.x, w4.y, w4.z, w4.w};
+        // (s_nop 0: a store of more than 64 bits reads its data one cycle late -- a vector instruction right behind it must
+        //  not write those registers; the compiler's hazard pass keeps that distance for its own stores and does not look
+        //  into assembly.  Without it: wrong bytes in some launches, found by the digest of tools/mod_time.py.)
+        asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(voff), "v"(d4), "s"(base));
+      }
+    }
+#else
     wg_loop<32 * kModTile>(tid, [&](const int j) {
       typedef unsigned int u4 __attribute__((ext_vector_type(4)));
       const uint4 w4 = eight(j);
       __builtin_nontemporal_store(u4{w4.x, w4.y, w4.z, w4.w}, reinterpret_cast<u4 *>(out + (size_t)j * 16));
     });
+#endif
 #endif
 #endif
   }
