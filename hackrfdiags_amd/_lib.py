@@ -148,6 +148,8 @@ def load() -> C.CDLL:
     L.hrfd_mod_sync.argtypes = [_vp]
     L.hrfd_mod_debug_set_sliced.argtypes = [_vp, C.c_int]
     L.hrfd_mod_debug_set_scan.argtypes = [_vp, C.c_int]
+    if hasattr(L, "hrfd_mod_debug_set_tail"):              # (round 6; an older build named by HRFD_LIB has none)
+        L.hrfd_mod_debug_set_tail.argtypes = [_vp, C.c_int]
     L.hrfd_play_create.argtypes = [C.c_uint32, C.c_int, C.POINTER(_vp)]
     L.hrfd_play_destroy.argtypes = [_vp]
     L.hrfd_play_load_file.argtypes = [_vp, C.c_char_p]

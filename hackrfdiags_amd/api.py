@@ -423,6 +423,10 @@ class Mod:
         """test hook (FM, WBFM): 1 = the phase recurrence on round 2's k_phase_scan<64> (0: k_phase_rows, the default)"""
         check(self.L.hrfd_mod_debug_set_scan(self.h, int(kind)), "hrfd_mod_debug_set_scan")
 
+    def debug_set_tail(self, kind: int):
+        """test hook (WBFM): 0 = the lookup pass and the x8 cascade as two kernels (rounds 2-5), 1 = k_wb_tail (the default)"""
+        check(self.L.hrfd_mod_debug_set_tail(self.h, int(kind)), "hrfd_mod_debug_set_tail")
+
     def process_device(self, d_pcm, n, d_out, stream=None):
         check(self.L.hrfd_mod_process_device(self.h, _ptr(d_pcm), n, _ptr(d_out), _ptr(stream)),
               "hrfd_mod_process_device")

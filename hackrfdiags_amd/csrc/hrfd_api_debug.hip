@@ -356,3 +356,15 @@ extern "C" int hrfd_mod_debug_set_scan(hrfd_mod *h, int kind)
   h->scan_kind = kind;
   return HRFD_OK;
 }
+
+// test hook: 0 = the WBFM modulator's lookup pass and x8 cascade as two kernels (k_wb_rails, k_mod<WB_TAIL>: rounds 2-5), 1 = k_wb_tail
+extern "C" int hrfd_mod_debug_set_tail(hrfd_mod *h, int kind)
+{
+  HRFD_HOOK_GATE("hrfd_mod_debug_set_tail");
+  if (h == nullptr || (kind != 0 && kind != 1))
+  {
+    return fail(HRFD_EINVAL, "hrfd_mod_debug_set_tail: kind 0 | 1");
+  }
+  h->wb_fused = kind;
+  return HRFD_OK;
+}

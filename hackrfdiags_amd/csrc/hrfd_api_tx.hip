@@ -2,6 +2,9 @@
 // interpolateSignal and the signals/ generators over k_mod and its baseband passes) and hrfd_nco_*.  Part of the unity
 // translation unit hrfd_lib.hip, behind hrfd_api.hip (errors, HIP_TRY, grow).
 // ------------------------------------------------------------------ transmit
+#ifndef HRFD_WB_FUSED
+#define HRFD_WB_FUSED 1                 // round 6: the WBFM modulator's lookup pass and x8 cascade as ONE kernel (k_wb_tail)
+#endif
 struct hrfd_mod
 {
   int device = 0;
@@ -36,11 +39,54 @@ struct hrfd_mod
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_head[kMaxSlices] = {}, ev_scan[kMaxSlices] = {};
   int sliced = 1;                        // test hook: 0 = one pass after the other on the caller's stream
   int scan_kind = 0;                     // test hook: 1 = k_phase_scan<64> / k_phase_scan_plain whatever the bank size
+  int wb_fused = HRFD_WB_FUSED;          // test hook: 0 = the lookup pass and the x8 cascade as two kernels (rounds 2-5), 1 = k_wb_tail
   // staging for the host entry
   int16_t *d_in = nullptr;
   int8_t *d_out = nullptr;
   size_t cap_in = 0, cap_out = 0;
 };
+
+// the WBFM modulator's last pass over the slice [lo, lo + len) of every channel (len 0: the whole call): Nco::runFast's
+// lookup and stages 6-8 of the cascade in ONE kernel (k_wb_tail, round 6) -- or round 5's two, k_wb_rails in place over the
+// phases and k_mod<WB_TAIL> (h->wb_fused == 0: the A/B and the tests that run both)
+static void wb_tail_launch(hrfd_mod *h, const BaseParams &B0, const ModParams &T0, uint32_t lo, uint32_t len, uint32_t max_wgs, hipStream_t s)
+{
+  const uint32_t n = B0.n, C = B0.n_channels;
+  const uint32_t span = (len != 0u) ? len : n;
+  if (h->wb_fused != 0)
+  {
+    WbTailParams P;
+    P.cells = h->d_wb;
+    P.out = T0.out;
+    P.wbpack = h->d_wbpack;
+    P.wbtail = T0.wbtail;
+    P.wbtail_out = B0.wbtail_out;
+    P.n = n;
+    P.n_channels = C;
+    P.lo = lo;
+    P.len = len;
+    const uint32_t runs = (span * 32u + kWtRun - 1u) / kWtRun;
+    const uint32_t items_x = ((C + 7u) / 8u) * runs;                 // work items of the fullest XCD
+    const uint32_t waves = kWtThreads / 64;
+    const uint32_t wgs_x = std::max(1u, std::min(max_wgs / 8u, (items_x + waves - 1u) / waves));
+    hipLaunchKernelGGL(k_wb_tail, dim3(8u * wgs_x), dim3(kWtThreads), 0, s, P);
+    return;
+  }
+  BaseParams B = B0;
+  B.lo = lo;
+  B.len = len;
+  const size_t q = (size_t)span * 32 / 4 * C;
+  hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(max_wgs, (q + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, s, B);   // (two workgroups per CU: the 64 KiB table)
+  ModParams T = T0;
+  const uint32_t groups8 = 8u * ((C + 7u) / 8u);
+  if (len != 0u)
+  {
+    T.tile0 = lo / kModTile;
+    T.tiles_launch = (len + kModTile - 1) / kModTile;
+  }
+  const uint32_t tl = (T.tiles_launch != 0u) ? T.tiles_launch : (n + kModTile - 1) / kModTile;
+  hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(groups8 * tl), dim3(kModThreads), 0, s, T);
+}
 
 // the Nco phase recurrence over `steps` cells per channel, rows `row_stride` cells apart: k_phase_rows (four channels per
 // wave, a lone wave per SIMD up to 4096 channels, two up to 8192: the wave's time per step is the same; whole chunks of 64
@@ -483,10 +529,9 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
     {
       hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_HEAD>, dim3(grid), dim3(kModThreads), 0, s, M);
       phase_scan(h, h->d_wb, (size_t)n_per_channel * 32, (size_t)n_per_channel * 32, h->d_acc, h->n_channels, s);
-      hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(512, (s32 / 4 + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, s, B);   // (two workgroups per CU: the 64 KiB table)
       M.in = reinterpret_cast<const int16_t *>(h->d_wb);
       M.wbtail = h->d_wbtail[h->cur];
-      hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(grid), dim3(kModThreads), 0, s, M);
+      wb_tail_launch(h, B, M, 0u, 0u, 512u, s);
     }
     else
     {
@@ -528,13 +573,8 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
         phase_scan(h, h->d_wb + (size_t)lo * 32, (size_t)len * 32, (size_t)n_per_channel * 32, h->d_acc, h->n_channels, h->s_scan);
         HIP_TRY(hipEventRecord(h->ev_scan[k], h->s_scan));
         HIP_TRY(hipStreamWaitEvent(h->s_tail, h->ev_scan[k], 0));
-        B.lo = lo;
-        B.len = len;
-        const size_t q = (size_t)len * 32 / 4 * h->n_channels;
-        hipLaunchKernelGGL(k_wb_rails, dim3((uint32_t)std::min<size_t>(384, (q + kWbRailsThreads - 1) / kWbRailsThreads)), dim3(kWbRailsThreads), 0, h->s_tail, B);
-        T.tile0 = lo / kModTile;
-        T.tiles_launch = tl;
-        hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(groups8 * tl), dim3(kModThreads), 0, h->s_tail, T);
+        (void)tl;
+        wb_tail_launch(h, B, T, lo, len, 384u, h->s_tail);
       }
       HIP_TRY(hipEventRecord(h->ev_join, h->s_tail));
       HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));

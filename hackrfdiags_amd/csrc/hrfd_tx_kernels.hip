@@ -351,6 +351,90 @@ __device__ __forceinline__ float glibc_cosf(float y, int fma_variant)
   return fma_variant ? glibc_sincosf_v<true, true>(y) : glibc_sincosf_v<false, true>(y);
 }
 
+// Stages 6, 7, 8 of the cascade (HB3, HB2, HB1: x8) for ONE 256 kS/s sample j of both rails, in registers: v[rail][0] =
+// x5[j], v[rail][1] = x5[j - 1] (x5[j - 2] only reaches an output of sample j - 1) -> the sample's 8 output IQ pairs,
+// 16 bytes.  Shared by k_mod (every kind: stage 5 in LDS) and k_wb_tail (the WBFM modulator's rails straight from the
+// Nco lookup).  k8000: 1 << 15 in a scalar register (tail_k8000()).
+__device__ __forceinline__ int tail_k8000()
+{
+  int k;                                                  // as a literal it doubles the size of every add that takes it
+  asm("s_mov_b32 %0, 0x8000" : "=s"(k));
+  return k;
+}
+__device__ __forceinline__ uint4 tail_eight(const int (&v)[2][2], const int k8000)
+{
+  (void)k8000;
+  uint32_t w[4];
+  int z[2][8];
+#pragma unroll
+  for (int rail = 0; rail < 2; rail++)
+  {
+    const int xa = v[rail][0], xb = v[rail][1];
+    // stage 6 (HB3): y6[2j-1] (phase 1 of j-1), y6[2j], y6[2j+1]
+    int a0, a1;
+    const int p1 = (xb + 1) >> 1;                       // y6[2j-1], phase 1 of j - 1
+    hb4<Q_INTERP_HB3[0]>(xa, xb, a0, a1);               // y6[2j], y6[2j+1]
+    // stage 7 (HB2): y7[4j-1] (phase 1 of y6[2j-1]), y7[4j..4j+3]
+    int b0, b1, b2, b3;
+    const int q1 = (p1 + 1) >> 1;                       // y7[4j-1]
+#if HRFD_MOD_ZNUM
+    // (the numerators of b0 and b2 are kept: two of stage 8's outputs come straight from them, below; opaque to the
+    //  compiler, which otherwise folds "n + 32768" back into a second multiply-add with another constant)
+    int n0 = (1 << 14) + Q_INTERP_HB2[0] * (a0 + p1);
+    int n2 = (1 << 14) + Q_INTERP_HB2[0] * (a1 + a0);
+    asm("" : "+v"(n0));
+    asm("" : "+v"(n2));
+    b0 = n0 >> 15;                                      // y7[4j]
+    b1 = (a0 + 1) >> 1;                                 // y7[4j+1]
+    b2 = n2 >> 15;                                      // y7[4j+2]
+    b3 = (a1 + 1) >> 1;                                 // y7[4j+3]
+#else
+    hb4<Q_INTERP_HB2[0]>(a0, p1, b0, b1);               // y7[4j], y7[4j+1]
+    hb4<Q_INTERP_HB2[0]>(a1, a0, b2, b3);               // y7[4j+2], y7[4j+3]
+#endif
+    // stage 8 (HB1): y8[8j .. 8j+7], (int8_t) narrowing (:607-610).  Only the low byte of an output is kept, so the
+    // outputs are left as TWICE their Q15 numerators -- the byte wanted is then byte 2 of the word, which v_perm picks
+    // from two words at a time: no shift and no mask per output (hb4z)
+#if HRFD_MOD_ZNUM >= 2
+    // round 6, the same idea for the phase-1 inputs b1 and b3, themselves phase-1 outputs: with c1 = b1 + 1 = (a0 + 3) >> 1
+    // (the same two instructions as b1) the output is byte 2 of c1 << 15 -- a plain shift where (b1 << 15) + (1 << 15) is a
+    // 64-bit-encoded shift-add -- and the phase-0 outputs that take b1 take c1 with the 2 H subtracted from their constant
+    constexpr int kH1x2 = 2 * Q_INTERP_HB1[0];
+    const int c1 = (a0 + 3) >> 1, c3 = (a1 + 3) >> 1;   // b1 + 1, b3 + 1
+    (void)b1;
+    (void)b3;
+    hb4z<Q_INTERP_HB1[0]>(b0, q1, z[rail][0], z[rail][1]);
+    z[rail][2] = ((1 << 15) - kH1x2) + kH1x2 * (c1 + b0);
+    z[rail][3] = c1 << 15;
+    z[rail][4] = ((1 << 15) - kH1x2) + kH1x2 * (b2 + c1);
+    z[rail][6] = ((1 << 15) - kH1x2) + kH1x2 * (c3 + b2);
+    z[rail][7] = c3 << 15;
+#else
+    hb4z<Q_INTERP_HB1[0]>(b0, q1, z[rail][0], z[rail][1]);
+    hb4z<Q_INTERP_HB1[0]>(b1, b0, z[rail][2], z[rail][3]);
+    hb4z<Q_INTERP_HB1[0]>(b2, b1, z[rail][4], z[rail][5]);
+    hb4z<Q_INTERP_HB1[0]>(b3, b2, z[rail][6], z[rail][7]);
+#endif
+#if HRFD_MOD_ZNUM
+    // round 6: where the input of a phase-1 output is itself a phase-0 output, b = N >> 15, byte 2 of (b << 15) + (1 << 15)
+    // is byte 2 of N + (1 << 15): the bits of N below 15 cannot carry into bit 15.  The compiler does not see that only
+    // byte 2 is looked at and builds (N & 0xffff8000) + 0x8000 -- two instructions with 32-bit literals, four times per
+    // sample -- where one add does.
+    z[rail][1] = n0 + k8000;
+    z[rail][5] = n2 + k8000;
+#endif
+  }
+#pragma unroll
+  for (int d = 0; d < 4; d++)
+  {
+    // output dword d = I[2d], Q[2d], I[2d+1], Q[2d+1]: byte 2 of z[0][2d], z[1][2d], z[0][2d+1], z[1][2d+1]
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)z[1][2 * d], (uint32_t)z[0][2 * d], 0x0c0c0602u);
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)z[1][2 * d + 1], (uint32_t)z[0][2 * d + 1], 0x06020c0cu);
+    w[d] = lo | hi;
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 template <int KIND>
 __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 {
@@ -655,14 +739,11 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   // ---- stages 6, 7, 8 in registers: one 256 kS/s sample j -> 8 output IQ pairs
   const int valid = min(kModTile, n - t0);                // input samples really in this tile
   int8_t *out = M.out + ((size_t)c * M.n + t0) * 512;
-#if HRFD_MOD_ZNUM
-  int k8000;                                              // 1 << 15 in a scalar register: as a literal it doubles the size of every add that takes it
-  asm("s_mov_b32 %0, 0x8000" : "=s"(k8000));
-#endif
-  // the tail's inputs of sample j: x5[j], x5[j - 1], x5[j - 2] of both rails
+  const int k8000 = tail_k8000();
+  // the tail's inputs of sample j: x5[j], x5[j - 1] of both rails
   struct In3
   {
-    int v[2][3];
+    int v[2][2];
   };
   auto fetch = [&](const int j) -> In3 {
     In3 f;
@@ -672,7 +753,6 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       const int16_t *x5 = &r[rail][kO5 + kH5];
       f.v[rail][0] = x5[j];
       f.v[rail][1] = x5[j - 1];
-      f.v[rail][2] = x5[j - 2];
     }
     return f;
   };
@@ -680,76 +760,9 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
 #if (HRFD_MOD_ABLATE & 2)
     return make_uint4((uint32_t)j, (uint32_t)j * 3u, (uint32_t)tid, 7u);   // TIMING EXPERIMENT ONLY: no tail arithmetic
 #endif
-    uint32_t w[4];
-    int z[2][8];
-#pragma unroll
-    for (int rail = 0; rail < 2; rail++)
-    {
-      const int xa = f.v[rail][0], xb = f.v[rail][1], xc = f.v[rail][2];
-      // stage 6 (HB3): y6[2j-1] (phase 1 of j-1), y6[2j], y6[2j+1]
-      int a0, a1, p0, p1;
-      hb4<Q_INTERP_HB3[0]>(xb, xc, p0, p1);               // p1 = y6[2j-1]
-      hb4<Q_INTERP_HB3[0]>(xa, xb, a0, a1);               // y6[2j], y6[2j+1]
-      // stage 7 (HB2): y7[4j-1] (phase 1 of y6[2j-1]), y7[4j..4j+3]
-      int b0, b1, b2, b3;
-      const int q1 = (p1 + 1) >> 1;                       // y7[4j-1]
-      (void)p0;
-#if HRFD_MOD_ZNUM
-      // (the numerators of b0 and b2 are kept: two of stage 8's outputs come straight from them, below; opaque to the
-      //  compiler, which otherwise folds "n + 32768" back into a second multiply-add with another constant)
-      int n0 = (1 << 14) + Q_INTERP_HB2[0] * (a0 + p1);
-      int n2 = (1 << 14) + Q_INTERP_HB2[0] * (a1 + a0);
-      asm("" : "+v"(n0));
-      asm("" : "+v"(n2));
-      b0 = n0 >> 15;                                      // y7[4j]
-      b1 = (a0 + 1) >> 1;                                 // y7[4j+1]
-      b2 = n2 >> 15;                                      // y7[4j+2]
-      b3 = (a1 + 1) >> 1;                                 // y7[4j+3]
-#else
-      hb4<Q_INTERP_HB2[0]>(a0, p1, b0, b1);               // y7[4j], y7[4j+1]
-      hb4<Q_INTERP_HB2[0]>(a1, a0, b2, b3);               // y7[4j+2], y7[4j+3]
-#endif
-      // stage 8 (HB1): y8[8j .. 8j+7], (int8_t) narrowing (:607-610).  Only the low byte of an output is kept, so the
-      // outputs are left as TWICE their Q15 numerators -- the byte wanted is then byte 2 of the word, which v_perm picks
-      // from two words at a time: no shift and no mask per output (hb4z)
-#if HRFD_MOD_ZNUM >= 2
-      // round 6, the same idea for the phase-1 inputs b1 and b3, themselves phase-1 outputs: with c1 = b1 + 1 = (a0 + 3) >> 1
-      // (the same two instructions as b1) the output is byte 2 of c1 << 15 -- a plain shift where (b1 << 15) + (1 << 15) is a
-      // 64-bit-encoded shift-add -- and the phase-0 outputs that take b1 take c1 with the 2 H subtracted from their constant
-      constexpr int kH1x2 = 2 * Q_INTERP_HB1[0];
-      const int c1 = (a0 + 3) >> 1, c3 = (a1 + 3) >> 1;   // b1 + 1, b3 + 1
-      (void)b1;
-      (void)b3;
-      hb4z<Q_INTERP_HB1[0]>(b0, q1, z[rail][0], z[rail][1]);
-      z[rail][2] = ((1 << 15) - kH1x2) + kH1x2 * (c1 + b0);
-      z[rail][3] = c1 << 15;
-      z[rail][4] = ((1 << 15) - kH1x2) + kH1x2 * (b2 + c1);
-      z[rail][6] = ((1 << 15) - kH1x2) + kH1x2 * (c3 + b2);
-      z[rail][7] = c3 << 15;
-#else
-      hb4z<Q_INTERP_HB1[0]>(b0, q1, z[rail][0], z[rail][1]);
-      hb4z<Q_INTERP_HB1[0]>(b1, b0, z[rail][2], z[rail][3]);
-      hb4z<Q_INTERP_HB1[0]>(b2, b1, z[rail][4], z[rail][5]);
-      hb4z<Q_INTERP_HB1[0]>(b3, b2, z[rail][6], z[rail][7]);
-#endif
-#if HRFD_MOD_ZNUM
-      // round 6: where the input of a phase-1 output is itself a phase-0 output, b = N >> 15, byte 2 of (b << 15) + (1 << 15)
-      // is byte 2 of N + (1 << 15): the bits of N below 15 cannot carry into bit 15.  The compiler does not see that only
-      // byte 2 is looked at and builds (N & 0xffff8000) + 0x8000 -- two instructions with 32-bit literals, four times per
-      // sample -- where one add does.
-      z[rail][1] = n0 + k8000;
-      z[rail][5] = n2 + k8000;
-#endif
-    }
-#pragma unroll
-    for (int d = 0; d < 4; d++)
-    {
-      // output dword d = I[2d], Q[2d], I[2d+1], Q[2d+1]: byte 2 of z[0][2d], z[1][2d], z[0][2d+1], z[1][2d+1]
-      const uint32_t lo = __builtin_amdgcn_perm((uint32_t)z[1][2 * d], (uint32_t)z[0][2 * d], 0x0c0c0602u);
-      const uint32_t hi = __builtin_amdgcn_perm((uint32_t)z[1][2 * d + 1], (uint32_t)z[0][2 * d + 1], 0x06020c0cu);
-      w[d] = lo | hi;
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    (void)j;
+    const int v[2][2] = {{f.v[0][0], f.v[0][1]}, {f.v[1][0], f.v[1][1]}};
+    return tail_eight(v, k8000);
   };
   auto eight = [&](const int j) -> uint4 { return eight_of(fetch(j), j); };
   if (valid == kModTile)
@@ -1697,6 +1710,123 @@ __global__ __launch_bounds__(kWbRailsThreads) void k_wb_rails(const BaseParams B
     {
       B.wbtail_out[(size_t)c * 2] = w[2];
       B.wbtail_out[(size_t)c * 2 + 1] = w[3];
+    }
+  }
+}
+
+// ---- round 6: k_wb_tail = k_wb_rails + k_mod<WB_TAIL> in one pass, the rails never exist in memory ----------------
+// WbFmModulator::modulateSignal does Nco::runFast, the x900 scaling and the interpolator per sample with nothing stored
+// between (WbFmModulator.cc:583-637).  Rounds 2-5 wrote the rail pair of every 256 kS/s cell back over its phase
+// (k_wb_rails) and read it again in the x8 cascade (k_mod<WB_TAIL>): 8 of the call's 24 bytes of traffic per cell beside
+// the 16 bytes of output.  Here a wave reads a run of PHASES (4 bytes per cell, coalesced dwords), looks the rail pairs
+// up in the 64 KiB table -- in LDS once per PERSISTENT workgroup, not once per tile --, takes the pair of the cell in
+// front from its left neighbour lane (DPP: lane 0 from the last lane of the group in front) and runs stages 6-8 of the
+// cascade in registers (tail_eight, the code k_mod's tail runs): 16 bytes out per cell, one coalesced store per lane.
+// No LDS traffic but the table lookups, no barrier behind the table's load, waves independent of each other.
+// Work item = (channel, run of 2048 cells = 64 input samples: k_mod's tile), eight rounds of 4 x 64 cells; items are
+// dealt like k_mod's tiles: XCD x takes the channels x, x + 8, ... and its waves walk consecutive items (one contiguous
+// output stream per L2).
+struct WbTailParams
+{
+  const uint32_t *cells;    // [C][32 n] the Nco phase of every 256 kS/s sample (float bits; k_phase_rows' output)
+  int8_t *out;              // [C][512 n]
+  const uint32_t *wbpack;   // [16384] the rail-pair table (k_wb_rails)
+  const uint32_t *wbtail;   // [C][2] the previous call's last two rail pairs ([1] is the one in front of cell 0)
+  uint32_t *wbtail_out;     // [C][2] this call's
+  uint32_t n, n_channels;   // input samples per channel
+  uint32_t lo, len;         // the slice [lo, lo + len) of every channel in input samples (len 0: all)
+};
+constexpr int kWtThreads = 512;
+constexpr uint32_t kWtRun = 32u * kModTile;               // cells per work item
+__global__ __launch_bounds__(kWtThreads) void k_wb_tail(const WbTailParams P)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t pack[16384];
+  for (int i = threadIdx.x; i < 16384 / 4; i += kWtThreads)
+  {
+    reinterpret_cast<uint4 *>(pack)[i] = reinterpret_cast<const uint4 *>(P.wbpack)[i];
+  }
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t n32 = P.n * 32u;
+  const uint32_t lo32 = P.lo * 32u;
+  const uint32_t end32 = (P.len != 0u) ? min(n32, (P.lo + P.len) * 32u) : n32;
+  const uint32_t runs = (end32 - lo32 + kWtRun - 1u) / kWtRun;          // work items per channel
+  const uint32_t xcd = blockIdx.x & 7u, wi = blockIdx.x >> 3, wgs_x = gridDim.x >> 3;
+  const uint32_t ch_x = (P.n_channels > xcd) ? (P.n_channels - xcd + 7u) / 8u : 0u;
+  const uint32_t items_x = ch_x * runs;
+  const int k8000 = tail_k8000();
+  const uint32_t voff = lane * 16u;
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  for (uint32_t it = wi * (kWtThreads / 64) + wave; it < items_x; it += wgs_x * (kWtThreads / 64))
+  {
+    const uint32_t ci = it / runs;
+    const uint32_t c = 8u * ci + xcd;
+    const uint32_t q0 = lo32 + (it - ci * runs) * kWtRun;
+    const uint32_t q1 = min(q0 + kWtRun, end32);
+    const uint32_t *row = P.cells + (size_t)c * n32;
+    int8_t *orow = P.out + (size_t)c * n32 * 16u;
+    // the rail pair in front of the run, in every lane: the previous call's last pair, or the lookup of the cell in front
+    uint32_t carry = (q0 == 0u) ? P.wbtail[(size_t)c * 2 + 1] : wb_lookup(pack, row[q0 - 1u]);
+    uint32_t ph[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+      const uint32_t cell = q0 + 64u * m + lane;
+      ph[m] = (cell < q1) ? row[cell] : 0u;
+    }
+#pragma nounroll
+    for (uint32_t q = q0; q < q1; q += 256u)
+    {
+      // (the stores below are opaque to the compiler, which moves no load across them: the next round's phases first)
+      uint32_t nph[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+      {
+        const uint32_t cell = q + 256u + 64u * m + lane;
+        nph[m] = (cell < q1) ? row[cell] : 0u;
+      }
+      uint32_t rails[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+      {
+        rails[m] = wb_lookup(pack, ph[m]);
+      }
+      if (q + 256u >= n32)
+      {
+        // the call's last two pairs are the next call's history (n32 is a multiple of 32: both in one group of 64)
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+        {
+          const uint32_t cell = q + 64u * m + lane;
+          if (cell + 2u == n32 || cell + 1u == n32)
+          {
+            P.wbtail_out[(size_t)c * 2 + (cell + 2u - n32)] = rails[m];
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+      {
+        const uint32_t left = (m == 0) ? carry : rails[m - 1];
+        const uint32_t pv = shr1(rails[m], ror1(left));    // the pair of the cell in front: lane - 1's, lane 0: the last lane's of the group in front
+        const int v[2][2] = {{(int)(int16_t)(rails[m] & 0xffffu), (int)(int16_t)(pv & 0xffffu)}, {(int)rails[m] >> 16, (int)pv >> 16}};
+        const uint4 w4 = tail_eight(v, k8000);
+        const uint32_t g = q + 64u * m;                      // the group's first cell (uniform)
+        if (g + lane < q1)
+        {
+          int8_t *base = orow + (size_t)g * 16u;
+          const u4 d4 = u4{w4.x, w4.y, w4.z, w4.w};
+          // (scalar base, the lane's offset one register for the whole kernel; s_nop 0: see k_mod's tail)
+          asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(voff), "v"(d4), "s"(base));
+        }
+      }
+      carry = rails[3];
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+      {
+        ph[m] = nph[m];
+      }
     }
   }
 }

@@ -58,14 +58,14 @@ def test_behaviour_changing_hooks_are_inert_without_the_opt_in():
         "L = _lib.load()\n"
         "names = ['hrfd_rx_debug_set_atan', 'hrfd_rx_debug_set_warm', 'hrfd_rx_debug_set_run_len', 'hrfd_rx_debug_set_stream',\n"
         "         'hrfd_rx_debug_expire', 'hrfd_rx_debug_set_fir_flow', 'hrfd_rx_debug_set_gated', 'hrfd_rx_debug_set_stagger',\n"
-        "         'hrfd_mod_debug_set_sliced', 'hrfd_mod_debug_set_scan']\n"
+        "         'hrfd_mod_debug_set_sliced', 'hrfd_mod_debug_set_scan', 'hrfd_mod_debug_set_tail']\n"
         "rcs = [getattr(L, n)(None, 0) for n in names]\n"
         "print(rcs, L.hrfd_last_error().decode())\n" % ROOT)
     env = {k: v for k, v in os.environ.items() if k != "HRFD_DEBUG_HOOKS"}
     off = subprocess.check_output([sys.executable, "-c", code], env=env, text=True)
-    assert off.startswith("[-4, -4, -4, -4, -4, -4, -4, -4, -4, -4]") and "HRFD_DEBUG_HOOKS" in off
+    assert off.startswith("[-4, -4, -4, -4, -4, -4, -4, -4, -4, -4, -4]") and "HRFD_DEBUG_HOOKS" in off
     on = subprocess.check_output([sys.executable, "-c", code], env={**env, "HRFD_DEBUG_HOOKS": "1"}, text=True)
-    assert on.startswith("[-1, -1, -1, -1, -1, -1, -1, -1, -1, -1]")       # HRFD_EINVAL: they looked at the NULL handle
+    assert on.startswith("[-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1]")       # HRFD_EINVAL: they looked at the NULL handle
 
 
 def test_no_cpu_fallback(lib):

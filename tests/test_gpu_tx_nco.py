@@ -115,7 +115,7 @@ def test_nco_many_channels(oracle):
 
 
 # ---------------------------------------------------------------- AM / FM modulators
-def _mod_case(oracle, kind, api_kind, tol):
+def _mod_case(oracle, kind, api_kind, tol, tail=None):
     """many channels, calls of ragged lengths, a per-channel parameter change and a reset between
     calls; returns the fraction of output bytes that differ from the oracle (all within tol)."""
     C = 4
@@ -125,6 +125,8 @@ def _mod_case(oracle, kind, api_kind, tol):
     pcm[3, 100:140] = 32767
     pcm[3, 140:180] = -32768
     m = api.Mod(api_kind, C)
+    if tail is not None:
+        m.debug_set_tail(tail)
     os_ = [getattr(oracle, kind)() for _ in range(C)]
     off, diff, total = 0, 0, 0
     for k, n in enumerate([512, 512, 100, 33, 1, 700, 512]):
@@ -152,10 +154,12 @@ def test_am_modulator_bit_exact(oracle):
     assert _mod_case(oracle, "ammod", api.MOD_AM, 0) == 0.0
 
 
-def test_wbfm_modulator_bit_exact(oracle):
+@pytest.mark.parametrize("tail", [1, 0], ids=["k_wb_tail", "rails_then_cascade"])
+def test_wbfm_modulator_bit_exact(oracle, tail):
     """WbFmModulator: integer cascades around a table-lookup Nco whose phase recurrence is
-    reproduced operation for operation -- no tolerance"""
-    assert _mod_case(oracle, "wbfmmod", api.MOD_WBFM, 0) == 0.0
+    reproduced operation for operation -- no tolerance.  Both forms of the last pass: the lookup fused into the x8 cascade
+    (k_wb_tail, round 6, the default) and rounds 2-5's two kernels."""
+    assert _mod_case(oracle, "wbfmmod", api.MOD_WBFM, 0, tail) == 0.0
 
 
 @pytest.mark.parametrize("n", [16 * 512 + 77, 2061, 1601, 1537, 4600, 4609], ids=lambda n: "n%d" % n)
@@ -167,14 +171,17 @@ def test_wbfm_modulator_time_slices(oracle, n):
     which the slices halve four times at the end instead of twice (72 tiles)."""
     C = 5
     pcm = np.stack([synth.lcg_pcm(140 + c, 2 * n) for c in range(C)])
-    a, b = api.Mod(api.MOD_WBFM, C), api.Mod(api.MOD_WBFM, C)
+    a, b, d = api.Mod(api.MOD_WBFM, C), api.Mod(api.MOD_WBFM, C), api.Mod(api.MOD_WBFM, C)
     a.debug_set_sliced(2)                                   # slices whether or not the recurrence's stream got CUs of its own
     b.debug_set_sliced(0)
+    d.debug_set_sliced(2)
+    d.debug_set_tail(0)                                     # rounds 2-5's last pass: k_wb_rails in place, then k_mod<WB_TAIL>
     os_ = [oracle.wbfmmod() for _ in range(C)]
     for call in range(2):
         x = pcm[:, call * n:(call + 1) * n]
-        ga, gb = a.process(x), b.process(x)
+        ga, gb, gd = a.process(x), b.process(x), d.process(x)
         assert (ga == gb).all(), call
+        assert (ga == gd).all(), call
         for c in range(C):
             assert (ga[c] == os_[c].process(x[c])).all(), (call, c)
 

@@ -4,6 +4,8 @@ usage: python tools/mod_time.py KIND [C] [B] [reps] [warm]   KIND: ssb | interp 
 (A/B: alternate `HRFD_LIB=.../variants/NAME/libhrfd.so python tools/mod_time.py ...` on ONE box: tools/mod_ab.sh.)"""
 import os, sys, zlib
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+if os.environ.get("HRFD_MOD_TAIL"):
+    os.environ["HRFD_DEBUG_HOOKS"] = "1"               # (read once by the library: before it is loaded)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from hackrfdiags_amd import api
@@ -21,6 +23,8 @@ pcm = torch.randint(-amp, amp, (C, n * (2 if kind == "interp" else 1)), dtype=to
 out = torch.zeros((C, 512 * n), dtype=torch.int8, device=dev)
 torch.cuda.synchronize()
 m = api.Mod(K, C)
+if os.environ.get("HRFD_MOD_TAIL"):
+    m.debug_set_tail(int(os.environ["HRFD_MOD_TAIL"]))   # WBFM: 0 = k_wb_rails + k_mod<WB_TAIL>, 1 = k_wb_tail
 st = torch.cuda.Stream(device=dev)
 for _ in range(warm):
     m.process_device(pcm.data_ptr(), n, out.data_ptr(), stream=st.cuda_stream)
