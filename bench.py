@@ -174,7 +174,7 @@ def cpu_baseline_port(seconds, threads, x):
 
 MOD_KINDS = {"ssbmod": ("MOD_SSB", "SSB"), "ammod": ("MOD_AM", "AM"), "fmmod": ("MOD_FM", "FM"), "wbfmmod": ("MOD_WBFM", "WBFM")}
 MOD_KERNELS = {"ssbmod": "hrfd::k_mod<1>",
-               "wbfmmod": "hrfd::k_mod<101> (x32 + Nco step), k_phase_rows (the serial Nco recurrence, nine time slices), k_wb_rails, hrfd::k_mod<102> (x8)"}
+               "wbfmmod": "hrfd::k_mod<101> (x32 + Nco step), k_phase_rows (the serial Nco recurrence, nine time slices), hrfd::k_wb_tail (Nco lookup + x8, round 6)"}
 
 
 def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle, rank, world, extras=True):
@@ -189,16 +189,9 @@ def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle,
     kind, kname = MOD_KINDS[workload]
     m = api.Mod(getattr(api, kind), C, device=device.index)
     stream = torch.cuda.Stream(device=device)
-    every = 4 if steps >= 16 else 1                      # every 4th step is bracketed with events (see measure_rx)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range((steps + every - 1) // every)]
 
-    def step(i=None):
-        timed = i is not None and i % every == 0
-        if timed:
-            ev[i // every][0].record(stream)
+    def step():
         m.process_device(pcm.data_ptr(), n, out.data_ptr(), stream=stream.cuda_stream)
-        if timed:
-            ev[i // every][1].record(stream)
 
     for _ in range(settle + warmup):
         step()
@@ -207,20 +200,33 @@ def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle,
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # (round 6, as on the receive side since round 5: ONE event pair on the launch stream around all calls of the timed
+    #  region prices the roofline; single calls are bracketed BEHIND the region for min / median)
+    ev_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
+    ev_region[0].record(stream)
+    for _ in range(steps):
+        step()
+    ev_region[1].record(stream)
     stream.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, device)
     m.sync()                                             # raises if a k_phase_scan wait expired
+    region_ms = ev_region[0].elapsed_time(ev_region[1]) / steps
+    n_samp = min(4, steps)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_samp)]
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    stream.synchronize()
+    m.sync()
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     samples = C * n * 256
     algo_bytes = C * n * (2 + 512)
-    mean_ms = float(np.mean(kernel_ms))
-    achieved = algo_bytes / (mean_ms * 1e-3) / 1e9
+    achieved = algo_bytes / (region_ms * 1e-3) / 1e9
     fill = stream_gbs(device, 1, out) if (rank == 0 and extras) else None
     if fill is not None:
         assert under_profiler() or achieved <= fill, f"the modulator writes faster ({achieved:.0f} GB/s) than a kernel that does nothing else ({fill:.0f}): a denominator is wrong"
@@ -233,9 +239,10 @@ def measure_mod(api, shard, device, dist, workload, C, B, steps, warmup, settle,
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "measured_stream_write_GBps": None if fill is None else round(fill, 1),
                      "frac_of_measured_write": None if fill is None else round(achieved / fill, 4),
-                     "kernel": MOD_KERNELS.get(workload, "k_am_rails / k_fm_phase + k_fm_rails, then hrfd::k_mod<100>"),
-                     "kernel_ms_mean": round(mean_ms, 4), "kernel_ms_min": round(float(np.min(kernel_ms)), 4),
-                     "algorithmic_bytes_per_launch": algo_bytes},
+                     "kernel": MOD_KERNELS.get(workload, "k_am_rails / k_fm_step + k_phase_rows + k_fm_rails, then hrfd::k_mod<100>"),
+                     "region_ms_per_launch": round(region_ms, 4), "priced_with": "region_ms_per_launch (one HIP event pair around the timed region / steps)",
+                     "kernel_ms_min": round(float(np.min(kernel_ms)), 4), "kernel_ms_median": round(float(np.median(kernel_ms)), 4),
+                     "kernel_launches_sampled": n_samp, "algorithmic_bytes_per_launch": algo_bytes},
     }
 
 
@@ -697,9 +704,11 @@ def verify_against_oracle(iq, pcm, modes, launches, B, n, threshold, seed=0):
     """`--verify` (on by default for the receive workloads): AFTER the timed region, `n` channels of the bench's own batch
     -- channel 0, the last one and seeded-random ones from the whole range -- go through the sequential CPU oracle
     (tests/reflib.Oracle: the checker, never the thing measured), from a fresh state through every launch the handle has
-    seen (settle + warm-up + timed steps over the same resident batch, the streams continuing), and the PCM the LAST timed
-    launch left in the output buffer must be the oracle's, sample for sample.  One Python thread per channel (ctypes
-    releases the GIL inside the oracle)."""
+    seen (settle + warm-up + timed steps + the single launches sampled behind the region, all over the same resident batch,
+    the streams continuing), and the PCM the handle's LAST launch left in the output buffer -- the last of the sampled
+    launches behind the timed region -- must be the oracle's, sample for sample.  One Python thread per channel (ctypes
+    releases the GIL inside the oracle).  With N > 1 only rank 0 verifies (seconds; the other ranks wait for it in the
+    first collective of multi_gpu_legs)."""
     from concurrent.futures import ThreadPoolExecutor
     from tests import reflib
     orc = reflib.Oracle()
@@ -854,7 +863,12 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
             modes = [[api.AM, api.FM, api.WBFM, api.LSB][(4 * c) // C] for c in range(C)]
         elif workload in ("am", "fm", "ssb"):
             modes = [{"am": api.AM, "fm": api.FM, "ssb": api.LSB}[workload]] * C
-        out["verification"] = verify_against_oracle(iq, pcm, modes, settle + warmup + steps + n_samp, B, verify, threshold, seed=C + steps)
+        try:
+            out["verification"] = verify_against_oracle(iq, pcm, modes, settle + warmup + steps + n_samp, B, verify, threshold, seed=C + steps)
+        except AssertionError:
+            raise                                        # a PCM mismatch: no line
+        except Exception as e:                           # noqa: BLE001  (the checker broke, not the library: the measurements stand, the line says so)
+            out["verification"] = {"oracle_channels_checked": 0, "error": repr(e)[:200]}
     rx.close()
     del iq, pcm, n_pcm, iq256, iq_root
     torch.cuda.empty_cache()                             # the next workload of the line starts from a clean allocator
@@ -862,14 +876,15 @@ def measure_rx(api, shard, device, dist, *, workload, C, B, signal, steps, warmu
 
 
 def brief(r, text, extra=None):
-    """one entry of the bench line's `also` object"""
+    """one entry of the verbose `also` object (--extras-verbose)"""
     d = {"workload": text, "ms_per_step": round(r["ms_per_step"], 4), "value_MSamples_per_s": round(r["value"], 1)}
     if "roofline" in r:                                  # modulators
-        d["kernel_ms_mean"] = r["roofline"]["kernel_ms_mean"]
+        d["region_ms_per_launch"] = r["roofline"]["region_ms_per_launch"]
+        d["kernel_ms_min"] = r["roofline"]["kernel_ms_min"]
         d["roofline_frac"] = r["roofline"]["frac"]
         d["algorithmic_bytes_per_launch"] = r["roofline"]["algorithmic_bytes_per_launch"]
     else:
-        d["kernel_ms_mean"] = round(r["mean_ms"], 4)
+        d["region_ms_per_launch"] = round(r["mean_ms"], 4)
         d["kernel_ms_min"] = round(r["kernel_ms_min"], 4)
         d["roofline_frac"] = round(r["achieved"] / HBM_PEAK_GBS, 4)
         d["algorithmic_bytes_per_launch"] = r["algo_bytes"]
@@ -887,6 +902,23 @@ def brief(r, text, extra=None):
         if t is None:
             d["traffic_source"] = src
     return d
+
+
+def compact(d):
+    """the same entry as the driver-visible line carries it (`configs`): ms per step, fraction of the 8 TB/s roofline priced
+    with the region event pair, PMC traffic over algorithmic bytes -- everything else of the entry is in `also`
+    (--extras-verbose) and in DESIGN.md"""
+    c = {"ms": d.get("ms_per_step"), "frac": d.get("roofline_frac"), "traffic_x": d.get("traffic_over_algorithmic")}
+    if d.get("region_ms_per_launch") is not None:
+        c["kernel_ms"] = d["region_ms_per_launch"]
+    v = d.get("verification")
+    if v:
+        c["oracle_channels_ok"] = v.get("oracle_channels_checked") if not v.get("error") and v.get("pcm_blocks_mismatching", 0) == 0 else 0
+        if v.get("error"):
+            c["verify_error"] = v["error"][:80]
+    if "invalid" in d:
+        c["invalid"] = d["invalid"]
+    return c
 
 
 def also_lines(api, shard, device, args):
@@ -922,7 +954,8 @@ def also_lines(api, shard, device, args):
        warmup=min(args.warmup, 5), settle=0, idle_s=1.0)
     rx("wbfm_256x16_quiet25", workload="wbfm", C=256, B=16, signal="fmtone", quiet_fraction=0.25, threshold=-30)
     rx("wbfm_256x16_iqdump", workload="wbfm", C=256, B=16, signal="fmtone", iqdump=True)
-    for name, wl, C in (("ssbmod_1024x16", "ssbmod", 1024), ("wbfmmod_1024x16", "wbfmmod", 1024)):
+    for name, wl, C in (("ssbmod_1024x16", "ssbmod", 1024), ("ammod_1024x16", "ammod", 1024), ("fmmod_1024x16", "fmmod", 1024),
+                        ("wbfmmod_1024x16", "wbfmmod", 1024)):
         r = measure_mod(api, shard, device, None, wl, C, 16, K, W, settle, 0, 1, extras=False)
         out[name] = brief(r, f"{C} {r['kname']} modulator channels, 16 blocks of 512 PCM samples per step"
                           + (" (BASELINE config 5)" if wl == "ssbmod" else ""), {"steps": K, "warmup": W, "settle_steps": settle, "name": name})
@@ -1025,6 +1058,26 @@ def multi_gpu_legs(api, shard, device, dist, args, r_excl, C, B, settle, rank, w
     return out
 
 
+def headline_kernel_name(args):
+    """the dominant kernel of the headline workload, with the template arguments it really runs with"""
+    if args.workload == "wbfm":
+        return ("hrfd::k_rx_wbfm_flow<SVC=4 (flow_body runs WBFM with 6 service + 10 stream waves), GATED=false, DUMP=%s, MODE=3 WBFM>%s"
+                % ("true" if args.iqdump else "false", " + the gated pass behind it" if args.quiet_fraction > 0 else ""))
+    if args.workload == "mixed" and not args.serial_modes:
+        return "hrfd::k_rx_flow_bank<4> (several modes in one launch, the mode read per workgroup)"
+    return "hrfd::k_rx_wbfm_flow<4, .., MODE> per mode (--serial-modes: k_rx_fir / k_rx_post / k_rx_finish)"
+
+
+def libm_variant_name():
+    """which build of glibc's sinf / cosf the host's libm is, as libhrfd probed it (visible in the line): the FM
+    modulator, Nco::run and the pm / fm generators follow it bit for bit; "unknown" = neither probed build, +-1 LSB there"""
+    from hackrfdiags_amd import _lib
+    L = _lib.load()
+    if not hasattr(L, "hrfd_libm_variant"):
+        return None
+    return {0: "glibc sincosf without FMA", 1: "glibc sincosf, FMA build", -1: "unknown libm (device follows the FMA build; FM / pm / Nco::run expect +-1 LSB)"}.get(int(L.hrfd_libm_variant()), "?")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1058,6 +1111,9 @@ def main():
     ap.add_argument("--shards", type=int, default=8, help="--workload fanout: shards of the bank (config 4: 8)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extras-verbose", action="store_true",
+                    help="print the full `also` object (every entry with its workload text, byte counts, verification record) beside "
+                         "the compact `configs`; the default line stays under 8 KB (the driver keeps a line's tail)")
     ap.add_argument("--no-extras", action="store_true",
                     help="leave out the end-to-end and single-block latency figures and the `also` measurements "
                          "(profiling runs: only the headline launches in the kernel statistics)")
@@ -1086,6 +1142,16 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)    # nccl == RCCL on ROCm
 
     from hackrfdiags_amd import api, shard
+
+    if rank == 0 and args.verify and args.workload not in MOD_KINDS and args.workload not in ("ingest", "fanout"):
+        # the checker is built and loaded BEFORE anything is measured (tests/reflib runs `make -C oracle` when the library is
+        # stale): a broken checker must not cost the line its measurements
+        try:
+            from tests import reflib
+            reflib.Oracle()
+        except Exception as e:                               # noqa: BLE001
+            print(f"bench.py: --verify switched off, the oracle does not load: {e!r}", file=sys.stderr)
+            args.verify = 0
 
     if args.workload in MOD_KINDS:
         return bench_mod(args, api, device, rank, world, dist)
@@ -1149,37 +1215,27 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "traffic_source": traffic_src,
                 "traffic_over_algorithmic": None if traffic is None else round(traffic / r["algo_bytes"], 4),
-                "measured_stream_read_GBps": round(read_gbs, 1),
-                "frac_of_measured_read": round(achieved / read_gbs, 4),
-                "measured_stream_write_GBps": round(write_gbs, 1),
-                "issue": issue_summary() if (args.workload == "wbfm" and C == 256 and B == 16) else None,
-                "kernel": ("hrfd::k_rx_wbfm_flow<4, GATED=false, DUMP=%s, WBFM> (re-split, round 5: one persistent workgroup per CU, "
-                           "10 stream waves put (q, i) pairs into a 512-tile LDS ring, 6 service waves do theta (first-quadrant "
-                           "table in LDS), wrap, de-emphasis recurrence with the tile's v in registers, integer stages)%s"
-                           % ("true" if args.iqdump else "false",
-                                                            ", the gated pass behind it" if args.quiet_fraction > 0 else "")
-                           if args.workload == "wbfm" else
-                           "hrfd::k_rx_flow_bank<4> (a bank of several modes as one launch, the mode read per workgroup)"
-                           if args.workload == "mixed" and not args.serial_modes else
-                           "the demodulator kernels of a step (hrfd::k_rx_wbfm_flow<4, .., MODE> per mode; with --serial-modes "
-                           "the block kernels k_rx_fir / k_rx_post / k_rx_finish): first kernel's start to last kernel's end, "
-                           "HIP events on the launch stream"),
-                "kernel_ms_mean": round(r["mean_ms"], 4),
-                "kernel_launches_timed": r["launches_timed"],
-                "kernel_timing": "one HIP event pair on the launch stream around all launches of the timed region / steps; "
-                                 "min, median, sampled_mean: single launches bracketed BEHIND the region",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": r["algo_bytes"],
+                "kernel": headline_kernel_name(args),
+                "region_ms_per_launch": round(r["mean_ms"], 4),
+                "priced_with": "region_ms_per_launch: one HIP event pair on the launch stream around the %d launches of the timed region / steps "
+                               "(a throughput reciprocal: back-to-back launches); kernel_ms_*: single launches bracketed BEHIND the region" % r["launches_timed"],
                 "kernel_ms_min": round(r["kernel_ms_min"], 4),
                 "kernel_ms_median": round(r["kernel_ms_median"], 4),
                 "kernel_ms_sampled_mean": round(r["kernel_ms_sampled_mean"], 4),
                 "kernel_launches_sampled": r["launches_sampled"],
-                "algorithmic_bytes_per_launch": r["algo_bytes"],
+                "measured_stream_read_GBps": round(read_gbs, 1),
+                "frac_of_measured_read": round(achieved / read_gbs, 4),
+                "measured_stream_write_GBps": round(write_gbs, 1),
+                "issue": issue_summary() if (args.workload == "wbfm" and C == 256 and B == 16) else None,
             },
             "verification": {"uncommitted_launches": counters[5], "tiles_repaired_in_place": counters[4],
                              "launches": counters[6], **r.get("verification", {"oracle_channels_checked": 0})},
             "kernel_code_tag": kernel_code_tag(),
             "kernel_source_tag": kernel_source_tag(),
+            "libm_variant": libm_variant_name(),
             "runtime": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "under_profiler": under_profiler()},
         }
         if multi is not None:
@@ -1194,10 +1250,30 @@ def main():
             line["end_to_end"] = end_to_end(api, device, C)
             line["single_block_latency_ms"] = single_block_latency_ms(api, device)
         if default_headline and not args.no_extras:
-            line["also"] = also_lines(api, shard, device, args)
+            also = also_lines(api, shard, device, args)
+            if args.extras_verbose:
+                line["also"] = also
+            # The driver keeps a line's TAIL: every other BASELINE configuration, the north star's shape and the robustness
+            # cases as one compact object right in front of cpu_baseline (ms per step, fraction of 8 TB/s priced with the
+            # region event pair, PMC traffic over algorithmic bytes); the headline repeated as its first entry.
+            head = {"ms": line["ms_per_step"], "frac": line["roofline"]["frac"], "traffic_x": line["roofline"]["traffic_over_algorithmic"],
+                    "kernel_ms": line["roofline"]["region_ms_per_launch"]}
+            cfg = {"wbfm_256x16": head}
+            for k, d in also.items():
+                if k.startswith("realtime"):
+                    cfg[k] = {"p50_ms": d["paced_64ms"]["p50_ms"], "p99_ms": d["paced_64ms"]["p99_ms"], "budget_used_p99": d["paced_64ms"]["budget_used_p99"],
+                              **({"invalid": d["invalid"]} if "invalid" in d else {})}
+                elif k == "fallback_wbfm_64x80_host_replay":
+                    cfg[k] = {"gates_open_ms": d["gates_open_ms"], "gates_closing_ms": d["gates_closing_ms"], "replay_cost_ms": d["replay_cost_ms"]}
+                else:
+                    cfg[k] = compact(d)
+            line["configs"] = cfg
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        print(json.dumps(line), flush=True)
+        text = json.dumps(line)
+        if len(text) > 8000 and not args.extras_verbose:
+            print(f"bench.py: the line is {len(text)} bytes (> 8000: the driver keeps a tail)", file=sys.stderr)
+        print(text, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -146,6 +146,9 @@ def load() -> C.CDLL:
     L.hrfd_mod_process.argtypes = [_vp, _vp, C.c_uint32, _vp, _u32p]
     L.hrfd_mod_process_device.argtypes = [_vp, _vp, C.c_uint32, _vp, _vp]
     L.hrfd_mod_sync.argtypes = [_vp]
+    if hasattr(L, "hrfd_libm_variant"):
+        L.hrfd_libm_variant.argtypes = []
+        L.hrfd_libm_variant.restype = C.c_int
     L.hrfd_mod_debug_set_sliced.argtypes = [_vp, C.c_int]
     L.hrfd_mod_debug_set_scan.argtypes = [_vp, C.c_int]
     if hasattr(L, "hrfd_mod_debug_set_tail"):              # (round 6; an older build named by HRFD_LIB has none)

@@ -358,7 +358,11 @@ __device__ __forceinline__ float glibc_cosf(float y, int fma_variant)
 __device__ __forceinline__ int tail_k8000()
 {
   int k;                                                  // as a literal it doubles the size of every add that takes it
+#if defined(HRFD_K8000_VGPR)
+  asm("v_mov_b32 %0, 0x8000" : "=v"(k));                 // (A/B: a vector register instead of a scalar one)
+#else
   asm("s_mov_b32 %0, 0x8000" : "=s"(k));
+#endif
   return k;
 }
 __device__ __forceinline__ uint4 tail_eight(const int (&v)[2][2], const int k8000)

@@ -254,7 +254,7 @@ int hrfd_fanout_collect(hrfd_fanout *f, int dst_device, int16_t *d_pcm_all, uint
 /* kinds HRFD_MOD_AM / HRFD_MOD_FM replace AmModulator::acceptData (AmModulator.cc:381-395,
  * modulateSignal :574-612) and FmModulator::acceptData (FmModulator.cc:393-407, modulateSignal
  * :586-627: an 8 kS/s Nco driven by deviation * pcm / 32768), same x256 cascade and tables;
- * PCM in, as for SSB.  FM goes through cos/sin: int8 IQ within +-1 LSB of the reference. */
+ * PCM in, as for SSB.  FM goes through cosf / sinf: bit-exact on a glibc host since round 5 (hrfd_libm_variant() below). */
 #define HRFD_MOD_AM     3
 #define HRFD_MOD_FM     4
 /* kind HRFD_MOD_WBFM replaces WbFmModulator::acceptData (WbFmModulator.cc:341-356: PCM x32,
@@ -266,11 +266,16 @@ int hrfd_fanout_collect(hrfd_fanout *f, int dst_device, int16_t *d_pcm_all, uint
  * am.cc:40-52 ((pcm*0.8 + 65536)/4 on both rails), dsb.cc:38-46 (pcm/4), pm.cc:41-53
  * (phase = pcm/60000*pi, 16000*cos/sin), fm.cc:44-77 (theta += pcm/65536*3.5, wrapped at +-2pi).
  * PCM in, int8 IQ at 2.048 MS/s out -- the .iq files that `load iqfile` plays (hrfd_play).
- * AM and DSB are bit-exact; PM and FM go through cos/sin: int8 IQ within +-1 LSB of the reference. */
+ * All four bit-exact (PM and FM go through cosf / sinf: on a glibc host, hrfd_libm_variant() below). */
 #define HRFD_MOD_SIG_AM  6
 #define HRFD_MOD_SIG_DSB 7
 #define HRFD_MOD_SIG_PM  8
 #define HRFD_MOD_SIG_FM  9
+/* Which build of glibc's sinf / cosf the HOST's libm is: the reference reaches them through cos(float) / sin(float)
+ * (Nco.cc:186-199, FmModulator.cc:600, signals/pm.cc, fm.cc) and the device restates that build bit for bit.
+ * 1 = FMA build, 0 = without FMA, -1 = neither probed build (a libm that is not glibc's: the device follows the FMA
+ * build and the FM modulator, Nco::run and the pm / fm generators may then differ from that host's libm by +-1 LSB). */
+int hrfd_libm_variant(void);
 int hrfd_mod_create(int kind, uint32_t n_channels, int device, hrfd_mod **out);
 int hrfd_mod_destroy(hrfd_mod *h);
 int hrfd_mod_reset(hrfd_mod *h, uint32_t channel);

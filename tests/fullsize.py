@@ -94,7 +94,8 @@ def check_rx_bank_distinct(oracle, api, C, B, mode_of, launches=2, n_check=64, t
     rx = api.Rx(C)
     other = None
     _set_modes(rx, C, mode_of)
-    if twin is not None:
+    from tests.hooks import HOOKS_ON
+    if twin is not None and HOOKS_ON:                    # (the second kernel is chosen through a hook: left out in the shipped state)
         other = api.Rx(C)
         _set_modes(other, C, mode_of)
         twin(other)
