@@ -1280,22 +1280,29 @@ extern "C" int hrfd_rx_failed_channels(hrfd_rx *h, uint8_t *out, uint32_t n)
 // Replays `subset` (ascending channel ids) through the exact path: one block per launch (state advances in
 // order); a channel whose de-emphasis tiles did not re-synchronise is redone on the one-lane path.  Inputs and
 // outputs are the full [n_channels][n_blocks][...] device buffers of the call being repaired.
+// (round 6: the blocks [b0, b0 + nb) of the call -- hrfd_rx_process_block repairs a long call chunk by chunk)
 static int rx_replay(hrfd_rx *h, const std::vector<uint32_t> &subset, const int8_t *d_iq, uint64_t stride,
                      uint32_t block_bytes, uint32_t n_blocks, uint32_t gain_db, int16_t *d_pcm, uint32_t *d_npcm,
-                     uint32_t *d_mag, uint8_t *d_allowed, int8_t *d_iq256, hipStream_t s, bool pcm_is_clear)
+                     uint32_t *d_mag, uint8_t *d_allowed, int8_t *d_iq256, hipStream_t s, bool pcm_is_clear,
+                     uint32_t b0 = 0, uint32_t nb = 0)
 {
   if (subset.empty())
   {
     return HRFD_OK;
   }
+  if (nb == 0)
+  {
+    nb = n_blocks - b0;
+  }
   // squelched units write no PCM: they must read as zeros, not as what a failed batch left there
-  const size_t row = (size_t)n_blocks * ((block_bytes + 511u) / 512u) * sizeof(int16_t);
+  const size_t blk_row = (size_t)((block_bytes + 511u) / 512u) * sizeof(int16_t);
+  const size_t row = (size_t)n_blocks * blk_row;
   const bool whole_bank = subset.size() == h->n_channels;
   if (pcm_is_clear)
   {
     // (no batch ran over this buffer: the caller's memset still stands)
   }
-  else if (whole_bank)
+  else if (whole_bank && nb == n_blocks)
   {
     HIP_TRY(hipMemsetAsync(d_pcm, 0, row * h->n_channels, s));
   }
@@ -1303,10 +1310,10 @@ static int rx_replay(hrfd_rx *h, const std::vector<uint32_t> &subset, const int8
   {
     for (uint32_t c : subset)
     {
-      HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(d_pcm) + row * c, 0, row, s));
+      HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(d_pcm) + row * c + blk_row * b0, 0, blk_row * nb, s));
     }
   }
-  for (uint32_t b = 0; b < n_blocks; b++)
+  for (uint32_t b = b0; b < b0 + nb; b++)
   {
     // attempt 0: the exact per-block kernel; attempt 1: its one-lane de-emphasis for the channels whose tiles did not
     // re-synchronise.  The whole bank runs on the cached per-mode lists (no subset, no upload: the reference's own
@@ -1408,29 +1415,39 @@ extern "C" int hrfd_rx_process_block(hrfd_rx *h, const int8_t *iq, uint32_t bloc
   }
   else
   {
-  std::vector<uint32_t> redo;                              // channels to run on the exact per-block path
-  if (n_blocks > 1 && (uint32_t)(kMaxHal + 64) * 16u <= block_bytes)
+  // Round 6: a call of more than 64 blocks runs as CHUNKS of at most 64, one batch launch each (every chunk then has the
+  // shapes a 64-block call has: the flow kernels for the FIR modes, and the gated pass on the device behind them -- until
+  // round 5 a long call with closing gates went back to the host block by block: +6 ms for 64 channels x 80 blocks).  The
+  // chunks follow each other on the stream; the host looks at every chunk's verdict before the next one starts, so a
+  // channel that did not commit is replayed over ITS chunk's blocks from the state the chunk in front left.
+  const bool batch_ok = (uint32_t)(kMaxHal + 64) * 16u <= block_bytes;
+  for (uint32_t b0 = 0; b0 < n_blocks; b0 += 64u)
   {
-    // whole batch in one launch, blocks of a channel in parallel (speculative)
-    const LaunchOpts opt = {n_blocks, 0, 0, 0};
-    rc = rx_launch(h, h->d_iq, stride, block_bytes, n_blocks, gain_db, h->d_pcm, h->d_npcm,
-                   h->d_mag_out, h->d_allowed, d_iq256, s, opt);
-    if (rc != HRFD_OK) return rc;
-    if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
-    for (uint32_t c = 0; c < C && viol != 0; c++)
+    const uint32_t nb = std::min(64u, n_blocks - b0);
+    std::vector<uint32_t> redo;                            // channels to run on the exact per-block path
+    const bool batch_ran = nb > 1 && batch_ok;
+    if (batch_ran)
     {
-      if (h->h_fail[c] != 0) redo.push_back(c);
+      // the chunk in one launch, blocks of a channel in parallel (speculative)
+      const LaunchOpts opt = {n_blocks, b0, 0, 0};
+      rc = rx_launch(h, h->d_iq + (size_t)b0 * block_bytes, stride, block_bytes, nb, gain_db, h->d_pcm, h->d_npcm,
+                     h->d_mag_out, h->d_allowed, d_iq256, s, opt);
+      if (rc != HRFD_OK) return rc;
+      if ((rc = hrfd_rx_sync(h, &viol)) != HRFD_OK) return rc;
+      for (uint32_t c = 0; c < C && viol != 0; c++)
+      {
+        if (h->h_fail[c] != 0) redo.push_back(c);
+      }
     }
-  }
-  else
-  {
-    for (uint32_t c = 0; c < C; c++) redo.push_back(c);
-  }
-  const bool batch_ran = (n_blocks > 1 && (uint32_t)(kMaxHal + 64) * 16u <= block_bytes);
-  if ((rc = rx_replay(h, redo, h->d_iq, stride, block_bytes, n_blocks, gain_db, h->d_pcm, h->d_npcm, h->d_mag_out,
-                      h->d_allowed, d_iq256, s, !batch_ran)) != HRFD_OK)
-  {
-    return rc;
+    else
+    {
+      for (uint32_t c = 0; c < C; c++) redo.push_back(c);
+    }
+    if ((rc = rx_replay(h, redo, h->d_iq, stride, block_bytes, n_blocks, gain_db, h->d_pcm, h->d_npcm, h->d_mag_out,
+                        h->d_allowed, d_iq256, s, !batch_ran, b0, nb)) != HRFD_OK)
+    {
+      return rc;
+    }
   }
   }
   HIP_TRY(hipMemcpyAsync(pcm, h->d_pcm, pcm_bytes, hipMemcpyDeviceToHost, s));

@@ -155,7 +155,9 @@ int hrfd_rx_process_device(hrfd_rx *h, const int8_t *d_iq, uint64_t channel_stri
  * resubmit that channel one block per call (n_blocks == 1 is always exact) --
  * hrfd_rx_failed_channels says which, hrfd_rx_process_block does all of this by
  * itself.  Closed squelch gates are not failures (the device repairs them, see above) unless the batch has more
- * than 64 blocks or runs on the block kernels (small banks, odd block sizes). */
+ * than 64 blocks or runs on the block kernels (small banks, odd block sizes).  (hrfd_rx_process_block runs a call of
+ * more than 64 blocks as chunks of at most 64, each with the device's repair behind it: a caller of this entry that wants
+ * the same keeps its calls at 64 blocks or fewer.) */
 int hrfd_rx_sync(hrfd_rx *h, uint32_t *n_violations);
 /* out[c] != 0 for the channels of that call that did not commit (n = n_channels). */
 int hrfd_rx_failed_channels(hrfd_rx *h, uint8_t *out, uint32_t n);
