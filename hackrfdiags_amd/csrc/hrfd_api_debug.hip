@@ -247,16 +247,18 @@ extern "C" int hrfd_rx_debug_set_stream(hrfd_rx *h, int on)
 
 // test hook: workgroup 0 of the NEXT k_rx_wbfm_flow launch treats its wait number `where` (1 ring space, 2 blocks
 // finished, 3 a generation's units, 4 partial sums, 5 verification order, 6 integer-stage order, 7 AM / SSB: room in the
-// four-generation rings) as expired the first
+// four-generation rings, ..., 15 a block's magnitude slot: block b - 16 finished) as expired the first
 // time it polls it -- the bounded-spin failure path (kFailExpired, abort word, host replay of the channel) on demand
 // (where = 1000 p + g: no wait expires; the service wave of generation g of workgroup 0 is held up behind hand-over point p
 // of its loop instead: flow_hold_up)
 extern "C" int hrfd_rx_debug_expire(hrfd_rx *h, int where)
 {
   HRFD_HOOK_GATE("hrfd_rx_debug_expire");
-  if (h == nullptr || where < 0 || (where > 11 && where < 1000) || where > 10063)
+  // (12 .. 14 belong to build flags that are off; 15 is the shipped build's wait of a block b >= 16 for block b - 16's
+  //  magnitude slot, hrfd_rx_flow.hip kCtlBlk: ADVICE round 5)
+  if (h == nullptr || where < 0 || (where > 15 && where < 1000) || where > 10063)
   {
-    return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 11, or 1000 point + generation");
+    return fail(HRFD_EINVAL, "hrfd_rx_debug_expire: 0 (off) .. 15, or 1000 point + generation");
   }
   h->expire_once = where;
   return HRFD_OK;

@@ -646,7 +646,15 @@ struct Flow
 
   // The second half of the set-up: the channel's configuration, control words and carried pipelines into LDS, and the
   // kernel's only two workgroup barriers.  Every wave calls it exactly once: the service waves at their start, the stream
-  // waves in front of (or, -DHRFD_FLOW_EARLY=1, behind) the requests for their first unit
+  // waves in front of (or, -DHRFD_FLOW_EARLY=1, behind) the requests for their first unit.
+  // (the call sites differ between the two kinds of wave, which is outside what HIP promises for
+  //  __syncthreads() -- a barrier reached through different code paths.  It holds on gfx950 because s_barrier counts WAVES,
+  //  not call sites: the workgroup's barrier is released when every wave of the workgroup has executed one s_barrier,
+  //  whichever instruction address it sits at.  What must stay true, and is the whole contract here: every one of the 16
+  //  waves executes EXACTLY the two barriers of this function (GATED: and the one of setup() in front of it, which all
+  //  waves reach at the same place) and no other, no wave leaves the kernel in front of them
+  //  (the early exits of the body come behind setup_lds or are taken by the whole workgroup), and nothing between the
+  //  two barriers depends on the kind of wave.  A third barrier anywhere in Flow<> breaks it.)
   __device__ __forceinline__ void setup_lds()
   {
     cfg = P.cfg[c];

@@ -452,6 +452,12 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
   constexpr bool kPhase = (KIND == HRFD_MOD_FM_PHASE);   // the input is [C][n] float phases: Nco::run's cosf / sinf, x 16000, (int16_t) here
                                                          // (FmModulator.cc:600-612; rounds 1-4: a pass of its own, k_fm_rails, on a second stream)
   constexpr bool kMono = (KIND == HRFD_MOD_WB_HEAD);      // the input is the PCM itself, [C][n]: rail 0, rail 1 is zero (WbFmModulator.cc:389-425)
+#ifndef HRFD_MONO_ONE_RAIL
+#define HRFD_MONO_ONE_RAIL 1
+#endif
+  // (round 6: stages 1-5 of the WBFM head pass run the ONE rail there is -- until round 5 half of their threads interpolated
+  //  the zero rail, which nothing reads behind stage 0)
+  constexpr int kRails = (kMono && HRFD_MONO_ONE_RAIL) ? 1 : 2;
   const uint32_t tiles = (M.n + kModTile - 1) / kModTile;
   const uint32_t tiles_l = (M.tiles_launch != 0u) ? M.tiles_launch : tiles;
   // Workgroup ids go round the eight XCDs, each with an L2 of its own: XCD x takes the channels x, x + 8, ... and a
@@ -642,8 +648,8 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       constexpr const int16_t (&h)[40] = (KIND == HRFD_MOD_INTERP) ? Q_INTERPSIG_S1 : Q_AUDIO_D40;
       static_assert((kO0 + kH0 - kH1 / 2 - 19) >= 0 && (kRail % 2) == 0, "the dwords below");
       if (!(HRFD_MOD_ABLATE & 16))   // (TIMING EXPERIMENT ONLY when set)
-      wg_loop<2 * (kH1 / 2 + kModTile)>(tid, [&](const int t) {
-        const int rail = t & 1, u = t >> 1;
+      wg_loop<kRails * (kH1 / 2 + kModTile)>(tid, [&](const int t) {
+        const int rail = (kRails == 2) ? (t & 1) : 0, u = (kRails == 2) ? (t >> 1) : t;
         const int first = kO0 + kH0 + (u - kH1 / 2) - 19;   // index of x[n - 19]
         const uint32_t *w = reinterpret_cast<const uint32_t *>(&r[rail][first & ~1]);
         const uint32_t sh = (first & 1) ? 16u : 0u;
@@ -665,9 +671,9 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
     // ---- stages 2 (HB8) and 3 (HB3): one stage-1 position p per thread and rail -> s2[2p], s2[2p+1] in
     //      registers (and s2[2p-1], the cheap phase-1 value of the position before) -> s3[4p .. 4p+3]
     if (!(HRFD_MOD_ABLATE & 32))   // (TIMING EXPERIMENT ONLY when set)
-    wg_loop<2 * (kH3 / 4 + 2 * kModTile)>(tid, [&](const int t)
+    wg_loop<kRails * (kH3 / 4 + 2 * kModTile)>(tid, [&](const int t)
     {
-      const int rail = t & 1, u = t >> 1;
+      const int rail = (kRails == 2) ? (t & 1) : 0, u = (kRails == 2) ? (t >> 1) : t;
       // stage-1 index p = u - kH3/4, from -2; x[p-3 .. p] as two sample pairs out of three aligned dwords (shifted by
       // a sample where p - 3 is odd), the HB8 phase 0 as two v_dot2 (hb8_pair has the arithmetic)
       constexpr int kFirst = kO1 + kH1 - kH3 / 4 - 3;      // index of x[p - 3] for u = 0
@@ -692,9 +698,9 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
     __syncthreads();
     // ---- stage 4: HB8, outputs m in [-kH4, 16*tile); two stage-3 positions per thread and rail
     if (!(HRFD_MOD_ABLATE & 64))   // (TIMING EXPERIMENT ONLY when set)
-    wg_loop<2 * ((kH4 / 2 + 8 * kModTile) / 2)>(tid, [&](const int t)
+    wg_loop<kRails * ((kH4 / 2 + 8 * kModTile) / 2)>(tid, [&](const int t)
     {
-      const int rail = t & 1, u = t >> 1;                   // u: the input positions n = 2u - kH4/2 and n + 1
+      const int rail = (kRails == 2) ? (t & 1) : 0, u = (kRails == 2) ? (t >> 1) : t;   // u: the input positions n = 2u - kH4/2 and n + 1
       constexpr int kFirst = kO3 + kH3 - kH4 / 2 - 4;       // index of x[n - 4] for u = 0
       static_assert(kFirst >= kO3 && (kFirst % 2) == 0 && (kO4 % 2) == 0, "aligned dwords inside stage 3's outputs");
       const uint32_t *w = reinterpret_cast<const uint32_t *>(&r[rail][kFirst]) + u;
@@ -704,9 +710,9 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
     __syncthreads();
     // ---- stage 5: HB8, outputs m in [-kH5, 32*tile)
     if (!(HRFD_MOD_ABLATE & 128))   // (TIMING EXPERIMENT ONLY when set)
-    wg_loop<2 * ((kH5 / 2 + 16 * kModTile + 1) / 2)>(tid, [&](const int t)
+    wg_loop<kRails * ((kH5 / 2 + 16 * kModTile + 1) / 2)>(tid, [&](const int t)
     {
-      const int rail = t & 1, u = t >> 1;                   // the input positions n = 2u - kH5/2 - 1 (even) and n + 1
+      const int rail = (kRails == 2) ? (t & 1) : 0, u = (kRails == 2) ? (t >> 1) : t;   // the input positions n = 2u - kH5/2 - 1 (even) and n + 1
       constexpr int kFirst = kO4 + kH4 - kH5 / 2 - 1 - 4;   // index of x[n - 4] for u = 0: two samples in front of the stage's
       static_assert(kFirst >= 0 && (kFirst % 2) == 0 && ((kO5 + kH5) % 2) == 0, "aligned dwords in, aligned dwords out");   // history (they only reach the outputs of position -2, which are not kept)
       const uint32_t *w = reinterpret_cast<const uint32_t *>(&r[rail][kFirst]) + u;
@@ -730,11 +736,21 @@ __global__ __launch_bounds__(kModThreads) void k_mod(const ModParams M)
       uint32_t *cell = M.wbstep + ((size_t)c * M.n + t0) * 32;
       const float dev = M.param[c];
       const double two_pi = 6.283185307179586476925286766559;
-      for (int j = tid; j < valid32; j += kModThreads)
+      // (round 6: four consecutive cells per thread -- one 8-byte LDS read, one 16-byte store; until round 5 a dword each)
+      static_assert(((kO5 + kH5) % 4) == 0, "8-byte reads of stage 5's outputs");
+      for (int q = tid; q < valid32 / 4; q += kModThreads)
       {
-        float f = dev * (float)(int)r[0][kO5 + kH5 + j];
-        f = f / 1024.0f;
-        cell[j] = __builtin_bit_cast(uint32_t, div_then_float(two_pi * (double)f, 256000.0, 1.0 / 256000.0));
+        const uint2 x4 = *reinterpret_cast<const uint2 *>(&r[0][kO5 + kH5 + 4 * q]);
+        const int xs[4] = {(int)(int16_t)(x4.x & 0xffffu), (int)x4.x >> 16, (int)(int16_t)(x4.y & 0xffffu), (int)x4.y >> 16};
+        uint32_t st[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+          float f = dev * (float)xs[k];
+          f = f / 1024.0f;
+          st[k] = __builtin_bit_cast(uint32_t, div_then_float(two_pi * (double)f, 256000.0, 1.0 / 256000.0));
+        }
+        *reinterpret_cast<uint4 *>(cell + 4 * q) = make_uint4(st[0], st[1], st[2], st[3]);
       }
       return;
     }

@@ -533,6 +533,32 @@ def test_a_held_up_service_wave_is_not_overtaken(oracle, mode, point, gen):
             assert (got[c, b] == want[c][b][0]).all(), (c, b)
 
 
+def test_expired_block_slot_wait_is_replayed(oracle):
+    """wait 15 of the flow kernel -- a unit of block b >= 16 waits for block b - 16 to be finished before it
+    takes its magnitude slot (runs of more than 16 blocks: since round 5 up to 64) -- forced to expire: 40 blocks of the
+    shortest size (32 KiB: a stream wave reaches block 16 while block 0's sum is still out), one run per channel.  The
+    channel concerned is reported and not committed (or the wait was never polled: then everything committed), the
+    blocking entry replays it, and the PCM is the oracle's either way, over two calls."""
+    bb, B, C = 32768, 40, 3
+    need = (2 * B * bb + BLK - 1) // BLK
+    xs = np.stack([synth.make_input("fmtone", 700 + c, need)[:2 * B * bb].reshape(2 * B, bb) for c in range(C)])
+    rx = api.Rx(C)
+    rx.set_mode(api.WBFM)
+    rx.debug_set_run_len(64)
+    orc = []
+    for c in range(C):
+        o = oracle.rx(); o.set_mode(WBFM); orc.append(o)
+    for call in range(2):
+        rx.debug_expire(15)
+        x = xs[:, call * B:(call + 1) * B]
+        pcm, n_pcm, mag, allowed, _ = rx.process_block(x, B)
+        for c in range(C):
+            for b in range(B):
+                p, m, a, _ = orc[c].process(x[c, b])
+                assert n_pcm[c, b] == len(p) and int(mag[c, b]) == m, (call, c, b)
+                assert (pcm[c, b, :len(p)] == p).all(), (call, c, b)
+
+
 @pytest.mark.parametrize("run_len", [0, 16], ids=["several_runs_per_channel", "one_workgroup_per_channel"])
 @pytest.mark.parametrize("where", [3, 5, 6, 1])
 def test_expired_wait_fails_the_channel_and_is_replayed(oracle, where, run_len):
