@@ -1756,7 +1756,10 @@ struct WbTailParams
   uint32_t n, n_channels;   // input samples per channel
   uint32_t lo, len;         // the slice [lo, lo + len) of every channel in input samples (len 0: all)
 };
-constexpr int kWtThreads = 512;
+#ifndef HRFD_WT_THREADS
+#define HRFD_WT_THREADS 1024
+#endif
+constexpr int kWtThreads = HRFD_WT_THREADS;             // (1024: one table for sixteen waves, two workgroups per CU -- A/B in profiles/r6_*)
 constexpr uint32_t kWtRun = 32u * kModTile;               // cells per work item
 __global__ __launch_bounds__(kWtThreads) void k_wb_tail(const WbTailParams P)
 {
