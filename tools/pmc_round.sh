@@ -62,7 +62,8 @@ for d in sorted(glob.glob(O + "/raw_*_FETCH_SIZE")):
             continue
         # HRFD_BENCH_SETTLE=0: warm-up + timed steps are all the steps the bench ran -- plus, for the receive workloads, the
         # min(8, steps) single launches it samples behind the timed region (bench.measure_rx, round 5)
-        steps_total = STEPS + WARM + (0 if name.endswith(("mod_1024x16", "mod_8192x16")) else min(8, STEPS))
+        # (round 6: the modulator workloads sample min(4, steps) single calls behind theirs, bench.measure_mod)
+        steps_total = STEPS + WARM + (min(4, STEPS) if name.endswith(("mod_1024x16", "mod_8192x16")) else min(8, STEPS))
         tot = 0.0
         for k, v in sorted(acc.items()):
             per_step = len(v) / steps_total
