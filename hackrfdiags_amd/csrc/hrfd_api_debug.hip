@@ -351,11 +351,11 @@ extern "C" int hrfd_mod_debug_set_sliced(hrfd_mod *h, int on)
 extern "C" int hrfd_mod_debug_set_scan(hrfd_mod *h, int kind)
 {
   HRFD_HOOK_GATE("hrfd_mod_debug_set_scan");
-  if (h == nullptr || (kind != 0 && kind != 1))
+  if (h == nullptr || kind < 0 || kind > 2)
   {
-    return fail(HRFD_EINVAL, "hrfd_mod_debug_set_scan: kind 0 | 1");
+    return fail(HRFD_EINVAL, "hrfd_mod_debug_set_scan: kind 0 | 1 | 2");
   }
-  h->scan_kind = kind;
+  h->scan_kind = kind;                                      // (2, round 6: k_phase_rows -- four steps per lane -- where k_phase_rows8 would run)
   return HRFD_OK;
 }
 

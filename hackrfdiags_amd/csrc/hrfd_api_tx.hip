@@ -38,7 +38,7 @@ struct hrfd_mod
   bool cu_masked = false;               // the recurrence's stream has CUs of its own
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_head[kMaxSlices] = {}, ev_scan[kMaxSlices] = {};
   int sliced = 1;                        // test hook: 0 = one pass after the other on the caller's stream
-  int scan_kind = 0;                     // test hook: 1 = k_phase_scan<64> / k_phase_scan_plain whatever the bank size
+  int scan_kind = 0;                     // test hook: 1 = k_phase_scan<64> / k_phase_scan_plain whatever the bank size, 2 = k_phase_rows (four steps per lane) where k_phase_rows8 would run
   int wb_fused = HRFD_WB_FUSED;          // test hook: 0 = the lookup pass and the x8 cascade as two kernels (rounds 2-5), 1 = k_wb_tail
   // staging for the host entry
   int16_t *d_in = nullptr;
@@ -88,6 +88,9 @@ static void wb_tail_launch(hrfd_mod *h, const BaseParams &B0, const ModParams &T
   hipLaunchKernelGGL(k_mod<HRFD_MOD_WB_TAIL>, dim3(groups8 * tl), dim3(kModThreads), 0, s, T);
 }
 
+#ifndef HRFD_PHASE_ROWS8
+#define HRFD_PHASE_ROWS8 1
+#endif
 // the Nco phase recurrence over `steps` cells per channel, rows `row_stride` cells apart: k_phase_rows (four channels per
 // wave, a lone wave per SIMD up to 4096 channels, two up to 8192: the wave's time per step is the same; whole chunks of 64
 // steps, which every call and every time slice is); banks beyond that put more waves on a SIMD than that shape likes and
@@ -96,7 +99,16 @@ static void phase_scan(hrfd_mod *h, uint32_t *cells, size_t steps, size_t row_st
 {
   if (h->scan_kind != 1 && n_channels <= 8192u && (steps & 63) == 0 && row_stride < ((size_t)1 << 28))
   {
-    hipLaunchKernelGGL(k_phase_rows, dim3((n_channels + 15) / 16), dim3(kPrThreads), 0, s, cells, steps, row_stride, d_acc, n_channels);
+    // (round 6: eight steps per lane where the step count allows whole chunks of 128 -- every WBFM call and time slice;
+    //  scan_kind 2, a test hook, keeps the four-step kernel)
+    if (h->scan_kind != 2 && HRFD_PHASE_ROWS8 && (steps & 127) == 0)
+    {
+      hipLaunchKernelGGL(k_phase_rows8, dim3((n_channels + 15) / 16), dim3(kPrThreads), 0, s, cells, steps, row_stride, d_acc, n_channels);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_phase_rows, dim3((n_channels + 15) / 16), dim3(kPrThreads), 0, s, cells, steps, row_stride, d_acc, n_channels);
+    }
   }
   else if ((steps & 3) == 0 && (row_stride & 3) == 0)
   {

@@ -1621,6 +1621,251 @@ __global__ __launch_bounds__(kPrThreads) void k_phase_rows(uint32_t *cells, size
   }
 }
 
+// ---- round 6: the same arrangement with EIGHT steps per lane (chunks of 128 steps) ---------------------------------
+// A row of 16 lanes covers 128 steps, lane j the steps 8j .. 8j+7 as TWO coalesced 16-byte loads deliver them: the DPP hop
+// (two wait states and the slower operand path) comes once per eight steps instead of once per four, and the round's
+// steps are read straight out of the slot registers the loads put them in -- k_phase_rows copies them first (four moves per
+// chunk), because it reloads a slot in front of its rounds; here a slot is reloaded BEHIND them (seven chunks ahead instead
+// of eight: ~10 us of latency cover at 12 ns per step).  tools/ubench/phase_scan_rate.hip priced the hop at 0.65 ns of
+// the 12.15 ns a step takes; every caller whose step count is a multiple of 128 gets this kernel (the WBFM modulator's
+// calls and time slices: multiples of 2048), the others k_phase_rows.
+//   v[40:103] eight slots of eight     v112 .. v119 w0 .. w7     v120 x    v121 k    v122 x0    v[104:111] a refused chunk's steps
+//   s40 chunks done   s41 refused   s[42:43] address   s44 chunks - 1   s45 4.85f   s[46:47] lanes 0 .. 14 of every row
+//   s48 round counter   s[50:51] scratch   s[52:53] lane 15 of every row   s[54:55] the entry's exec mask
+// Memory operations behind the loads of the chunk that is due (they complete in order): the first turns 14 + 2 d (the
+// 7 - d chunks requested in front of the loop, two loads each, and two stores + two loads of every turn since), then 28.
+constexpr int kPr8Chunk = 128;
+#define HRFD_P8_WRAP(x, dst) \
+  "v_mul_f32 v121, 0x3e22f984, " x "\n" \
+  "v_rndne_f32 v121, v121\n" \
+  "v_fmamk_f32 " dst ", v121, 0xc0c90fdb, " x "\n" \
+  "v_fmac_f32 " dst ", 0x343bbd2e, v121\n"
+#define HRFD_P8_LANE(s1, s2, s3, s4, s5, s6, s7) \
+  HRFD_P8_WRAP("v122", "v112") \
+  "v_add_f32 v120, v112, " s1 "\n" HRFD_P8_WRAP("v120", "v113") \
+  "v_add_f32 v120, v113, " s2 "\n" HRFD_P8_WRAP("v120", "v114") \
+  "v_add_f32 v120, v114, " s3 "\n" HRFD_P8_WRAP("v120", "v115") \
+  "v_add_f32 v120, v115, " s4 "\n" HRFD_P8_WRAP("v120", "v116") \
+  "v_add_f32 v120, v116, " s5 "\n" HRFD_P8_WRAP("v120", "v117") \
+  "v_add_f32 v120, v117, " s6 "\n" HRFD_P8_WRAP("v120", "v118") \
+  "v_add_f32 v120, v118, " s7 "\n" HRFD_P8_WRAP("v120", "v119")
+#define HRFD_P8_ROUND(s0, s1, s2, s3, s4, s5, s6, s7) \
+  "s_nop 1\n" \
+  "v_add_f32_dpp v122, v119, " s0 " row_shr:1 row_mask:0xf bank_mask:0xf\n" HRFD_P8_LANE(s1, s2, s3, s4, s5, s6, s7)
+#define HRFD_P8_ADDR(chunk_sgpr_or_const) \
+  "s_min_u32 s42, " chunk_sgpr_or_const ", s44\n" \
+  "s_lshl_b32 s42, s42, 9\n" \
+  "s_add_u32 s42, %[b0], s42\n" \
+  "s_addc_u32 s43, %[b1], 0\n"
+#define HRFD_P8_CHECK(sa, sb) \
+  "v_cmp_nle_f32_e64 s[50:51], |" sa "|, s45\n" \
+  "s_or_b64 vcc, vcc, s[50:51]\n" \
+  "v_cmp_nle_f32_e64 s[50:51], |" sb "|, s45\n" \
+  "s_or_b64 vcc, vcc, s[50:51]\n"
+#define HRFD_P8_TURN(lo, hi, s0, s1, s2, s3, s4, s5, s6, s7, behind) \
+  "s_cmp_ge_u32 s40, %[n]\n" \
+  "s_cbranch_scc1 9f\n" \
+  "s_waitcnt vmcnt(" behind ")\n" \
+  "s_mov_b64 vcc, 0\n" \
+  HRFD_P8_CHECK(s0, s1) HRFD_P8_CHECK(s2, s3) HRFD_P8_CHECK(s4, s5) HRFD_P8_CHECK(s6, s7) \
+  "s_cbranch_vccz 1f\n" \
+  "v_mov_b32 v104, " s0 "\n" "v_mov_b32 v105, " s1 "\n" "v_mov_b32 v106, " s2 "\n" "v_mov_b32 v107, " s3 "\n" \
+  "v_mov_b32 v108, " s4 "\n" "v_mov_b32 v109, " s5 "\n" "v_mov_b32 v110, " s6 "\n" "v_mov_b32 v111, " s7 "\n" \
+  "s_mov_b32 s41, 1\n" \
+  "s_branch 9f\n" \
+  "1:\n" \
+  "v_add_f32_dpp v122, v119, " s0 " row_ror:1 row_mask:0xf bank_mask:0xf\n" HRFD_P8_LANE(s1, s2, s3, s4, s5, s6, s7) \
+  "s_mov_b32 s48, 5\n" \
+  "2:\n" \
+  HRFD_P8_ROUND(s0, s1, s2, s3, s4, s5, s6, s7) HRFD_P8_ROUND(s0, s1, s2, s3, s4, s5, s6, s7) HRFD_P8_ROUND(s0, s1, s2, s3, s4, s5, s6, s7) \
+  "s_sub_u32 s48, s48, 1\n" \
+  "s_cmp_lg_u32 s48, 0\n" \
+  "s_cbranch_scc1 2b\n" \
+  "s_lshl_b32 s42, s40, 9\n" \
+  "s_add_u32 s42, %[b0], s42\n" \
+  "s_addc_u32 s43, %[b1], 0\n" \
+  "s_add_u32 s40, s40, 1\n" \
+  "s_cmp_eq_u32 s40, %[n]\n" \
+  "s_cbranch_scc1 3f\n" \
+  "global_store_dwordx4 %[voff], v[112:115], s[42:43] offset:4\n" \
+  "global_store_dwordx4 %[voff], v[116:119], s[42:43] offset:20\n" \
+  "s_branch 4f\n" \
+  "3:\n" \
+  "s_mov_b64 exec, s[46:47]\n" \
+  "global_store_dwordx4 %[voff], v[112:115], s[42:43] offset:4\n" \
+  "global_store_dwordx4 %[voff], v[116:119], s[42:43] offset:20\n" \
+  "s_mov_b64 exec, s[52:53]\n" \
+  "global_store_dwordx4 %[voff], v[112:115], s[42:43] offset:4\n" \
+  "global_store_dwordx3 %[voff], v[116:118], s[42:43] offset:20\n" \
+  "s_mov_b64 exec, s[54:55]\n" \
+  "4:\n" \
+  "s_add_u32 s42, s40, 7\n" HRFD_P8_ADDR("s42") \
+  "global_load_dwordx4 " lo ", %[voff], s[42:43]\n" \
+  "global_load_dwordx4 " hi ", %[voff], s[42:43] offset:16\n"
+
+// w: the accumulator in front of the run in (lane 15 of the row counts), the one behind the last chunk done out.  Returns
+// the chunks done; refused: the next one holds a step the branch-free wrap is not proven for, `held` are its steps.
+__device__ __forceinline__ uint32_t pr_pipeline8(float &w, float (&held)[8], bool &refused, const uint32_t voff, const uint32_t *wbase, const uint32_t nchunks)
+{
+  const uint64_t b = (uint64_t)(uintptr_t)wbase;
+  const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)nchunks);
+  uint32_t done, flag;
+#define HRFD_P8_T(A, B, C, D, E, F, G, H, behind) \
+  HRFD_P8_TURN("v[" #A ":" #D "]", "v[" #E ":" #H "]", "v" #A, "v" #B, "v" #C, "v" #D, "v" #E, "v" #F, "v" #G, "v" #H, behind)
+  asm volatile(
+      "s_mov_b64 s[54:55], exec\n"
+      "s_mov_b32 s40, 0\n"
+      "s_mov_b32 s41, 0\n"
+      "s_sub_u32 s44, %[n], 1\n"
+      "s_mov_b32 s45, 0x409b3333\n"
+      "s_mov_b32 s46, 0x7fff7fff\n"
+      "s_mov_b32 s47, 0x7fff7fff\n"
+      "s_mov_b32 s52, 0x80008000\n"
+      "s_mov_b32 s53, 0x80008000\n"
+      "v_mov_b32 v119, %[w]\n"
+      "s_nop 4\n"
+      HRFD_P8_ADDR("0") "global_load_dwordx4 v[40:43], %[voff], s[42:43]\n" "global_load_dwordx4 v[44:47], %[voff], s[42:43] offset:16\n"
+      HRFD_P8_ADDR("1") "global_load_dwordx4 v[48:51], %[voff], s[42:43]\n" "global_load_dwordx4 v[52:55], %[voff], s[42:43] offset:16\n"
+      HRFD_P8_ADDR("2") "global_load_dwordx4 v[56:59], %[voff], s[42:43]\n" "global_load_dwordx4 v[60:63], %[voff], s[42:43] offset:16\n"
+      HRFD_P8_ADDR("3") "global_load_dwordx4 v[64:67], %[voff], s[42:43]\n" "global_load_dwordx4 v[68:71], %[voff], s[42:43] offset:16\n"
+      HRFD_P8_ADDR("4") "global_load_dwordx4 v[72:75], %[voff], s[42:43]\n" "global_load_dwordx4 v[76:79], %[voff], s[42:43] offset:16\n"
+      HRFD_P8_ADDR("5") "global_load_dwordx4 v[80:83], %[voff], s[42:43]\n" "global_load_dwordx4 v[84:87], %[voff], s[42:43] offset:16\n"
+      HRFD_P8_ADDR("6") "global_load_dwordx4 v[88:91], %[voff], s[42:43]\n" "global_load_dwordx4 v[92:95], %[voff], s[42:43] offset:16\n"
+      HRFD_P8_ADDR("7") "global_load_dwordx4 v[96:99], %[voff], s[42:43]\n" "global_load_dwordx4 v[100:103], %[voff], s[42:43] offset:16\n"
+      HRFD_P8_T(40, 41, 42, 43, 44, 45, 46, 47, "14") HRFD_P8_T(48, 49, 50, 51, 52, 53, 54, 55, "16")
+      HRFD_P8_T(56, 57, 58, 59, 60, 61, 62, 63, "18") HRFD_P8_T(64, 65, 66, 67, 68, 69, 70, 71, "20")
+      HRFD_P8_T(72, 73, 74, 75, 76, 77, 78, 79, "22") HRFD_P8_T(80, 81, 82, 83, 84, 85, 86, 87, "24")
+      HRFD_P8_T(88, 89, 90, 91, 92, 93, 94, 95, "26") HRFD_P8_T(96, 97, 98, 99, 100, 101, 102, 103, "28")
+      "8:\n"
+      HRFD_P8_T(40, 41, 42, 43, 44, 45, 46, 47, "28") HRFD_P8_T(48, 49, 50, 51, 52, 53, 54, 55, "28")
+      HRFD_P8_T(56, 57, 58, 59, 60, 61, 62, 63, "28") HRFD_P8_T(64, 65, 66, 67, 68, 69, 70, 71, "28")
+      HRFD_P8_T(72, 73, 74, 75, 76, 77, 78, 79, "28") HRFD_P8_T(80, 81, 82, 83, 84, 85, 86, 87, "28")
+      HRFD_P8_T(88, 89, 90, 91, 92, 93, 94, 95, "28") HRFD_P8_T(96, 97, 98, 99, 100, 101, 102, 103, "28")
+      "s_branch 8b\n"
+      "9:\n"
+      "s_waitcnt vmcnt(0)\n"                                // (requests behind the end repeat the last chunk: they land in the slots)
+      "v_mov_b32 %[w], v119\n"
+      "v_mov_b32 %[h0], v104\n"
+      "v_mov_b32 %[h1], v105\n"
+      "v_mov_b32 %[h2], v106\n"
+      "v_mov_b32 %[h3], v107\n"
+      "v_mov_b32 %[h4], v108\n"
+      "v_mov_b32 %[h5], v109\n"
+      "v_mov_b32 %[h6], v110\n"
+      "v_mov_b32 %[h7], v111\n"
+      "s_mov_b32 %[done], s40\n"
+      "s_mov_b32 %[flag], s41\n"
+      : [w] "+v"(w), [h0] "=&v"(held[0]), [h1] "=&v"(held[1]), [h2] "=&v"(held[2]), [h3] "=&v"(held[3]), [h4] "=&v"(held[4]),
+        [h5] "=&v"(held[5]), [h6] "=&v"(held[6]), [h7] "=&v"(held[7]), [done] "=&s"(done), [flag] "=&s"(flag)
+      : [voff] "v"(voff), [b0] "s"(b0), [b1] "s"(b1), [n] "s"(n)
+      : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s51", "s52", "s53", "s54", "s55",
+        "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+        "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+        "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99",
+        "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
+        "v117", "v118", "v119", "v120", "v121", "v122");
+#undef HRFD_P8_T
+  refused = flag != 0u;
+  return done;
+}
+#undef HRFD_P8_TURN
+#undef HRFD_P8_CHECK
+#undef HRFD_P8_ADDR
+#undef HRFD_P8_ROUND
+#undef HRFD_P8_LANE
+#undef HRFD_P8_WRAP
+
+// steps: a multiple of 128.  Everything else as k_phase_rows (runs, refused chunks through the reference's loops, a run
+// writes exactly its own cells).
+__global__ __launch_bounds__(kPrThreads) void k_phase_rows8(uint32_t *cells, size_t steps, size_t row_stride, float *acc_io, uint32_t n_channels)
+{
+  const int j = threadIdx.x & 15;
+  const uint32_t cw = blockIdx.x * (uint32_t)(kPrThreads / 16) + 4u * (threadIdx.x >> 6);     // the wave's first channel
+  const uint32_t nchunks = (uint32_t)(steps / kPr8Chunk);
+  if (nchunks == 0u || cw >= n_channels)
+  {
+    return;
+  }
+  const uint32_t c = min(cw + ((threadIdx.x >> 4) & 3u), n_channels - 1u);
+  const uint32_t *wbase = cells + (size_t)cw * row_stride;
+  const uint32_t voff = (uint32_t)(((size_t)(c - cw) * row_stride + 8u * (size_t)j) * 4u);
+  uint32_t *row = cells + (size_t)c * row_stride + 8u * (size_t)j;   // the lane's eight cells of chunk 0
+  float w = acc_io[c];
+  uint32_t i = 0;
+  bool wild = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(w) <= 3.1415927f)) != 0ull;
+  auto carry_of = [&]() -> float {
+    float cr;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:1 row_mask:0xf bank_mask:0xf" : "=v"(cr) : "v"(w));
+    return cr;
+  };
+  auto loops_chunk = [&](const float (&cur)[8]) {
+    const float carry = carry_of();
+    float x0, v[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    pr_add<true>(x0, w, cur[0]);
+#pragma nounroll
+    for (int t = 0; t < 16; t++)
+    {
+      if (t != 0)
+      {
+        pr_add<false>(x0, w, cur[0]);
+      }
+      v[0] = ps_wrap_loops(x0);
+#pragma unroll
+      for (int k = 1; k < 7; k++)
+      {
+        v[k] = ps_wrap_loops(v[k - 1] + cur[k]);
+      }
+      w = ps_wrap_loops(v[6] + cur[7]);
+    }
+    uint32_t *cell = row + (size_t)kPr8Chunk * i;
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+    {
+      cell[1 + k] = __builtin_bit_cast(uint32_t, v[k]);
+    }
+    if (j != 15)
+    {
+      cell[8] = __builtin_bit_cast(uint32_t, w);
+    }
+    if (j == 0)
+    {
+      cell[0] = __builtin_bit_cast(uint32_t, carry);
+    }
+    i++;
+    wild = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(w) <= 3.1415927f)) != 0ull;
+  };
+#pragma nounroll
+  while (i < nchunks)
+  {
+    if (wild)
+    {
+      const uint4 q0 = *reinterpret_cast<const uint4 *>(row + (size_t)kPr8Chunk * i), q1 = *reinterpret_cast<const uint4 *>(row + (size_t)kPr8Chunk * i + 4);
+      const float cur[8] = {__builtin_bit_cast(float, q0.x), __builtin_bit_cast(float, q0.y), __builtin_bit_cast(float, q0.z), __builtin_bit_cast(float, q0.w),
+                            __builtin_bit_cast(float, q1.x), __builtin_bit_cast(float, q1.y), __builtin_bit_cast(float, q1.z), __builtin_bit_cast(float, q1.w)};
+      loops_chunk(cur);
+      continue;
+    }
+    const float carry = carry_of();
+    const uint32_t i0 = i;
+    float held[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    bool refused = false;
+    i += pr_pipeline8(w, held, refused, voff, wbase + (size_t)kPr8Chunk * i0, nchunks - i0);
+    if (i != i0 && j == 0)
+    {
+      row[(size_t)kPr8Chunk * i0] = __builtin_bit_cast(uint32_t, carry);
+    }
+    if (i < nchunks)
+    {
+      loops_chunk(held);                                  // (refused: a step above 4.85)
+    }
+  }
+  if (j == 15)
+  {
+    acc_io[c] = w;
+  }
+}
+
 // the same recurrence for a cell count that is not a multiple of four (no 16-byte pieces): one thread per channel,
 // straight from memory
 __global__ void k_phase_scan_plain(uint32_t *cells, size_t steps, size_t row_stride, float *acc_io, uint32_t n_channels)

@@ -56,7 +56,7 @@ int hrfd_rx_debug_set_fir_flow(hrfd_rx *h, int mode);    /* FIR modes: -1 automa
 int hrfd_rx_debug_set_gated(hrfd_rx *h, int on);         /* 0: no gated pass on the device (host replay instead) */
 int hrfd_rx_debug_set_stagger(hrfd_rx *h, int units);
 int hrfd_mod_debug_set_sliced(hrfd_mod *h, int on);      /* WBFM modulator: 0 unsliced, 1 automatic, 2 always sliced */
-int hrfd_mod_debug_set_scan(hrfd_mod *h, int kind);      /* FM / WBFM modulators: 1 = the phase recurrence on k_phase_scan<64> (0: k_phase_rows) */
+int hrfd_mod_debug_set_scan(hrfd_mod *h, int kind);      /* FM / WBFM modulators: the phase recurrence on 0 = k_phase_rows8 / k_phase_rows, 1 = k_phase_scan<64>, 2 = k_phase_rows */
 int hrfd_mod_debug_set_tail(hrfd_mod *h, int kind);      /* WBFM modulator: 0 = k_wb_rails + k_mod<WB_TAIL> (rounds 2-5), 1 = k_wb_tail (one pass) */
 
 #ifdef __cplusplus

@@ -255,17 +255,19 @@ def test_phase_recurrence_kernels_agree(oracle, kind, C):
     mk = api.MOD_FM if kind == "fm" else api.MOD_WBFM
     n = 1024 + 512
     pcm = np.stack([synth.lcg_pcm(300 + c, 2 * n) for c in range(C)])
-    a, b = api.Mod(mk, C), api.Mod(mk, C)
+    a, b, d = api.Mod(mk, C), api.Mod(mk, C), api.Mod(mk, C)
     b.debug_set_scan(1)
+    d.debug_set_scan(2)                                     # round 6: a is k_phase_rows8 (eight steps per lane) for WBFM, d the four-step kernel
     os_ = [getattr(oracle, kind + "mod")() for _ in range(C)]
     if kind == "wbfm" and C >= 3:
-        a.set_param(1.5e6, channel=C - 2)
-        b.set_param(1.5e6, channel=C - 2)
+        for m in (a, b, d):
+            m.set_param(1.5e6, channel=C - 2)
         os_[C - 2].set_param(1.5e6)
     for call in range(2):
         x = pcm[:, call * n:(call + 1) * n]
-        ga, gb = np.atleast_2d(a.process(x)), np.atleast_2d(b.process(x))
+        ga, gb, gd = np.atleast_2d(a.process(x)), np.atleast_2d(b.process(x)), np.atleast_2d(d.process(x))
         assert (ga == gb).all(), call
+        assert (ga == gd).all(), call
         for c in range(C):
             want = os_[c].process(x[c])
             assert (ga[c] == want).all(), (call, c)
