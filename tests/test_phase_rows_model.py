@@ -1,4 +1,4 @@
-"""k_phase_rows' arrangement, modelled on the CPU (numpy, float32 with exactly rounded fused multiply-adds): the Nco phase
+"""k_phase_rows' arrangement (and, round 6, k_phase_rows8's: eight steps per lane), modelled on the CPU (numpy, float32 with exactly rounded fused multiply-adds): the Nco phase
 recurrence (PhaseAccumulator.cc:157-181) with lane = TIME.  A channel is a row of 16 lanes, lane j holds steps 4j .. 4j+3
 of a chunk of 64; in each of sixteen rounds EVERY lane computes x0 = (w3 of its left neighbour) + step0 -- lane 0 keeps the
 x0 a rotate gave it from the chunk in front -- and then four wrapped accumulations in its own registers.  The claim the
@@ -42,47 +42,53 @@ def serial(acc, steps):
     return out, acc
 
 
-def rows_chunk(w3, cur, garbage):
-    """one chunk of 64 steps on a row of 16 lanes.  w3: the lanes' w3 registers on entry (lane 15 = the accumulator in
-    front of the chunk, the others whatever the last chunk left); cur[lane][r]: the steps; garbage: what w0..w2 and x0 hold
-    on entry (anything).  Returns the four w registers per lane after sixteen rounds."""
-    w = garbage.copy()                                      # [16][4]
-    w[:, 3] = w3
-    x0 = np.roll(w[:, 3], 1) + cur[:, 0]                    # row_ror:1 add: every lane written, lane 0 from lane 15
+def rows_chunk(wl, cur, garbage):
+    """one chunk of 16 S steps on a row of 16 lanes, S = cur.shape[1] steps per lane (k_phase_rows: 4, k_phase_rows8, round 6:
+    8).  wl: the lanes' LAST w registers on entry (lane 15 = the accumulator in front of the chunk, the others whatever the
+    last chunk left); cur[lane][r]: the steps; garbage: what the other w registers and x0 hold on entry (anything).  Returns
+    the S w registers per lane after sixteen rounds."""
+    S = cur.shape[1]
+    w = garbage.copy()                                      # [16][S]
+    w[:, S - 1] = wl
+    x0 = np.roll(w[:, S - 1], 1) + cur[:, 0]                # row_ror:1 add: every lane written, lane 0 from lane 15
     for t in range(16):
         if t:
-            shifted = np.roll(w[:, 3], 1) + cur[:, 0]       # row_shr:1 add ...
+            shifted = np.roll(w[:, S - 1], 1) + cur[:, 0]   # row_shr:1 add ...
             x0[1:] = shifted[1:]                            # ... lane 0 has no source and keeps its x0
         w[:, 0] = wrap_fast(x0)
-        w[:, 1] = wrap_fast(w[:, 0] + cur[:, 1])
-        w[:, 2] = wrap_fast(w[:, 1] + cur[:, 2])
-        w[:, 3] = wrap_fast(w[:, 2] + cur[:, 3])
+        for r in range(1, S):
+            w[:, r] = wrap_fast(w[:, r - 1] + cur[:, r])
     return w
 
 
-def test_rows_arrangement_equals_the_serial_recurrence():
-    rng = np.random.default_rng(7)
+import pytest
+
+
+@pytest.mark.parametrize("S", [4, 8], ids=["k_phase_rows", "k_phase_rows8"])
+def test_rows_arrangement_equals_the_serial_recurrence(S):
+    rng = np.random.default_rng(7 + S)
+    n = 16 * S
     for trial in range(40):
         nchunks = int(rng.integers(1, 6))
-        steps = (rng.uniform(-4.85, 4.85, size=64 * nchunks)).astype(F)
+        steps = (rng.uniform(-4.85, 4.85, size=n * nchunks)).astype(F)
         if trial % 3 == 0:
             steps[rng.integers(0, steps.size, size=steps.size // 3)] = F(0)
         acc0 = F(rng.uniform(-3.14, 3.14))
         want, want_acc = serial(acc0, steps)
         got = np.empty_like(want)
-        w3 = np.full(16, acc0, dtype=F)                     # every lane of the row: the phase of cell 0
-        garbage = rng.uniform(-50, 50, size=(16, 4)).astype(F)
+        wl = np.full(16, acc0, dtype=F)                     # every lane of the row: the phase of cell 0
+        garbage = rng.uniform(-50, 50, size=(16, S)).astype(F)
         for i in range(nchunks):
-            cur = steps[64 * i:64 * (i + 1)].reshape(16, 4)
-            carry = w3[15]
-            w = rows_chunk(w3, cur, garbage)
-            # lane j's w0 .. w3 are the phases of cells 4j+1 .. 4j+4: one cell to the right; cell 0 is the carry
+            cur = steps[n * i:n * (i + 1)].reshape(16, S)
+            carry = wl[15]
+            w = rows_chunk(wl, cur, garbage)
+            # lane j's w0 .. w(S-1) are the phases of cells S j + 1 .. S j + S: one cell to the right; cell 0 is the carry
             flat = w.reshape(-1)
-            got[64 * i] = carry
-            got[64 * i + 1:64 * (i + 1)] = flat[:63]
-            w3, garbage = w[:, 3].copy(), w.copy()
+            got[n * i] = carry
+            got[n * i + 1:n * (i + 1)] = flat[:n - 1]
+            wl, garbage = w[:, S - 1].copy(), w.copy()
         assert got.tobytes() == want.tobytes(), trial
-        assert w3[15].tobytes() == want_acc.tobytes(), trial
+        assert wl[15].tobytes() == want_acc.tobytes(), trial
 
 
 def test_branch_free_wrap_equals_the_loops_where_the_kernel_uses_it():
