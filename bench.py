@@ -1066,7 +1066,7 @@ def multi_gpu_legs(api, shard, device, dist, args, r_excl, C, B, settle, rank, w
         C4 = 4096 // world
         r4 = measure_rx(api, shard, device, dist, C=C4, scatter=False, **common)
         out["config4"] = {"workload": f"BASELINE config 4: 4096 WBFM channels over {world} GPU(s), {C4} per GPU x {B} blocks "
-                                      "(STRONG scaling: the N = 1 point is `also.wbfm_4096x16` of the one-GPU line)",
+                                      "(STRONG scaling: the N = 1 point is `configs.wbfm_4096x16` of the one-GPU line)",
                           "scaling": "strong", "kernel_ms_mean": round(r4["mean_ms"], 4), **legs(C4, r4)}
     return out
 
@@ -1178,7 +1178,7 @@ def main():
     C, B = args.channels, args.blocks
     # The clock governor needs ~25 ms of this load before it holds its clock (profiles/README.md): when
     # the caller asks for a short warm-up, untimed "settle" launches come first so that the K timed
-    # steps are measured at the clock a long-running stream sees, whatever W is.  (`also.wbfm_256x16_unsettled`
+    # steps are measured at the clock a long-running stream sees, whatever W is.  (`configs.wbfm_256x16_unsettled`
     # is the figure without them.)
     settle = max(0, SETTLE_STEPS - args.warmup)
     r = measure_rx(api, shard, device, dist, workload=args.workload, C=C, B=B, signal=args.signal, steps=args.steps,
