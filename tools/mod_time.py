@@ -4,7 +4,7 @@ usage: python tools/mod_time.py KIND [C] [B] [reps] [warm]   KIND: ssb | interp 
 (A/B: alternate `HRFD_LIB=.../variants/NAME/libhrfd.so python tools/mod_time.py ...` on ONE box: tools/mod_ab.sh.)"""
 import os, sys, zlib
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
-if os.environ.get("HRFD_MOD_TAIL") or os.environ.get("HRFD_MOD_SCAN"):
+if os.environ.get("HRFD_MOD_TAIL") or os.environ.get("HRFD_MOD_SCAN") or os.environ.get("HRFD_MOD_SLICED"):
     os.environ["HRFD_DEBUG_HOOKS"] = "1"               # (read once by the library: before it is loaded)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -27,6 +27,8 @@ if os.environ.get("HRFD_MOD_TAIL"):
     m.debug_set_tail(int(os.environ["HRFD_MOD_TAIL"]))   # WBFM: 0 = k_wb_rails + k_mod<WB_TAIL>, 1 = k_wb_tail
 if os.environ.get("HRFD_MOD_SCAN"):
     m.debug_set_scan(int(os.environ["HRFD_MOD_SCAN"]))   # FM / WBFM: 0 = k_phase_rows8 / rows, 1 = k_phase_scan<64>, 2 = k_phase_rows
+if os.environ.get("HRFD_MOD_SLICED"):
+    m.debug_set_sliced(int(os.environ["HRFD_MOD_SLICED"]))   # FM / WBFM: 0 = one pass after the other, 1 = automatic, 2 = always sliced
 st = torch.cuda.Stream(device=dev)
 for _ in range(warm):
     m.process_device(pcm.data_ptr(), n, out.data_ptr(), stream=st.cuda_stream)
