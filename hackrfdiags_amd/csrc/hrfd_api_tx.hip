@@ -518,8 +518,12 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
       // front is) and halve at the end (a slice's rails and tail are through before the next, shorter recurrence is);
       // what stays exposed is the first slice's head pass and the last slice's rails and tail, so those two slices
       // are two tiles long.  Every slice costs the recurrence a launch (~20 us).
-      static_assert(kModTile == 64, "slice lengths below are in tiles of 64 samples");
-      const uint32_t nt = (n_per_channel + kModTile - 1) / kModTile;
+      // (round 6: the lengths below are in UNITS of 64 samples whatever the cascade's tile -- 64 until round 5, 128 now --
+      //  and every one of them is even, so a cut is a multiple of 128 samples: a whole tile, and a whole chunk of
+      //  k_phase_rows8's 128 steps x 32)
+      constexpr uint32_t kUnit = 64u;
+      static_assert(kModTile == 64 || kModTile == 128, "the cuts below fall on multiples of 128 samples");
+      const uint32_t nt = ((n_per_channel + kUnit - 1) / kUnit) & ~1u;   // (even; the last slice ends with the call whatever is left)
       std::vector<uint32_t> lens;
       if (nt > 24)
       {
@@ -535,7 +539,8 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
         while (mid != 0u)
         {
           const uint32_t k = (mid + piece - 1u) / piece;        // pieces still to go: even shares
-          const uint32_t len = (mid + k - 1u) / k;
+          uint32_t len = (mid + k - 1u) / k;
+          len = std::min(mid, (len + 1u) & ~1u);                // (an even number of units: see above; the last piece takes what is left)
           lens.push_back(len);
           mid -= len;
         }
@@ -544,7 +549,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
       uint32_t lo = 0;
       for (size_t k = 0; k + 1 < lens.size(); k++)
       {
-        lo += lens[k] * kModTile;
+        lo += lens[k] * kUnit;
         cuts.push_back(lo);
       }
       cuts.push_back(n_per_channel);                          // (the last slice ends with the call, whole tile or not)
@@ -646,7 +651,7 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
       // k + 1 run on a stream of their own beside the cascade of slice k.  What stays exposed is the first slice's
       // recurrence and rails.  (Round 3 ran the four passes one after the other: the recurrence's 0.14 ms and the rails'
       // 0.04 sat in front of the cascade's 0.81.)
-      const uint32_t nt = tiles;
+      const uint32_t nt = (n_per_channel + 63u) / 64u;          // (units of 64 samples, whatever the cascade's tile: round 6)
       const bool fm_sliced = h->sliced != 0 && nt >= 64u && h->s_scan != nullptr;
       if (!fm_sliced)
       {
@@ -675,8 +680,8 @@ extern "C" int hrfd_mod_process_device(hrfd_mod *h, const int16_t *d_pcm, uint32
         // 36-tile slice instead of 49, whatever the stream's priority).  This way slice k + 1's recurrence is resident
         // before the cascade of slice k starts (its event takes ~13 us to cross queues): timeline of a step in
         // profiles/r4_fmmod_timeline.txt.  Exposed: two event hops, the first slice's recurrence and rails.
-        const uint32_t l0 = std::max(8u, nt / 16u), l1 = std::min(3u * l0 + l0 / 2u, nt - l0 - 1u);
-        const uint32_t cut[4] = {0u, l0 * kModTile, (l0 + l1) * kModTile, n_per_channel};
+        const uint32_t l0 = (std::max(8u, nt / 16u) + 1u) & ~1u, l1 = std::min(3u * l0 + l0 / 2u, nt - l0 - 2u) & ~1u;   // (even: cuts on whole tiles of 64 or 128)
+        const uint32_t cut[4] = {0u, l0 * 64u, (l0 + l1) * 64u, n_per_channel};
         hipLaunchKernelGGL(k_fm_step, dim3(gs), dim3(256), 0, s, B);
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(h->s_scan, h->ev_fork, 0));
